@@ -1,0 +1,58 @@
+"""Shared test helpers: golden-fixture loading, config objects, the tolerance rule."""
+import glob
+import os
+from types import SimpleNamespace as NS
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def make_cfg(C, T, V, dropout=0.0, To=25):
+    """Attribute-style config with the schema of the reference YAML (train_h36m.yaml:1-28)."""
+    arch = NS(model_params=NS(
+        input_n=T, output_n=To, joints=V, n_txcnn_layers=4, txc_kernel_size=3, reduction=8,
+        hidden_dim=64, clipping=15,
+        input_gcn=NS(model_complexity=[C] * 4, interpretable=[True] * 5),
+        output_gcn=NS(model_complexity=[3], interpretable=[True])))
+    return arch, NS(dropout=dropout)
+
+
+_cache = {}
+
+
+def load_case(name):
+    if name not in _cache:
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        _cache[name] = {k: z[k] for k in z.files}
+    return _cache[name]
+
+
+def state_of(rec):
+    return {k[len("state/"):]: torch.from_numpy(v.copy()) for k, v in rec.items() if k.startswith("state/")}
+
+
+def tol_ok(a, ref, rel=1e-4, floor=1.0):
+    """SURVEY §7 rule: max|a-b| <= 1e-4 * max(floor, max|ref|) per tensor (fp32 north_star tolerance)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    err = float(np.abs(a - ref).max()) if a.size else 0.0
+    bound = rel * max(floor, float(np.abs(ref).max()) if ref.size else 0.0)
+    return err <= bound, err, bound
+
+
+def assert_close(a, ref, what, rel=1e-4, floor=1.0):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    if isinstance(ref, torch.Tensor):
+        ref = ref.detach().cpu().numpy()
+    ok, err, bound = tol_ok(a, ref, rel, floor)
+    assert ok, "%s: max err %.3e > bound %.3e" % (what, err, bound)
+
+
+def grad_summary(g):
+    f = g.detach().cpu().flatten().double()
+    return np.concatenate([[f.sum().item(), f.abs().sum().item(), f.norm().item()], f[:61].numpy()])
