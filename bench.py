@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sequences/sec of forward + MPJPE + backward of CIST-GCN on synthetic
+H3.6M-shaped poses (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch resident in HBM: forward, loss, backward and, for
+N > 1, the gather of all gradients into the flat buffer plus its RCCL all-reduce.  No optimizer,
+no logging, no H2D.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace as NS
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# name -> (C, B per GPU, T_in, V); T_out = 25 everywhere
+WORKLOADS = {
+    "cistgcn8_b16_t50_v22": (8, 16, 50, 22),      # BASELINE.json configs[1] (default)
+    "cistgcn64_b256_t50_v22": (64, 256, 50, 22),  # configs[2] / per-GPU shard of configs[3]
+    "cistgcn32_b256_t50_v25": (32, 256, 50, 25),  # configs[4] shape
+    "cistgcn8_b16_t10_v22": (8, 16, 10, 22),      # reference-YAML frames
+    "cistgcn64_b256_t10_v22": (64, 256, 10, 22),
+    "cistgcn32_b256_t10_v18": (32, 256, 10, 18),  # reference AMASS joints
+}
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_cfg(C, T, V, dropout):
+    arch = NS(model_params=NS(input_n=T, output_n=25, joints=V, n_txcnn_layers=4, txc_kernel_size=3, reduction=8,
+                              hidden_dim=64, clipping=15,
+                              input_gcn=NS(model_complexity=[C] * 4, interpretable=[True] * 5),
+                              output_gcn=NS(model_complexity=[3], interpretable=[True])))
+    return arch, NS(dropout=dropout)
+
+
+def synth(B, T, V, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = 50 + 350 * torch.randn(B, T, V, 3, generator=g)
+    tgt = x[:, -1:] + 20 * torch.randn(B, 25, V, 3, generator=g)
+    return x, tgt
+
+
+def domain_shapes(C, T, V, To=25):
+    """(Cin, Cout, T, V) of the six fused ST-GCN launches per domain in one forward."""
+    w = [10, C, C, C, C, 10]
+    return [(w[i], w[i + 1], T, V) for i in range(5)] + [(3, 3, V, To)]
+
+
+def roofline_domain_kernel(B, C, T, V, device, reps=30):
+    """Times the dominant kernel (fused ST-GCN stage, space domain, forward) live with HIP events on the
+    stream it is launched on, over the six shapes it takes in one forward; algorithmic bytes per launch
+    = 4*B*(Cin*T*V + V*T*T + Cout*T*V) + weights."""
+    from cistgcn_amd import ops
+    tot_t, tot_b, per = 0.0, 0.0, []
+    for (ci, co, t, v) in domain_shapes(C, T, V):
+        x = torch.randn(B, ci, t, v, device=device)
+        adj = torch.randn(B, v, t, t, device=device) * 0.1
+        w = torch.randn(co, ci, device=device) * 0.1
+        b = torch.randn(co, device=device)
+        for _ in range(3):
+            ops.stgcn_domain(x, adj, w, b, 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.stgcn_domain(x, adj, w, b, 0)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) / reps * 1e-3
+        nbytes = 4.0 * (B * (ci * t * v + v * t * t + co * t * v) + co * ci + co)
+        per.append({"shape": [B, ci, co, t, v], "us": dt * 1e6, "GBps": nbytes / dt / 1e9})
+        tot_t += dt
+        tot_b += nbytes
+    return tot_b, tot_t, per
+
+
+def cpu_baseline(C, B, T, V, dropout, budget_s=15.0):
+    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on
+    this box's host cores on the same workload: forward + MPJPE + backward."""
+    from oracle import cistgcn_ref as O
+    torch.manual_seed(0)
+    net = O.CISTGCN(*make_cfg(C, T, V, dropout)).train()
+    x, tgt = synth(B, T, V, 0)
+    def step():
+        net.zero_grad(set_to_none=True)
+        pred, = net(x)
+        O.mpjpe(pred, tgt).backward()
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {"value": B * n / el, "unit": "sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d fwd+bwd steps of %s-shaped batch (B=%d) in %.1f s, torch %s CPU" % (n, "workload", B, el, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="cistgcn8_b16_t50_v22", choices=sorted(WORKLOADS))
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from cistgcn_amd import _lib, ops
+    from cistgcn_amd.models import CISTGCN_0
+    from cistgcn_amd.runtime import EagerStep, FlatGrads, GraphedStep, allreduce_mean_
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    C, B, T, V = WORKLOADS[args.workload]
+    torch.manual_seed(0)
+    net = CISTGCN_0(*make_cfg(C, T, V, args.dropout)).to(device).train()
+    ops.manual_seed(1234 + rank, device)
+    x, tgt = synth(B, T, V, rank)
+    x, tgt = x.to(device), tgt.to(device)
+    flat = FlatGrads(net.parameters(), device) if world > 1 else None
+    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat))
+
+    def one():
+        step.replay()
+        if world > 1:
+            allreduce_mean_(flat.flat)
+
+    for _ in range(args.warmup):
+        one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss = float(step.loss.item())
+    if not (loss == loss):
+        raise SystemExit("bench.py: loss is NaN")
+
+    out = {
+        "metric": "sequences/sec (fwd+bwd) H3.6M 22-joint 50->25" if (T, V) == (50, 22) else "sequences/sec (fwd+bwd)",
+        "value": B * world * args.steps / el, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "C": C, "per_gpu_batch": B, "global_batch": B * world, "T_in": T, "T_out": 25,
+                   "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph,
+                   "loss": loss},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            nbytes, secs, per = roofline_domain_kernel(B, C, T, V, device)
+            out["roofline"] = {"bound": "hbm", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "cg_stgcn_domain_fwd_kernel<0>", "avg_us": secs / len(per) * 1e6,
+                               "algorithmic_bytes_per_launch_avg": nbytes / len(per), "per_shape": per}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, B, T, V, args.dropout)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""ctypes binding of libcistgcn_hip.so (the C ABI declared in include/cistgcn_hip.h).
+
+There is exactly one backend.  If the library is missing the loader raises; nothing in this
+package computes on the CPU or through stock PyTorch operators instead.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_float, c_int, c_int32, c_longlong, c_uint, c_ulonglong, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcistgcn_hip.so")
+
+_handle = None
+# Host pointers are refused unless a test harness has injected an emulated build of the very same
+# kernel sources (tests/hipemu).  The product never sets this.
+_host_pointers_ok = False
+
+
+class View4(ctypes.Structure):
+    _fields_ = [("n", c_longlong * 4), ("s", c_longlong * 4)]
+
+
+class NormAct(ctypes.Structure):
+    _fields_ = [
+        ("x", c_void_p), ("xv", View4),
+        ("y", c_void_p), ("yv", View4),
+        ("pre", c_void_p),
+        ("add", c_void_p), ("av", View4),
+        ("add_post", c_int),
+        ("bn_mode", c_int),
+        ("stats", c_void_p),
+        ("gamma", c_void_p), ("beta", c_void_p),
+        ("running_mean", c_void_p), ("running_var", c_void_p), ("num_batches_tracked", c_void_p),
+        ("momentum", c_float), ("eps", c_float),
+        ("save_mean", c_void_p), ("save_rstd", c_void_p),
+        ("drop_p", c_float), ("seed", c_void_p), ("salt", c_uint),
+        ("alpha", c_void_p), ("alpha_n", c_int),
+        ("dy", c_void_p), ("dyv", View4),
+        ("dx", c_void_p), ("dxv", View4),
+        ("dadd", c_void_p), ("dav", View4),
+        ("dpre", c_void_p),
+        ("red", c_void_p),
+        ("dgamma", c_void_p), ("dbeta", c_void_p), ("dalpha", c_void_p),
+    ]
+
+
+P = c_void_p
+LL = c_longlong
+_SIGNATURES = {
+    "cg_contract": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, LL, P],
+    "cg_chan_stats": [P, POINTER(View4), P, P, P],
+    "cg_chan_sum": [P, POINTER(View4), P, P],
+    "cg_norm_act_fwd": [POINTER(NormAct), P],
+    "cg_norm_act_bwd": [POINTER(NormAct), c_int, P],
+    "cg_reduce_bc": [P, POINTER(View4), c_int, P, P, P],
+    "cg_reduce_bc_bwd": [P, P, c_int, P, POINTER(View4), P],
+    "cg_add3": [P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P],
+    "cg_zero": [P, LL, P],
+    "cg_feature_lift_fwd": [P, P, LL, LL, LL, P],
+    "cg_feature_lift_bwd": [P, P, P, LL, LL, LL, P],
+    "cg_dstd_stats_fwd": [P, P, c_int, c_int, c_int, c_int, P],
+    "cg_dstd_stats_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
+    "cg_se_gate_fwd": [P, P, P, P, c_int, c_int, c_int, P],
+    "cg_se_gate_bwd": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "cg_cumsum": [P, POINTER(View4), P, POINTER(View4), c_int, P],
+    "cg_mpjpe_fwd": [P, P, P, LL, P],
+    "cg_mpjpe_bwd": [P, P, P, P, LL, P],
+    "cg_seed_bump": [P, P],
+    "cg_stgcn_domain_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, P],
+    "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
+}
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+
+def declare(handle):
+    """Attach argument/return types for every entry point of include/cistgcn_hip.h."""
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(handle, name)     # AttributeError if the library does not export it
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    return handle
+
+
+def lib():
+    """The loaded kernel library; raises RuntimeError if it has not been built."""
+    global _handle
+    if _handle is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "cistgcn_amd: %s is missing. Build it with `python -m cistgcn_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no fallback implementation." % LIB_PATH)
+        _handle = declare(ctypes.CDLL(LIB_PATH))
+    return _handle
+
+
+_STATUS = {-1: "bad argument (null pointer / option without its buffer)", -2: "unsupported shape"}
+
+
+def check(status, name):
+    if status != 0:
+        what = _STATUS.get(status, "hipError_t %d" % status)
+        raise RuntimeError("cistgcn_hip: %s failed: %s" % (name, what))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,64 @@
+// Shared device helpers for the CIST-GCN gfx950 kernels.
+// Wavefront = 64 lanes (CDNA4); every reduction below is written for that width.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CG_WAVE 64
+
+// ---- status codes returned through the C ABI (0 = ok, >0 = hipError_t, <0 = argument check) ----
+#define CG_OK 0
+#define CG_EARG (-1)
+#define CG_ESHAPE (-2)
+
+// 4-D strided view: dims n[0..3] (n[0] = batch rows, n[1] = channel), element strides s[0..3].
+// Layout-agnostic: NCTV, NTCV and (N,3,V,T) views of one buffer differ only in s[].
+struct CgView4 {
+  long long n[4];
+  long long s[4];
+};
+
+static inline int cg_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? CG_OK : (int)e;
+}
+
+// ---- wave / block reductions -------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T cg_wave_sum(T v) {
+#pragma unroll
+  for (int off = CG_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, CG_WAVE);
+  return v;
+}
+
+// Sum over the whole workgroup; result valid in thread 0. `scratch` holds >= 16 T's in LDS.
+// Contains two barriers; every thread of the block must call it.
+template <typename T>
+__device__ __forceinline__ T cg_block_sum(T v, T* scratch) {
+  const int lane = threadIdx.x & (CG_WAVE - 1);
+  const int wave = threadIdx.x / CG_WAVE;
+  const int nw = (blockDim.x + CG_WAVE - 1) / CG_WAVE;
+  v = cg_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) scratch[wave] = v;
+  __syncthreads();
+  T r = 0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nw; ++w) r += scratch[w];
+  return r;
+}
+
+// ---- counter-based RNG for dropout: splitmix64 of (seed, site salt, element index) ---------------
+__device__ __forceinline__ uint32_t cg_rand_u32(unsigned long long seed, unsigned int salt, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + ((unsigned long long)salt << 40) + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+
+// keep-scale for dropout: 0 (dropped) or 1/(1-p)
+__device__ __forceinline__ float cg_drop_scale(float p, unsigned long long seed, unsigned int salt, unsigned long long idx) {
+  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+  return cg_rand_u32(seed, salt, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+}

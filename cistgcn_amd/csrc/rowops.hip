@@ -1,0 +1,385 @@
+// Row kernels: everything that is per-channel affine / reduction over a 4-D strided view
+// (n0 = batch, n1 = channel, n2 x n3 = positions).  One workgroup owns one (channel, batch) row, so
+// per-row results (gate gradients) need no atomics and per-channel sums need one f64 atomic per
+// row.  Batch statistics are accumulated in f64 (sum, sum of squares): mm-scale pose coordinates
+// square to ~1e6 and the E[x^2]-E[x]^2 form is not safe in f32.
+//
+// Reference semantics restated here: nn.BatchNorm{1,2}d (train: biased batch variance, running_var
+// updated with the unbiased one, momentum 0.1, eps 1e-5; eval: running stats), nn.Dropout(inplace),
+// nn.PReLU (shared or per-channel alpha) as used throughout CISTGCN.py (e.g. :138-153, :229-237,
+// :305-358), SELayer scale (SE.py:20,41).
+#include "cg_common.h"
+
+#define CG_ROW_LOOP(P_, p_) for (long long p_ = threadIdx.x; p_ < (P_); p_ += blockDim.x)
+
+__device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c) {
+  return (long long)b * v.s[0] + (long long)c * v.s[1];
+}
+__device__ __forceinline__ long long cg_pos_off(const CgView4& v, long long p) {
+  const long long i2 = p / v.n[3], i3 = p - i2 * v.n[3];
+  return i2 * v.s[2] + i3 * v.s[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-channel sums  stats[c] = { sum_{b,p} v, sum v^2 },  v = x * pre[b,c]
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, const float* __restrict__ pre,
+                                     double* __restrict__ stats) {
+  __shared__ double red[32];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long P = xv.n[2] * xv.n[3];
+  const long long base = cg_row_base(xv, b, c);
+  const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
+  double s = 0.0, q = 0.0;
+  CG_ROW_LOOP(P, p) {
+    const float v = x[base + cg_pos_off(xv, p)] * w;
+    s += (double)v;
+    q += (double)v * (double)v;
+  }
+  s = cg_block_sum(s, red);
+  q = cg_block_sum(q, red + 16);
+  if (threadIdx.x == 0) {
+    atomicAdd(&stats[2 * c], s);
+    atomicAdd(&stats[2 * c + 1], q);
+  }
+}
+
+extern "C" int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !xv || !stats) return CG_EARG;
+  const long long P = xv->n[2] * xv->n[3];
+  if (xv->n[0] <= 0 || xv->n[1] <= 0 || P <= 0 || xv->n[0] > 65535) return CG_ESHAPE;
+  dim3 grid((unsigned)xv->n[1], (unsigned)xv->n[0]), block(P <= 256 ? 64 : 256);
+  hipLaunchKernelGGL(cg_chan_stats_kernel, grid, block, 0, stream, x, *xv, pre, stats);
+  return cg_launch_status();
+}
+
+// per-channel plain sum in f32 output (bias gradients): out[c] = sum_{b,p} x
+__global__ void cg_chan_sum_kernel(const float* __restrict__ x, CgView4 xv, float* __restrict__ out) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  const long long P = xv.n[2] * xv.n[3];
+  double s = 0.0;
+  for (int b = 0; b < xv.n[0]; ++b) {
+    const long long base = cg_row_base(xv, b, c);
+    CG_ROW_LOOP(P, p) s += (double)x[base + cg_pos_off(xv, p)];
+  }
+  s = cg_block_sum(s, red);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+extern "C" int cg_chan_sum(const float* x, const CgView4* xv, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!x || !xv || !out) return CG_EARG;
+  if (xv->n[1] <= 0) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_chan_sum_kernel, dim3((unsigned)xv->n[1]), dim3(256), 0, stream, x, *xv, out);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused  y = PReLU( Dropout( (x*pre) * scale + shift ) [+ add] ) [+ add if add_post]
+// ---------------------------------------------------------------------------------------------
+struct CgNormAct {
+  const float* x;  CgView4 xv;
+  float* y;        CgView4 yv;
+  const float* pre;              // (B,C) per-sample channel gate, or null
+  const float* add; CgView4 av;  // addend (same logical shape) or null
+  int add_post;                  // 0: added before the PReLU, 1: after it
+  int bn_mode;                   // 0 none, 1 batch statistics (train), 2 running statistics (eval)
+  const double* stats;           // [C][2] sums over B*P (bn_mode 1)
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float momentum, eps;
+  float* save_mean; float* save_rstd;    // [C]; written in fwd (both modes), read in bwd
+  float drop_p; const unsigned long long* seed; unsigned int salt;
+  const float* alpha; int alpha_n;       // PReLU slope(s) or null
+  // backward only
+  const float* dy; CgView4 dyv;
+  float* dx; CgView4 dxv;
+  float* dadd; CgView4 dav;     // gradient of a pre-activation addend (null: not needed)
+  float* dpre;                  // (B,C) or null
+  double* red;                  // [C][2] sum g, sum g*xhat  (+ alpha_n slots behind it for d alpha)
+  float* dgamma; float* dbeta; float* dalpha;
+};
+
+struct CgChanAffine { float scale, shift, mean, rstd; };
+
+__device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c, bool backward) {
+  CgChanAffine r;
+  r.scale = 1.f; r.shift = 0.f; r.mean = 0.f; r.rstd = 1.f;
+  if (a.bn_mode == 0) return r;
+  if (backward) {
+    r.mean = a.save_mean[c]; r.rstd = a.save_rstd[c];
+  } else if (a.bn_mode == 1) {
+    const double cnt = (double)a.xv.n[0] * (double)(a.xv.n[2] * a.xv.n[3]);
+    const double mean = a.stats[2 * c] / cnt;
+    double var = a.stats[2 * c + 1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    r.mean = (float)mean;
+    r.rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+      a.save_mean[c] = r.mean; a.save_rstd[c] = r.rstd;
+      if (a.running_mean) {
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+        if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+      }
+    }
+  } else {
+    r.mean = a.running_mean[c];
+    r.rstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+    if (blockIdx.y == 0 && threadIdx.x == 0) { a.save_mean[c] = r.mean; a.save_rstd[c] = r.rstd; }
+  }
+  r.scale = a.gamma[c] * r.rstd;
+  r.shift = a.beta[c] - r.mean * r.scale;
+  return r;
+}
+
+__global__ void cg_norm_act_fwd_kernel(CgNormAct a) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+  const CgChanAffine af = cg_chan_affine(a, c, false);
+  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+  const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
+  const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
+  const long long bx = cg_row_base(a.xv, b, c), by = cg_row_base(a.yv, b, c);
+  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
+  CG_ROW_LOOP(P, p) {
+    float u = a.x[bx + cg_pos_off(a.xv, p)] * w * af.scale + af.shift;
+    if (a.drop_p > 0.f) u *= cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
+    if (a.add && !a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
+    if (a.alpha) u = u > 0.f ? u : alpha * u;
+    if (a.add && a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
+    a.y[by + cg_pos_off(a.yv, p)] = u;
+  }
+}
+
+// gradient at the affine output (after PReLU and dropout are undone); also returns pre-activation u
+__device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChanAffine& af, float w, float alpha,
+                                                unsigned long long seed, int b, int c, long long C, long long P,
+                                                long long p, long long bx, long long ba, long long bdy,
+                                                float& v, float& u, float& gu) {
+  v = a.x[bx + cg_pos_off(a.xv, p)] * w;
+  float keep = 1.f;
+  if (a.drop_p > 0.f) keep = cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
+  u = (v * af.scale + af.shift) * keep;
+  if (a.add && !a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
+  const float g = a.dy[bdy + cg_pos_off(a.dyv, p)];
+  gu = a.alpha ? (u > 0.f ? g : alpha * g) : g;
+  return gu * keep;
+}
+
+// pass 1 of backward: per-channel sums of g and g*xhat (f64), d alpha
+__global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a) {
+  __shared__ double red[48];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+  const CgChanAffine af = cg_chan_affine(a, c, true);
+  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+  const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
+  const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
+  const long long bx = cg_row_base(a.xv, b, c), bdy = cg_row_base(a.dyv, b, c);
+  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
+  double s1 = 0.0, s2 = 0.0, sa = 0.0;
+  CG_ROW_LOOP(P, p) {
+    float v, u, gu;
+    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, bx, ba, bdy, v, u, gu);
+    s1 += (double)gh;
+    s2 += (double)gh * (double)((v - af.mean) * af.rstd);
+    if (a.alpha && !(u > 0.f)) sa += (double)a.dy[bdy + cg_pos_off(a.dyv, p)] * (double)u;
+  }
+  s1 = cg_block_sum(s1, red);
+  s2 = cg_block_sum(s2, red + 16);
+  sa = cg_block_sum(sa, red + 32);
+  if (threadIdx.x == 0) {
+    atomicAdd(&a.red[2 * c], s1);
+    atomicAdd(&a.red[2 * c + 1], s2);
+    if (a.alpha) atomicAdd(&a.red[2 * C + (a.alpha_n == 1 ? 0 : c)], sa);
+  }
+}
+
+// pass 2 of backward: dx, d add, d pre (row sums), and the per-channel parameter gradients
+__global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+  const CgChanAffine af = cg_chan_affine(a, c, true);
+  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+  const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
+  const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
+  const long long bx = cg_row_base(a.xv, b, c), bdy = cg_row_base(a.dyv, b, c);
+  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
+  const long long bdx = a.dx ? cg_row_base(a.dxv, b, c) : 0;
+  const long long bda = a.dadd ? cg_row_base(a.dav, b, c) : 0;
+  float m1 = 0.f, m2 = 0.f;
+  if (a.bn_mode == 1) {
+    const double cnt = (double)a.xv.n[0] * (double)P;
+    m1 = (float)(a.red[2 * c] / cnt);
+    m2 = (float)(a.red[2 * c + 1] / cnt);
+  }
+  double sp = 0.0;
+  CG_ROW_LOOP(P, p) {
+    float v, u, gu;
+    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, bx, ba, bdy, v, u, gu);
+    float gv;
+    if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
+    else gv = gh * af.scale;
+    if (a.dx) a.dx[bdx + cg_pos_off(a.dxv, p)] = gv * w;
+    if (a.dadd) a.dadd[bda + cg_pos_off(a.dav, p)] = gu;
+    if (a.dpre) sp += (double)gv * (double)a.x[bx + cg_pos_off(a.xv, p)];
+  }
+  if (a.dpre) {
+    sp = cg_block_sum(sp, red);
+    if (threadIdx.x == 0) a.dpre[(long long)b * C + c] = (float)sp;
+  }
+  if (b == 0 && threadIdx.x == 0) {
+    if (a.bn_mode != 0) {
+      if (a.dgamma) a.dgamma[c] = (float)a.red[2 * c + 1];
+      if (a.dbeta) a.dbeta[c] = (float)a.red[2 * c];
+    }
+    if (a.alpha && a.dalpha) {
+      if (a.alpha_n == 1) { if (c == 0) a.dalpha[0] = (float)a.red[2 * C]; }
+      else a.dalpha[c] = (float)a.red[2 * C + c];
+    }
+  }
+}
+
+static int cg_norm_act_check(const CgNormAct* a, bool fwd) {
+  if (!a || !a->x) return CG_EARG;
+  const long long P = a->xv.n[2] * a->xv.n[3];
+  if (a->xv.n[0] <= 0 || a->xv.n[1] <= 0 || P <= 0 || a->xv.n[0] > 65535) return CG_ESHAPE;
+  if (a->bn_mode != 0 && (!a->gamma || !a->beta || !a->save_mean || !a->save_rstd)) return CG_EARG;
+  if (fwd && a->bn_mode == 1 && !a->stats) return CG_EARG;
+  if (fwd && a->bn_mode == 2 && (!a->running_mean || !a->running_var)) return CG_EARG;
+  if (a->drop_p > 0.f && !a->seed) return CG_EARG;
+  if (a->drop_p < 0.f || a->drop_p >= 1.f) return CG_EARG;
+  return CG_OK;
+}
+
+static dim3 cg_row_block(const CgView4& v) { return dim3(v.n[2] * v.n[3] <= 256 ? 64 : 256); }
+
+extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) {
+  int st = cg_norm_act_check(a, true);
+  if (st != CG_OK) return st;
+  if (!a->y) return CG_EARG;
+  dim3 grid((unsigned)a->xv.n[1], (unsigned)a->xv.n[0]);
+  hipLaunchKernelGGL(cg_norm_act_fwd_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+  return cg_launch_status();
+}
+
+// `red` must be zero on entry (the host hands out slices of the per-step zeroed arena).
+extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream_) {
+  int st = cg_norm_act_check(a, false);
+  if (st != CG_OK) return st;
+  if (!a->dy) return CG_EARG;
+  if ((a->bn_mode != 0 || a->alpha) && !a->red) return CG_EARG;
+  dim3 grid((unsigned)a->xv.n[1], (unsigned)a->xv.n[0]);
+  if (need_reduce) {
+    hipLaunchKernelGGL(cg_norm_act_bwd_reduce_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+    st = cg_launch_status();
+    if (st != CG_OK) return st;
+  }
+  hipLaunchKernelGGL(cg_norm_act_bwd_apply_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-(b,c) reductions over the positions: mean (0), max with first-arg-max (1), sum (2) (ContextLayer :465-467,
+// SE squeeze SE.py:17,38, FPN action context CISTGCN.py:76)
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_reduce_bc_kernel(const float* __restrict__ x, CgView4 xv, int kind, float* __restrict__ out,
+                                    int32_t* __restrict__ arg) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  __shared__ double red[16];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long C = xv.n[1], P = xv.n[2] * xv.n[3];
+  const long long base = cg_row_base(xv, b, c);
+  if (kind != 1) {
+    double s = 0.0;
+    CG_ROW_LOOP(P, p) s += (double)x[base + cg_pos_off(xv, p)];
+    s = cg_block_sum(s, red);
+    if (threadIdx.x == 0) out[(long long)b * C + c] = kind == 0 ? (float)(s / (double)P) : (float)s;
+  } else {
+    float best = -INFINITY; int bi = 0x7fffffff;
+    CG_ROW_LOOP(P, p) {
+      const float v = x[base + cg_pos_off(xv, p)];
+      if (v > best || (v == best && (int)p < bi) || bi == 0x7fffffff) { best = v; bi = (int)p; }
+    }
+    sv[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) {
+        const float ov = sv[threadIdx.x + s]; const int oi = si[threadIdx.x + s];
+        if (oi != 0x7fffffff && (si[threadIdx.x] == 0x7fffffff || ov > sv[threadIdx.x] ||
+                                 (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))) {
+          sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[(long long)b * C + c] = sv[0]; arg[(long long)b * C + c] = si[0]; }
+  }
+}
+
+extern "C" int cg_reduce_bc(const float* x, const CgView4* xv, int kind, float* out, int32_t* arg, void* stream_) {
+  if (!x || !xv || !out || (kind == 1 && !arg)) return CG_EARG;
+  if (xv->n[0] <= 0 || xv->n[0] > 65535 || xv->n[1] <= 0 || xv->n[2] * xv->n[3] <= 0) return CG_ESHAPE;
+  dim3 grid((unsigned)xv->n[1], (unsigned)xv->n[0]);
+  hipLaunchKernelGGL(cg_reduce_bc_kernel, grid, cg_row_block(*xv), 0, (hipStream_t)stream_, x, *xv, kind, out, arg);
+  return cg_launch_status();
+}
+
+__global__ void cg_reduce_bc_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int kind,
+                                        float* __restrict__ dx, CgView4 dxv) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long C = dxv.n[1], P = dxv.n[2] * dxv.n[3];
+  const long long base = cg_row_base(dxv, b, c);
+  const float g = dout[(long long)b * C + c];
+  const int hit = kind == 1 ? arg[(long long)b * C + c] : -1;
+  const float gm = g / (float)P;
+  CG_ROW_LOOP(P, p) dx[base + cg_pos_off(dxv, p)] = kind == 0 ? gm : ((int)p == hit ? g : 0.f);
+}
+
+extern "C" int cg_reduce_bc_bwd(const float* dout, const int32_t* arg, int kind, float* dx, const CgView4* dxv, void* stream_) {
+  if (!dout || !dx || !dxv || (kind == 1 && !arg)) return CG_EARG;
+  if (dxv->n[0] <= 0 || dxv->n[0] > 65535 || dxv->n[1] <= 0) return CG_ESHAPE;
+  dim3 grid((unsigned)dxv->n[1], (unsigned)dxv->n[0]);
+  hipLaunchKernelGGL(cg_reduce_bc_bwd_kernel, grid, cg_row_block(*dxv), 0, (hipStream_t)stream_, dout, arg, kind, dx, *dxv);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// strided copy / sum of up to three views (cat, halo padding, residual sums, broadcast)
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_add3_kernel(float* __restrict__ y, CgView4 yv, const float* __restrict__ a, CgView4 av,
+                               const float* __restrict__ b_, CgView4 bv, const float* __restrict__ c_, CgView4 cv) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long long P = yv.n[2] * yv.n[3];
+  const long long by = cg_row_base(yv, b, c), ba = cg_row_base(av, b, c);
+  const long long bb = b_ ? cg_row_base(bv, b, c) : 0, bc = c_ ? cg_row_base(cv, b, c) : 0;
+  CG_ROW_LOOP(P, p) {
+    float v = a[ba + cg_pos_off(av, p)];
+    if (b_) v += b_[bb + cg_pos_off(bv, p)];
+    if (c_) v += c_[bc + cg_pos_off(cv, p)];
+    y[by + cg_pos_off(yv, p)] = v;
+  }
+}
+
+extern "C" int cg_add3(float* y, const CgView4* yv, const float* a, const CgView4* av, const float* b,
+                       const CgView4* bv, const float* c, const CgView4* cv, void* stream_) {
+  if (!y || !yv || !a || !av) return CG_EARG;
+  if (yv->n[0] <= 0 || yv->n[0] > 65535 || yv->n[1] <= 0 || yv->n[2] * yv->n[3] <= 0) return CG_ESHAPE;
+  CgView4 zero = *av;
+  dim3 grid((unsigned)yv->n[1], (unsigned)yv->n[0]);
+  hipLaunchKernelGGL(cg_add3_kernel, grid, cg_row_block(*yv), 0, (hipStream_t)stream_, y, *yv, a, *av,
+                     b, b ? *bv : zero, c, c ? *cv : zero);
+  return cg_launch_status();
+}
+
+extern "C" int cg_zero(void* p, long long bytes, void* stream_) {
+  if (!p || bytes < 0) return CG_EARG;
+  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream_);
+  return e == hipSuccess ? CG_OK : (int)e;
+}

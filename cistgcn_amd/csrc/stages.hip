@@ -1,0 +1,374 @@
+// Stage kernels of the CIST-GCN path that are not plain contractions or per-channel affines:
+// feature lift (row A), block statistics (row C), squeeze-excite gate (row H), cumulative sum
+// (row J), tail sum (row L) and the MPJPE loss (row L).  Citations are to the reference file
+// human_motion_prediction/models/CISTGCN/CISTGCN.py unless stated otherwise.
+#include "cg_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// Row A — CISTGCN.py:568-577.  x (B,T,V,3) -> f (B,10,T,V), channels [x(3), acc(3), vel(3), |vel|]
+//   vel[t] = x[t+1]-x[t] (t<T-1), vel[T-1] = x[T-1];  acc[t] = vel[t+1]-vel[t] (t<T-1), acc[T-1] = vel[T-1]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float cg_vel(const float* x, long long T, long long V, long long b, long long t, long long v, int d) {
+  const float cur = x[((b * T + t) * V + v) * 3 + d];
+  if (t == T - 1) return cur;
+  return x[((b * T + t + 1) * V + v) * 3 + d] - cur;
+}
+
+__global__ void cg_feature_lift_fwd_kernel(const float* __restrict__ x, float* __restrict__ f, long long B, long long T, long long V) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T * V) return;
+  const long long v = i % V, t = (i / V) % T, b = i / (V * T);
+  const long long TV = T * V;
+  float* o = f + b * 10 * TV + t * V + v;
+  float n2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float ve = cg_vel(x, T, V, b, t, v, d);
+    const float ac = (t == T - 1) ? ve : cg_vel(x, T, V, b, t + 1, v, d) - ve;
+    o[(0 + d) * TV] = x[((b * T + t) * V + v) * 3 + d];
+    o[(3 + d) * TV] = ac;
+    o[(6 + d) * TV] = ve;
+    n2 += ve * ve;
+  }
+  o[9 * TV] = sqrtf(n2);
+}
+
+extern "C" int cg_feature_lift_fwd(const float* x, float* f, long long B, long long T, long long V, void* stream_) {
+  if (!x || !f) return CG_EARG;
+  if (B <= 0 || T <= 0 || V <= 0) return CG_ESHAPE;
+  const long long n = B * T * V;
+  hipLaunchKernelGGL(cg_feature_lift_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, f, B, T, V);
+  return cg_launch_status();
+}
+
+// total gradient reaching vel[t] (directly, through |vel| and through acc)
+__device__ __forceinline__ float cg_dvel(const float* x, const float* df, long long T, long long V, long long TV,
+                                         long long b, long long t, long long v, int d) {
+  const float* g = df + b * 10 * TV + t * V + v;
+  float r = g[(6 + d) * TV];
+  float ve[3], n2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) { ve[e] = cg_vel(x, T, V, b, t, v, e); n2 += ve[e] * ve[e]; }
+  if (n2 > 0.f) r += g[9 * TV] * ve[d] / sqrtf(n2);       // d|vel|/dvel, sub-gradient 0 at |vel| = 0
+  if (t < T - 1) r -= g[(3 + d) * TV]; else r += g[(3 + d) * TV];   // acc[t]
+  if (t >= 1) r += g[(3 + d) * TV - V];                    // acc[t-1] = vel[t] - vel[t-1]
+  return r;
+}
+
+__global__ void cg_feature_lift_bwd_kernel(const float* __restrict__ x, const float* __restrict__ df, float* __restrict__ dx,
+                                           long long B, long long T, long long V) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T * V) return;
+  const long long v = i % V, t = (i / V) % T, b = i / (V * T);
+  const long long TV = T * V;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float r = df[b * 10 * TV + d * TV + t * V + v];
+    const float dv = cg_dvel(x, df, T, V, TV, b, t, v, d);
+    if (t < T - 1) r -= dv; else r += dv;
+    if (t >= 1) r += cg_dvel(x, df, T, V, TV, b, t - 1, v, d);
+    dx[((b * T + t) * V + v) * 3 + d] = r;
+  }
+}
+
+extern "C" int cg_feature_lift_bwd(const float* x, const float* df, float* dx, long long B, long long T, long long V, void* stream_) {
+  if (!x || !df || !dx) return CG_EARG;
+  if (B <= 0 || T <= 0 || V <= 0) return CG_ESHAPE;
+  const long long n = B * T * V;
+  hipLaunchKernelGGL(cg_feature_lift_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, df, dx, B, T, V);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row C — DSTD_GC._get_stats_, CISTGCN.py:360-371, on a contiguous (B,C,T,V) tensor.
+//   out[b] = [ mean_c mean_{t,v} | mean_c mean_v (T) | std_c std_{t,v} | std_c std_v (T) ], all std unbiased.
+// One workgroup per sample.  LDS: per-(c,t) row mean and centred sum of squares, per-c mean and std.
+// Dynamic LDS layout (floats): rm[C*T] | rq[C*T] | cm[C] | cs[C]
+// ---------------------------------------------------------------------------------------------
+HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
+
+__device__ __forceinline__ void cg_stats_rows(const float* xb, int C, int T, int V, float* rm, float* rq, float* cm, float* cs) {
+  for (int r = threadIdx.x; r < C * T; r += blockDim.x) {
+    const float* row = xb + (long long)r * V;
+    float m = 0.f;
+    for (int v = 0; v < V; ++v) m += row[v];
+    m /= (float)V;
+    float q = 0.f;
+    for (int v = 0; v < V; ++v) { const float d = row[v] - m; q += d * d; }
+    rm[r] = m; rq[r] = q;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = 0.f;
+    for (int t = 0; t < T; ++t) m += rm[c * T + t];
+    m /= (float)T;
+    float q = 0.f;
+    for (int t = 0; t < T; ++t) { const float d = rm[c * T + t] - m; q += rq[c * T + t] + (float)V * d * d; }
+    cm[c] = m;
+    cs[c] = sqrtf(q / (float)(T * V - 1));
+  }
+  __syncthreads();
+}
+
+__global__ void cg_dstd_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int V) {
+  float* rm = (float*)cg_dyn_lds;
+  float* rq = rm + C * T;
+  float* cm = rq + C * T;
+  float* cs = cm + C;
+  const int b = blockIdx.x;
+  const float* xb = x + (long long)b * C * T * V;
+  cg_stats_rows(xb, C, T, V, rm, rq, cm, cs);
+  float* o = out + (long long)b * (2 + 2 * T);
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int c = 0; c < C; ++c) m += cm[c];
+    o[0] = m / (float)C;
+    float sm = 0.f;
+    for (int c = 0; c < C; ++c) sm += cs[c];
+    sm /= (float)C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = cs[c] - sm; q += d * d; }
+    o[1 + T] = sqrtf(q / (float)(C - 1));
+  }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float m = 0.f, sm = 0.f;
+    for (int c = 0; c < C; ++c) { m += rm[c * T + t]; sm += sqrtf(rq[c * T + t] / (float)(V - 1)); }
+    o[1 + t] = m / (float)C;
+    sm /= (float)C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = sqrtf(rq[c * T + t] / (float)(V - 1)) - sm; q += d * d; }
+    o[2 + T + t] = sqrtf(q / (float)(C - 1));
+  }
+}
+
+__global__ void cg_dstd_stats_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
+                                         int C, int T, int V) {
+  float* rm = (float*)cg_dyn_lds;
+  float* rq = rm + C * T;
+  float* cm = rq + C * T;
+  float* cs = cm + C;
+  float* tS = cs + C;       // [T] std over c of row stds
+  float* tM = tS + T;       // [T] mean over c of row stds
+  __shared__ float gS, gSm;
+  const int b = blockIdx.x;
+  const float* xb = x + (long long)b * C * T * V;
+  const float* g = dout + (long long)b * (2 + 2 * T);
+  cg_stats_rows(xb, C, T, V, rm, rq, cm, cs);
+  if (threadIdx.x == 0) {
+    float sm = 0.f;
+    for (int c = 0; c < C; ++c) sm += cs[c];
+    sm /= (float)C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = cs[c] - sm; q += d * d; }
+    gS = sqrtf(q / (float)(C - 1));
+    gSm = sm;
+  }
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float sm = 0.f;
+    for (int c = 0; c < C; ++c) sm += sqrtf(rq[c * T + t] / (float)(V - 1));
+    sm /= (float)C;
+    float q = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = sqrtf(rq[c * T + t] / (float)(V - 1)) - sm; q += d * d; }
+    tS[t] = sqrtf(q / (float)(C - 1));
+    tM[t] = sm;
+  }
+  __syncthreads();
+  const float g0 = g[0] / (float)(C * T * V);
+  const float gall = g[1 + T];
+  float* dxb = dx + (long long)b * C * T * V;
+  for (int i = threadIdx.x; i < C * T * V; i += blockDim.x) {
+    const int v = i % V, r = i / V, t = r % T, c = r / T;
+    (void)v;
+    const float xv = xb[i];
+    float d = g0 + g[1 + t] / (float)(C * V);
+    // std over c of s_c, s_c = std over (t,v)
+    d += gall * (cs[c] - gSm) / ((float)(C - 1) * gS) * (xv - cm[c]) / ((float)(T * V - 1) * cs[c]);
+    // std over c of s_ct, s_ct = std over v
+    const float sct = sqrtf(rq[r] / (float)(V - 1));
+    d += g[2 + T + t] * (sct - tM[t]) / ((float)(C - 1) * tS[t]) * (xv - rm[r]) / ((float)(V - 1) * sct);
+    dxb[i] = d;
+  }
+}
+
+static size_t cg_dstd_lds(int C, int T) { return (size_t)(2 * C * T + 2 * C + 2 * T) * sizeof(float); }
+
+extern "C" int cg_dstd_stats_fwd(const float* x, float* out, int B, int C, int T, int V, void* stream_) {
+  if (!x || !out) return CG_EARG;
+  if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_dstd_stats_fwd_kernel, dim3(B), dim3(256), cg_dstd_lds(C, T), (hipStream_t)stream_, x, out, C, T, V);
+  return cg_launch_status();
+}
+
+extern "C" int cg_dstd_stats_bwd(const float* x, const float* dout, float* dx, int B, int C, int T, int V, void* stream_) {
+  if (!x || !dout || !dx) return CG_EARG;
+  if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_dstd_stats_bwd_kernel, dim3(B), dim3(256), cg_dstd_lds(C, T), (hipStream_t)stream_, x, dout, dx, C, T, V);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row H — SELayer gate, SE.py:9-14 / 30-35:  gate = sigmoid(W2 relu(W1 pooled)),  W1 (H,C), W2 (C,H)
+// One workgroup per sample; LDS: pooled[C] | hidden[H] | scratch[C]
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_se_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1, const float* __restrict__ W2,
+                                      float* __restrict__ gate, int C, int H) {
+  float* sp = (float*)cg_dyn_lds;
+  float* sh = sp + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) sp[c] = pooled[(long long)b * C + c];
+  __syncthreads();
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += W1[j * C + c] * sp[c];
+    sh[j] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < H; ++j) s += W2[c * H + j] * sh[j];
+    gate[(long long)b * C + c] = 1.f / (1.f + expf(-s));
+  }
+}
+
+__global__ void cg_se_gate_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1, const float* __restrict__ W2,
+                                      const float* __restrict__ gate, const float* __restrict__ dgate,
+                                      float* __restrict__ dpooled, float* __restrict__ dW1, float* __restrict__ dW2, int C, int H) {
+  float* sp = (float*)cg_dyn_lds;
+  float* sh = sp + C;     // hidden (post-ReLU)
+  float* sz = sh + H;     // d z2 [C]
+  float* sd = sz + C;     // d z1 [H]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    sp[c] = pooled[(long long)b * C + c];
+    const float gt = gate[(long long)b * C + c];
+    sz[c] = dgate[(long long)b * C + c] * gt * (1.f - gt);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += W1[j * C + c] * sp[c];
+    sh[j] = s > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += W2[c * H + j] * sz[c];
+    sd[j] = sh[j] > 0.f ? s : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * H; i += blockDim.x) {
+    const int c = i / H, j = i % H;
+    atomicAdd(&dW2[c * H + j], sz[c] * sh[j]);
+    atomicAdd(&dW1[j * C + c], sd[j] * sp[c]);
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < H; ++j) s += W1[j * C + c] * sd[j];
+    dpooled[(long long)b * C + c] = s;
+  }
+}
+
+extern "C" int cg_se_gate_fwd(const float* pooled, const float* W1, const float* W2, float* gate, int B, int C, int H, void* stream_) {
+  if (!pooled || !W1 || !W2 || !gate) return CG_EARG;
+  if (B <= 0 || C <= 0 || H <= 0) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_se_gate_fwd_kernel, dim3(B), dim3(64), (size_t)(C + H) * 4, (hipStream_t)stream_, pooled, W1, W2, gate, C, H);
+  return cg_launch_status();
+}
+
+// dW1 (H,C) and dW2 (C,H) are zeroed here and accumulated with f32 atomics over the batch.
+extern "C" int cg_se_gate_bwd(const float* pooled, const float* W1, const float* W2, const float* gate, const float* dgate,
+                              float* dpooled, float* dW1, float* dW2, int B, int C, int H, void* stream_) {
+  if (!pooled || !W1 || !W2 || !gate || !dgate || !dpooled || !dW1 || !dW2) return CG_EARG;
+  if (B <= 0 || C <= 0 || H <= 0) return CG_ESHAPE;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(dW1, 0, (size_t)C * H * 4, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dW2, 0, (size_t)C * H * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(cg_se_gate_bwd_kernel, dim3(B), dim3(64), (size_t)(2 * C + 2 * H) * 4, stream, pooled, W1, W2, gate, dgate, dpooled, dW1, dW2, C, H);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row J — cumulative sum over axis 1 of a strided 4-D view (B, L, R1, R2), CISTGCN.py:589.
+// reverse = 1 gives the adjoint (suffix sums).
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_cumsum_kernel(const float* __restrict__ x, CgView4 xv, float* __restrict__ y, CgView4 yv, int reverse) {
+  const long long B = xv.n[0], L = xv.n[1], R1 = xv.n[2], R2 = xv.n[3];
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * R1 * R2) return;
+  const long long r2 = i % R2, r1 = (i / R2) % R1, b = i / (R1 * R2);
+  const long long bx = b * xv.s[0] + r1 * xv.s[2] + r2 * xv.s[3];
+  const long long by = b * yv.s[0] + r1 * yv.s[2] + r2 * yv.s[3];
+  float s = 0.f;
+  for (long long l = 0; l < L; ++l) {
+    const long long ll = reverse ? L - 1 - l : l;
+    s += x[bx + ll * xv.s[1]];
+    y[by + ll * yv.s[1]] = s;
+  }
+}
+
+extern "C" int cg_cumsum(const float* x, const CgView4* xv, float* y, const CgView4* yv, int reverse, void* stream_) {
+  if (!x || !y || !xv || !yv) return CG_EARG;
+  const long long n = xv->n[0] * xv->n[2] * xv->n[3];
+  if (n <= 0 || xv->n[1] <= 0) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_cumsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, *xv, y, *yv, reverse);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row L — MPJPE, losses/losses.py:50-61 with reduce_axis=[]:  mean over (b,t,v) of ||pred - target||_2
+// pred is a strided (N, 3) view (N = B*T*V rows with stride ps_n, coordinate stride ps_d).
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_mpjpe_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, float* __restrict__ loss, long long N) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+    const float a = pred[3 * i] - tgt[3 * i], b = pred[3 * i + 1] - tgt[3 * i + 1], c = pred[3 * i + 2] - tgt[3 * i + 2];
+    s += (double)sqrtf(a * a + b * b + c * c);
+  }
+  s = cg_block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss, (float)(s / (double)N));
+}
+
+__global__ void cg_mpjpe_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ gloss,
+                                    float* __restrict__ dpred, long long N) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float a = pred[3 * i] - tgt[3 * i], b = pred[3 * i + 1] - tgt[3 * i + 1], c = pred[3 * i + 2] - tgt[3 * i + 2];
+  const float n = sqrtf(a * a + b * b + c * c);
+  const float k = n > 0.f ? gloss[0] / ((float)N * n) : 0.f;
+  dpred[3 * i] = a * k; dpred[3 * i + 1] = b * k; dpred[3 * i + 2] = c * k;
+}
+
+extern "C" int cg_mpjpe_fwd(const float* pred, const float* tgt, float* loss, long long N, void* stream_) {
+  if (!pred || !tgt || !loss) return CG_EARG;
+  if (N <= 0) return CG_ESHAPE;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  long long blocks = (N + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(cg_mpjpe_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pred, tgt, loss, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_mpjpe_bwd(const float* pred, const float* tgt, const float* gloss, float* dpred, long long N, void* stream_) {
+  if (!pred || !tgt || !gloss || !dpred) return CG_EARG;
+  if (N <= 0) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_mpjpe_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, pred, tgt, gloss, dpred, N);
+  return cg_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dropout-seed bookkeeping: one device word, bumped once per training step so that graph replays
+// draw fresh masks while forward and backward of one step agree.
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_seed_bump_kernel(unsigned long long* seed) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *seed = *seed * 6364136223846793005ull + 1442695040888963407ull;
+}
+
+extern "C" int cg_seed_bump(unsigned long long* seed, void* stream_) {
+  if (!seed) return CG_EARG;
+  hipLaunchKernelGGL(cg_seed_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, seed);
+  return cg_launch_status();
+}

@@ -1,0 +1,370 @@
+// Fused ST-GCN stage of CIST-GCN (reference: Domain_GCNN_layer.forward, CISTGCN.py:265-266, with
+// ConvTemporalGraphical.forward :122-124 and the 1x1 `tcn` convolution :229-234).
+//
+//   G[b,ci,.,.] = graph product of x with the per-sample learned adjacency
+//        domain 0 ("space", CISTGCN.py:117):  G[ci,q,v] = sum_t x[ci,t,v] * Adj[b,v,t,q]   (T x T per joint)
+//        domain 1 ("time",  CISTGCN.py:110):  G[ci,t,w] = sum_v x[ci,t,v] * Adj[b,t,v,w]   (V x V per frame)
+//   y[b,co,.,.] = bias[co] + sum_ci W[co,ci] * G[b,ci,.,.]                                  (channel mix)
+//
+// One workgroup owns (sample, tile of GT "groups"), a group being one joint (domain 0) or one frame
+// (domain 1): its adjacency slabs, its x slice and the mixing weights are staged in LDS, the graph
+// product is written to LDS only, and the channel mix reads it back as float4 — G never reaches HBM.
+// Per-channel f64 sums of y for the following train-mode BatchNorm are an optional epilogue.
+//
+// LDS images (floats; Jp = J rounded up to 4 so that rows can be read as ds_read_b128):
+//   sA [GT][J][Jp]   adjacency, o padded with zeros         J = contraction/output length (T or V)
+//   sX [Cin][GT][J]  input slice
+//   sG [Cinp][PP]    graph product, PP = GT*Jp positions
+//   sWt[Cin][Coutp]  W transposed (fwd) / sW [Cout][Cinp] (bwd)
+#include "cg_common.h"
+
+HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
+
+struct CgDomainGeom {
+  int B, Cin, Cout, T, V;
+  int GT, ntiles;      // groups per tile, tiles per sample
+  int NG, J, Jp, PP;   // groups per sample, contraction length, padded, positions per tile
+  int Cinp, Coutp;
+};
+
+template <int DOMAIN>
+__device__ __forceinline__ long long cg_dom_off(const CgDomainGeom& g, int grp, int j) {
+  // offset of element (group grp, index j) inside one channel plane of a (T,V) tensor
+  return DOMAIN == 1 ? (long long)grp * g.V + j : (long long)j * g.V + grp;
+}
+
+template <int DOMAIN>
+__device__ __forceinline__ void cg_dom_stage_inputs(const CgDomainGeom& g, const float* __restrict__ xb, const float* __restrict__ ab,
+                                                    int g0, int ng, float* sA, float* sX) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int J = g.J, Jp = g.Jp, GT = g.GT;
+  // adjacency slabs are contiguous in HBM: (ng, J, J)
+  for (int e = tid; e < GT * J * Jp; e += nt) sA[e] = 0.f;
+  for (int e = tid; e < g.Cin * GT * J; e += nt) sX[e] = 0.f;
+  __syncthreads();
+  for (int e = tid; e < ng * J * J; e += nt) {
+    const int o = e % J, r = e / J;            // r = grp*J + j
+    sA[r * Jp + o] = ab[e];
+  }
+  if (DOMAIN == 1) {
+    const int run = ng * J;                    // contiguous (grp, j) run per channel
+    for (int e = tid; e < g.Cin * run; e += nt) {
+      const int ci = e / run, r = e - ci * run;
+      sX[ci * GT * J + r] = xb[(long long)ci * g.T * g.V + (long long)g0 * g.V + r];
+    }
+  } else {
+    for (int e = tid; e < g.Cin * J * ng; e += nt) {
+      const int grp = e % ng, r = e / ng, j = r % J, ci = r / J;
+      sX[(ci * GT + grp) * J + j] = xb[(long long)ci * g.T * g.V + (long long)j * g.V + g0 + grp];
+    }
+  }
+}
+
+// sG[ci][grp*Jp + o] = sum_j sX[ci][grp][j] * sA[grp][j][o]   (rows ci >= Cin of sG are zeroed)
+__device__ __forceinline__ void cg_dom_graph_product(const CgDomainGeom& g, const float* sA, const float* sX, float* sG) {
+  const int J = g.J, Jp = g.Jp, GT = g.GT, oq = Jp / 4;
+  for (int idx = threadIdx.x; idx < g.Cinp * GT * oq; idx += blockDim.x) {
+    const int oc = idx % oq, r = idx / oq;     // r = ci*GT + grp
+    const int grp = r % GT, ci = r / GT;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ci < g.Cin) {
+      const float* xr = sX + r * J;
+      const float* ar = sA + (grp * J) * Jp + 4 * oc;
+      for (int j = 0; j < J; ++j) {
+        const float xv = xr[j];
+        const float4 a = *reinterpret_cast<const float4*>(ar + j * Jp);
+        acc.x = fmaf(xv, a.x, acc.x); acc.y = fmaf(xv, a.y, acc.y);
+        acc.z = fmaf(xv, a.z, acc.z); acc.w = fmaf(xv, a.w, acc.w);
+      }
+    }
+    *reinterpret_cast<float4*>(sG + ci * g.PP + grp * Jp + 4 * oc) = acc;
+  }
+}
+
+template <int DOMAIN>
+__global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
+                                                                  const float* __restrict__ W, const float* __restrict__ bias,
+                                                                  float* __restrict__ y, double* __restrict__ ystats, CgDomainGeom g) {
+  float* sA = reinterpret_cast<float*>(cg_dyn_lds);
+  float* sX = sA + g.GT * g.J * g.Jp;
+  float* sG = sX + ((g.Cin * g.GT * g.J + 3) & ~3);
+  float* sWt = sG + g.Cinp * g.PP;
+  double* sStat = reinterpret_cast<double*>(sWt + g.Cin * g.Coutp);
+
+  const int b = blockIdx.x / g.ntiles, tile = blockIdx.x % g.ntiles;
+  const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+  const long long TV = (long long)g.T * g.V;
+  const float* xb = x + (long long)b * g.Cin * TV;
+  const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
+  const int tid = threadIdx.x, nt = blockDim.x;
+
+  cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
+  for (int e = tid; e < g.Cin * g.Coutp; e += nt) {
+    const int co = e % g.Coutp, ci = e / g.Coutp;
+    sWt[e] = co < g.Cout ? W[co * g.Cin + ci] : 0.f;
+  }
+  if (ystats) for (int e = tid; e < 2 * g.Coutp; e += nt) sStat[e] = 0.0;
+  __syncthreads();
+  cg_dom_graph_product(g, sA, sX, sG);
+  __syncthreads();
+
+  // channel mix: 4 output channels x 4 positions per work item
+  const int pq = g.PP / 4, cq = g.Coutp / 4;
+  float* yb = y + (long long)b * g.Cout * TV;
+  for (int idx = tid; idx < cq * pq; idx += nt) {
+    const int pc = idx % pq, cc = idx / pq;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+    for (int ci = 0; ci < g.Cin; ++ci) {
+      const float4 w = *reinterpret_cast<const float4*>(sWt + ci * g.Coutp + 4 * cc);
+      const float4 v = *reinterpret_cast<const float4*>(sG + ci * g.PP + 4 * pc);
+      const float wv[4] = {w.x, w.y, w.z, w.w};
+      const float gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
+    }
+    const int pos0 = 4 * pc, grp = pos0 / g.Jp, o0 = pos0 % g.Jp;   // 4 positions never straddle a group (Jp % 4 == 0)
+    if (grp >= ng) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int co = 4 * cc + a;
+      if (co >= g.Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+      double s = 0.0, sq = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = o0 + q;
+        if (o >= g.J) continue;
+        const float v = acc[a][q] + bv;
+        yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
+        s += (double)v; sq += (double)v * (double)v;
+      }
+      if (ystats) { atomicAdd(&sStat[2 * co], s); atomicAdd(&sStat[2 * co + 1], sq); }
+    }
+  }
+  if (ystats) {
+    __syncthreads();
+    for (int e = tid; e < 2 * g.Cout; e += nt) atomicAdd(&ystats[e], sStat[e]);
+  }
+}
+
+// Backward of the fused stage.  Recomputes G from x and Adj, then
+//   dG = W^T dy ; dx = dG A^T ; dAdj = x^T dG ; dW += dy G^T ; db += sum dy.
+template <int DOMAIN>
+__global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
+                                                                  const float* __restrict__ W, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, float* __restrict__ dadj,
+                                                                  float* __restrict__ dW, float* __restrict__ dbias, CgDomainGeom g) {
+  float* sA = reinterpret_cast<float*>(cg_dyn_lds);
+  float* sX = sA + g.GT * g.J * g.Jp;
+  float* sG = sX + ((g.Cin * g.GT * g.J + 3) & ~3);
+  float* sDG = sG + g.Cinp * g.PP;
+  float* sDY = sDG + g.Cinp * g.PP;
+  float* sW = sDY + g.Coutp * g.PP;        // [Coutp][Cinp]
+
+  const int b = blockIdx.x / g.ntiles, tile = blockIdx.x % g.ntiles;
+  const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+  const long long TV = (long long)g.T * g.V;
+  const float* xb = x + (long long)b * g.Cin * TV;
+  const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
+  const float* dyb = dy + (long long)b * g.Cout * TV;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int J = g.J, Jp = g.Jp, GT = g.GT, PP = g.PP;
+
+  cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
+  for (int e = tid; e < g.Coutp * g.Cinp; e += nt) {
+    const int ci = e % g.Cinp, co = e / g.Cinp;
+    sW[e] = (co < g.Cout && ci < g.Cin) ? W[co * g.Cin + ci] : 0.f;
+  }
+  for (int e = tid; e < g.Coutp * PP; e += nt) {
+    const int pos = e % PP, co = e / PP, grp = pos / Jp, o = pos % Jp;
+    float v = 0.f;
+    if (co < g.Cout && grp < ng && o < J) v = dyb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)];
+    sDY[e] = v;
+  }
+  __syncthreads();
+  cg_dom_graph_product(g, sA, sX, sG);
+  // dG[ci][pos] = sum_co W[co][ci] dy[co][pos]
+  const int pq = PP / 4, iq = g.Cinp / 4, cq = g.Coutp / 4;
+  for (int idx = tid; idx < iq * pq; idx += nt) {
+    const int pc = idx % pq, ic = idx / pq;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+    for (int co = 0; co < g.Cout; ++co) {
+      const float4 w = *reinterpret_cast<const float4*>(sW + co * g.Cinp + 4 * ic);
+      const float4 v = *reinterpret_cast<const float4*>(sDY + co * PP + 4 * pc);
+      const float wv[4] = {w.x, w.y, w.z, w.w};
+      const float gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      *reinterpret_cast<float4*>(sDG + (4 * ic + a) * PP + 4 * pc) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+  }
+  __syncthreads();
+
+  // dx[ci][grp][j] = sum_o dG[ci][grp][o] * A[grp][j][o]
+  float* dxb = dx + (long long)b * g.Cin * TV;
+  const int oq = Jp / 4;
+  for (int idx = tid; idx < g.Cin * ng * J; idx += nt) {
+    int ci, grp, j;
+    if (DOMAIN == 1) { j = idx % J; const int r = idx / J; grp = r % ng; ci = r / ng; }
+    else { grp = idx % ng; const int r = idx / ng; j = r % J; ci = r / J; }
+    const float* dg = sDG + ci * PP + grp * Jp;
+    const float* ar = sA + (grp * J + j) * Jp;
+    float s = 0.f;
+    for (int oc = 0; oc < oq; ++oc) {
+      const float4 d = *reinterpret_cast<const float4*>(dg + 4 * oc);
+      const float4 a = *reinterpret_cast<const float4*>(ar + 4 * oc);
+      s = fmaf(d.x, a.x, s); s = fmaf(d.y, a.y, s); s = fmaf(d.z, a.z, s); s = fmaf(d.w, a.w, s);
+    }
+    dxb[ci * TV + cg_dom_off<DOMAIN>(g, g0 + grp, j)] = s;
+  }
+  // dAdj[grp][j][o] = sum_ci x[ci][grp][j] * dG[ci][grp][o]
+  float* dab = dadj + ((long long)b * g.NG + g0) * J * J;
+  for (int idx = tid; idx < ng * J * oq; idx += nt) {
+    const int oc = idx % oq, r = idx / oq, j = r % J, grp = r / J;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ci = 0; ci < g.Cin; ++ci) {
+      const float xv = sX[(ci * GT + grp) * J + j];
+      const float4 d = *reinterpret_cast<const float4*>(sDG + ci * PP + grp * Jp + 4 * oc);
+      acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y);
+      acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+    }
+    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+    float* row = dab + ((long long)grp * J + j) * J;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * oc + q < J) row[4 * oc + q] = av[q];
+  }
+  // dW[co][ci] += sum_pos dy[co][pos] * G[ci][pos]   (4x4 register tile, float4 along positions)
+  for (int idx = tid; idx < cq * iq; idx += nt) {
+    const int ic = idx % iq, cc = idx / iq;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+    for (int pc = 0; pc < pq; ++pc) {
+      float dv[4][4], gv[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float4 d = *reinterpret_cast<const float4*>(sDY + (4 * cc + a) * PP + 4 * pc);
+        dv[a][0] = d.x; dv[a][1] = d.y; dv[a][2] = d.z; dv[a][3] = d.w;
+        const float4 v = *reinterpret_cast<const float4*>(sG + (4 * ic + a) * PP + 4 * pc);
+        gv[a][0] = v.x; gv[a][1] = v.y; gv[a][2] = v.z; gv[a][3] = v.w;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a][q] = fmaf(dv[a][e], gv[q][e], acc[a][q]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 4 * cc + a, ci = 4 * ic + q;
+        if (co < g.Cout && ci < g.Cin) atomicAdd(&dW[co * g.Cin + ci], acc[a][q]);
+      }
+  }
+  if (dbias) {
+    for (int co = tid; co < g.Cout; co += nt) {
+      float s = 0.f;
+      for (int p = 0; p < PP; ++p) s += sDY[co * PP + p];
+      atomicAdd(&dbias[co], s);
+    }
+  }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+static size_t cg_dom_lds_bytes(const CgDomainGeom& g, bool bwd) {
+  size_t f = (size_t)g.GT * g.J * g.Jp + (((size_t)g.Cin * g.GT * g.J + 3) & ~(size_t)3) + (size_t)g.Cinp * g.PP;
+  if (bwd) f += (size_t)g.Cinp * g.PP + (size_t)g.Coutp * g.PP + (size_t)g.Coutp * g.Cinp;
+  else f += (size_t)g.Cin * g.Coutp;
+  size_t bytes = f * sizeof(float);
+  if (!bwd) bytes += (size_t)2 * g.Coutp * sizeof(double) + 8;
+  return bytes;
+}
+
+static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, int domain, bool bwd) {
+  if (B <= 0 || Cin <= 0 || Cout <= 0 || T <= 0 || V <= 0 || (domain != 0 && domain != 1)) return CG_ESHAPE;
+  g.B = B; g.Cin = Cin; g.Cout = Cout; g.T = T; g.V = V;
+  g.NG = domain == 1 ? T : V;
+  g.J = domain == 1 ? V : T;
+  g.Jp = (g.J + 3) & ~3;
+  g.Cinp = (Cin + 3) & ~3;
+  g.Coutp = (Cout + 3) & ~3;
+  // groups per tile: the largest tile that keeps the LDS image <= 64 KiB (two workgroups per CU) and
+  // the grid >= 1024 workgroups; a single group is accepted up to the full 160 KiB.
+  int best = 0;
+  for (int gt = 1; gt <= g.NG; ++gt) {
+    g.GT = gt; g.PP = gt * g.Jp;
+    const size_t bytes = cg_dom_lds_bytes(g, bwd);
+    if (gt == 1) {
+      if (bytes > 160 * 1024 - 256) return CG_ESHAPE;
+      best = 1;
+      continue;
+    }
+    if (bytes > 64 * 1024) break;
+    if ((long long)B * ((g.NG + gt - 1) / gt) < 1024) break;
+    best = gt;
+  }
+  if (best == 0) return CG_ESHAPE;
+  g.GT = best; g.PP = best * g.Jp;
+  g.ntiles = (g.NG + best - 1) / best;
+  if ((long long)B * g.ntiles > 2147483647LL) return CG_ESHAPE;
+  return CG_OK;
+}
+
+extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
+                                   int B, int Cin, int Cout, int T, int V, int domain, void* stream_) {
+  if (!x || !adj || !W || !y) return CG_EARG;
+  CgDomainGeom g;
+  int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
+  if (st != CG_OK) return st;
+  const size_t lds = cg_dom_lds_bytes(g, false);
+  dim3 grid((unsigned)(B * g.ntiles)), block(256);
+  if (lds > 48 * 1024) {
+    const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_kernel<0> : (const void*)cg_stgcn_domain_fwd_kernel<1>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_fwd_kernel<0>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
+  else hipLaunchKernelGGL(cg_stgcn_domain_fwd_kernel<1>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
+  return cg_launch_status();
+}
+
+extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
+                                   float* dW, float* dbias, int B, int Cin, int Cout, int T, int V, int domain, void* stream_) {
+  if (!x || !adj || !W || !dy || !dx || !dadj || !dW) return CG_EARG;
+  CgDomainGeom g;
+  int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, true);
+  if (st != CG_OK) return st;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * Cin * sizeof(float), stream);
+  if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t lds = cg_dom_lds_bytes(g, true);
+  dim3 grid((unsigned)(B * g.ntiles)), block(256);
+  if (lds > 48 * 1024) {
+    const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_bwd_kernel<0> : (const void*)cg_stgcn_domain_bwd_kernel<1>;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<0>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, dW, dbias, g);
+  else hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<1>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, dW, dbias, g);
+  return cg_launch_status();
+}

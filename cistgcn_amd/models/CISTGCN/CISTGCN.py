@@ -1,0 +1,346 @@
+"""CIST-GCN on MI355X: the `nn.Module` surface of the reference model
+(human_motion_prediction/models/CISTGCN/CISTGCN.py:478-597) with the arithmetic on hand-written
+gfx950 kernels (cistgcn_amd/csrc, called through cistgcn_amd/ops.py).
+
+What is kept from the reference, because its callers depend on it:
+class name `CISTGCN`, ctor `(arch, learn)`, `forward(x: (B,T_in,V,3)) -> (pred: (B,T_out,V,3),)`,
+every `state_dict` key / shape, the init (same RNG consumption order, so the same seed gives the
+same weights), and the interpretation attributes written by each forward
+(`st_gcnns.{i}.{dsgn,tsgn}.Adj`, `.w1`, `.w2`, `context_layer.{joints,displacements,seq_joints,
+seq_joints_n,seq_joints_dims}`).
+
+The torch leaf modules below (`nn.Conv2d`, `nn.BatchNorm2d`, ...) are parameter holders only; their
+`forward` is never called.  There is no CPU path: tensors must live on the HIP device.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ..layers.SE import SELayer1d, SELayer2d
+
+
+class Stage(nn.Module):
+    """Numbered parameter slots of one reference `nn.Sequential` (gaps = parameter-free steps)."""
+
+    def __init__(self, **slots):
+        super().__init__()
+        for k, m in slots.items():
+            self.add_module(k.lstrip("s"), m)
+
+    def __getitem__(self, i):
+        return self._modules[str(i)]
+
+
+def _conv(cin, cout, k=1, bias=False, **kw):
+    return nn.Conv2d(cin, cout, k, bias=bias, **kw)
+
+
+def _init_small(root, gain, convs):
+    """Reference init passes: Map2Adj (CISTGCN.py:175-181, gain .05, convs too) and the model-level
+    one (:559-565, gain .1, Linear + PReLU only)."""
+    for m in root.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight, gain=gain)
+        if convs and isinstance(m, (nn.Conv2d, nn.Conv1d)):
+            nn.init.xavier_normal_(m.weight, gain=gain)
+        if isinstance(m, nn.PReLU):
+            nn.init.constant_(m.weight, 0.25)
+
+
+class Map2Adj(nn.Module):
+    """Parameters of the interpretability attention map (CISTGCN.py:127-181)."""
+
+    def __init__(self, cin, time_dim, joints_dim, domain):
+        super().__init__()
+        mid = cin // 2
+        def tower(kernel, out):
+            return Stage(s0=_conv(cin, mid), s1=nn.BatchNorm2d(mid), s2=nn.PReLU(), s3=_conv(mid, mid, kernel),
+                         s4=nn.BatchNorm2d(mid), s6=_conv(mid, out))
+        self.time_compress = tower((time_dim, 1), time_dim)
+        self.joint_compress = tower((1, joints_dim), joints_dim)
+        ch = joints_dim if domain == "space" else time_dim
+        self.expansor = Stage(s0=_conv(ch, ch), s1=nn.BatchNorm2d(ch), s3=nn.PReLU(), s4=_conv(ch, ch))
+        for part in (self.time_compress, self.joint_compress, self.expansor):
+            _init_small(part, 0.05, True)
+
+
+class GraphWeights(nn.Module):
+    """`gcn` slot of a domain layer.  Interpretable layers get their adjacency per sample from
+    Map2Adj and own no parameter; otherwise a batch-shared A (CISTGCN.py:104-120)."""
+
+    def __init__(self, time_dim, joints_dim, domain, interpretable):
+        super().__init__()
+        if not interpretable:
+            n, s = (time_dim, joints_dim) if domain == "time" else (joints_dim, time_dim)
+            self.A = nn.Parameter(torch.empty(n, s, s).uniform_(-1.0 / s ** 0.5, 1.0 / s ** 0.5))
+
+
+class DomainLayer(nn.Module):
+    """Parameters of one Domain_GCNN_layer (CISTGCN.py:208-257); kernel size is [1,1] in every
+    instantiation of the reference (:524,:553), so `tcn.0` is a channel-mixing matrix."""
+
+    def __init__(self, cin, cout, time_dim, joints_dim, domain, interpretable):
+        super().__init__()
+        self.domain, self.interpretable = domain, bool(interpretable)
+        self.gcn = GraphWeights(time_dim, joints_dim, domain, interpretable)
+        self.tcn = Stage(s0=_conv(cin, cout, bias=True), s1=nn.BatchNorm2d(cout))
+        self.residual = Stage(s0=_conv(cin, cout, bias=True), s1=nn.BatchNorm2d(cout)) if cin != cout else nn.Identity()
+        self.map_to_adj = Map2Adj(cin, time_dim, joints_dim, domain) if interpretable else nn.Identity()
+        self.prelu = nn.PReLU()
+
+
+class DSTDBlock(nn.Module):
+    """Parameters of one DSTD_GC block (CISTGCN.py:289-358)."""
+
+    def __init__(self, cin, cout, interpretable, time_dim, joints_dim, reduction):
+        super().__init__()
+        self.dsgn = DomainLayer(cin, cout, time_dim, joints_dim, "space", interpretable)
+        self.tsgn = DomainLayer(cin, cout, time_dim, joints_dim, "time", interpretable)
+        self.compressor = Stage(s0=_conv(2 * cout, cout), s1=nn.BatchNorm2d(cout), s2=nn.PReLU(),
+                                s3=SELayer2d(cout, reduction=reduction))
+        self.residual = Stage(s0=_conv(cin, cout, bias=True), s1=nn.BatchNorm2d(cout)) if cin != cout else nn.Identity()
+        mid = max(1, cout // 2)
+        self.global_norm = nn.BatchNorm2d(cin)
+        def gate_conv():
+            return Stage(s0=_conv(cin, mid, (time_dim, 1)), s1=nn.BatchNorm2d(mid), s3=nn.PReLU(),
+                         s4=_conv(mid, cout, (1, joints_dim)), s5=nn.BatchNorm2d(cout), s7=nn.PReLU())
+        def gate_map():
+            return Stage(s0=nn.Linear(cout + 2 + 2 * time_dim, cout, bias=False), s1=nn.BatchNorm1d(cout), s3=nn.PReLU(),
+                         s4=nn.Linear(cout, cout, bias=False))
+        self.conv_s, self.conv_t = gate_conv(), gate_conv()
+        self.map_s, self.map_t = gate_map(), gate_map()
+        self.prelu1 = Stage(s0=nn.BatchNorm2d(cout), s1=nn.PReLU())
+        self.prelu2 = Stage(s0=nn.BatchNorm2d(cout), s1=nn.PReLU())
+
+
+class FPN(nn.Module):
+    """Parameters of one time-extrapolator block (CISTGCN.py:38-72)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        if k != 3:
+            raise ValueError("txc_kernel_size %d is not supported by the MI355X path (reference YAMLs use 3)" % k)
+        for i, d in enumerate((1, 2, 3)):
+            self.add_module("block%d" % (i + 1), Stage(s0=_conv(cin, cout, 3, bias=True, padding=d, dilation=d),
+                                                       s1=nn.BatchNorm2d(cout), s3=nn.PReLU()))
+        self.compress = _conv(3 * cout + cin, cout, bias=True)
+
+
+class ContextLayer(nn.Module):
+    """Parameters of the context branch (CISTGCN.py:394-461)."""
+
+    def __init__(self, hidden, out_seq, joints, reduction):
+        super().__init__()
+        def ctx_conv(k):
+            return Stage(s0=_conv(1, hidden, k), s1=nn.BatchNorm2d(hidden), s2=nn.PReLU())
+        self.context_conv1, self.context_conv2, self.context_conv3 = ctx_conv(1), ctx_conv((out_seq, 1)), ctx_conv(1)
+        def head():
+            return Stage(s0=nn.Linear(hidden, out_seq, bias=False), s2=nn.PReLU())
+        self.map1, self.map2, self.map3 = head(), head(), head()
+        self.fmap_s = Stage(s0=nn.Linear(3 * out_seq, joints, bias=False), s1=nn.BatchNorm1d(joints))
+        self.fmap_t = Stage(s0=nn.Linear(3 * out_seq, out_seq, bias=False), s1=nn.BatchNorm1d(out_seq))
+        self.norm_map = Stage(s0=nn.Conv1d(out_seq, out_seq, 1, bias=False), s1=nn.BatchNorm1d(out_seq), s3=nn.PReLU(),
+                              s4=SELayer1d(out_seq, reduction=reduction),
+                              s5=nn.Conv1d(out_seq, out_seq, 1, bias=False), s6=nn.BatchNorm1d(out_seq), s8=nn.PReLU())
+        self.fconv = Stage(s0=_conv(1, 3), s1=nn.BatchNorm2d(3), s2=nn.PReLU(), s3=_conv(3, 3), s4=nn.BatchNorm2d(3), s5=nn.PReLU())
+        self.SE = SELayer2d(out_seq, reduction=reduction)
+
+
+# ---- linear maps as contractions (weights are viewed, never copied) ------------------------------
+def _pointwise(x, conv):
+    """1x1 convolution over the channel axis of a 3-D or 4-D (possibly strided) tensor."""
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    spec = "oc,bchw->bohw" if x.dim() == 4 else "oc,bcv->bov"
+    return ops.contract(spec, w, x, conv.bias, "o" if conv.bias is not None else None)
+
+
+def _collapse_rows(x, conv):
+    """(H,1) convolution that spans the whole axis 2: (B,C,H,W) -> (B,O,1,W)."""
+    w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[2])
+    y = ops.contract("och,bchw->bow", w, x)
+    return y.view(y.shape[0], y.shape[1], 1, y.shape[2])
+
+
+def _collapse_cols(x, conv):
+    """(1,W) convolution that spans the whole axis 3: (B,C,H,W) -> (B,O,H,1)."""
+    w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[3])
+    y = ops.contract("ocw,bchw->boh", w, x)
+    return y.view(y.shape[0], y.shape[1], y.shape[2], 1)
+
+
+def _linear(x, lin):
+    return ops.contract("oi,bi->bo", lin.weight, x)
+
+
+class CISTGCN(nn.Module):
+    """
+    Shape:
+        - Input:  (N, T_in, V, 3) float32 poses on the HIP device
+        - Output: 1-tuple with (N, T_out, V, 3)
+    """
+
+    def __init__(self, arch, learn):
+        super().__init__()
+        p = arch.model_params
+        self.clipping = p.clipping
+        self.n_input, self.n_output, self.n_joints = p.input_n, p.output_n, p.joints
+        self.n_txcnn_layers = p.n_txcnn_layers
+        self.txc_kernel_size = [p.txc_kernel_size] * 2
+        self.input_gcn, self.output_gcn = p.input_gcn, p.output_gcn
+        self.reduction, self.hidden_dim = p.reduction, p.hidden_dim
+        self.dropout = float(learn.dropout)
+        self.in_ch = 10
+        self.fused_domain = True     # False: graph product and channel mix as two generic contractions
+        # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
+        # so that one `opt` can build several models.
+        widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
+        widths_o = [3] + list(p.output_gcn.model_complexity)
+        T, V, To = self.n_input, self.n_joints, self.n_output
+
+        self.st_gcnns = nn.ModuleList()
+        self.txcnns = nn.ModuleList()
+        self.se = nn.ModuleList()
+        self.in_conv = nn.ModuleList()
+        self.context_layer = nn.ModuleList()
+        self.trans = nn.ModuleList()
+        for i in range(len(widths) - 1):
+            self.st_gcnns.append(DSTDBlock(widths[i], widths[i + 1], p.input_gcn.interpretable[i], T, V, self.reduction))
+        self.context_layer = ContextLayer(self.hidden_dim, To, V, self.reduction)
+        self.txcnns.append(FPN(T, To, p.txc_kernel_size))
+        for _ in range(1, self.n_txcnn_layers):
+            self.txcnns.append(FPN(To, To, p.txc_kernel_size))
+        self.prelus = nn.ModuleList(nn.PReLU() for _ in range(self.n_txcnn_layers))
+        self.dim_conversor = Stage(s0=_conv(self.in_ch, 3), s1=nn.BatchNorm2d(3), s2=nn.PReLU(), s3=_conv(3, 3), s4=nn.PReLU(3))
+        self.st_gcnns_o = nn.ModuleList()
+        for i in range(len(widths_o) - 1):
+            # the output block runs on (N,3,V,T_out): "time" axis = joints, "joint" axis = frames (:553)
+            self.st_gcnns_o.append(DSTDBlock(widths_o[i], widths_o[i + 1], p.output_gcn.interpretable[i], V, To, self.reduction))
+        for part in (self.st_gcnns_o, self.st_gcnns, self.txcnns):
+            _init_small(part, 0.1, False)
+        self._site = 0
+
+    # ---- fused row op with per-call dropout site id -------------------------------------------
+    def _na(self, x, bn=None, prelu=None, drop=False, **kw):
+        self._site += 1
+        return ops.norm_act(x, bn=bn, train=self.training, prelu=prelu, drop_p=self.dropout if drop else 0.0,
+                            salt=self._site, **kw)
+
+    # ---- Map2Adj.forward, CISTGCN.py:183-189 ----------------------------------------------------
+    def _adjacency(self, layer, x):
+        m = layer.map_to_adj
+        B, _, T, V = x.shape
+
+        def tower(t, collapse):
+            h = self._na(_pointwise(x, t[0]), bn=t[1], prelu=t[2])
+            h = self._na(collapse(h, t[3]), bn=t[4], drop=True)
+            return _pointwise(h, t[6])
+
+        q = tower(m.time_compress, _collapse_rows).view(B, T, V)     # q[b,tau,v]
+        s = tower(m.joint_compress, _collapse_cols).view(B, V, T)    # s[b,v,t]
+        if layer.domain == "space":
+            o = ops.contract("bvt,bxv->bvtx", s, q)                  # o[b,v,t,tau] = s[b,v,t] q[b,tau,v]
+        else:
+            o = ops.contract("bvt,btw->btvw", s, q)                  # o[b,t,v,w]  = s[b,v,t] q[b,t,w]
+        e = m.expansor
+        h = self._na(_pointwise(o, e[0]), bn=e[1], drop=True, prelu=e[3])
+        return _pointwise(h, e[4])
+
+    # ---- Domain_GCNN_layer.forward, CISTGCN.py:259-269 -------------------------------------------
+    def _domain(self, layer, xn):
+        res = xn if isinstance(layer.residual, nn.Identity) else self._na(_pointwise(xn, layer.residual[0]), bn=layer.residual[1])
+        conv = layer.tcn[0]
+        stats = None
+        if layer.interpretable:
+            adj = self._adjacency(layer, xn)
+            layer.Adj = adj
+            if self.fused_domain:
+                w = conv.weight.view(conv.out_channels, conv.in_channels)
+                y, stats = ops.stgcn_domain(xn, adj, w, conv.bias, 0 if layer.domain == "space" else 1, self.training)
+            else:
+                spec = "bctv,bvtq->bcqv" if layer.domain == "space" else "bctv,btvw->bctw"
+                y = _pointwise(ops.contract(spec, xn, adj), conv)
+        else:
+            layer.Adj = xn
+            spec = "bctv,vtq->bcqv" if layer.domain == "space" else "bctv,tvw->bctw"
+            y = _pointwise(ops.contract(spec, xn, layer.gcn.A), conv)
+        return self._na(y, bn=layer.tcn[1], drop=True, add=res, prelu=layer.prelu, stats=stats)
+
+    # ---- gate path of DSTD_GC.forward, CISTGCN.py:378-384 ----------------------------------------
+    def _gate(self, conv, mp, xn, stats):
+        h = self._na(_collapse_rows(xn, conv[0]), bn=conv[1], drop=True, prelu=conv[3])
+        h = self._na(_collapse_cols(h, conv[4]), bn=conv[5], drop=True, prelu=conv[7])
+        h = ops.cat_channels([h.view(h.shape[0], -1), stats])
+        h = self._na(_linear(h, mp[0]), bn=mp[1], drop=True, prelu=mp[3])
+        return _linear(h, mp[4])
+
+    # ---- DSTD_GC.forward, CISTGCN.py:373-390 ------------------------------------------------------
+    def _block(self, m, x):
+        xn = self._na(x, bn=m.global_norm)
+        stats = ops.dstd_stats(xn)                      # computed once; the reference evaluates it twice (:377,:379)
+        m.w1 = self._gate(m.conv_s, m.map_s, xn, stats)
+        m.w2 = self._gate(m.conv_t, m.map_t, xn, stats)
+        x1 = self._domain(m.dsgn, xn)
+        x2 = self._domain(m.tsgn, xn)
+        a = self._na(x1, pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1])
+        b = self._na(x2, pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])
+        c = m.compressor
+        h = self._na(_pointwise(ops.cat_channels([a, b]), c[0]), bn=c[1], prelu=c[2])
+        gate = ops.se_gate(ops.mean_bc(h), c[3].w1, c[3].w2)
+        res = xn if isinstance(m.residual, nn.Identity) else self._na(_pointwise(xn, m.residual[0]), bn=m.residual[1])
+        return self._na(h, pre=gate, add=res, add_post=True)
+
+    # ---- FPN.forward, CISTGCN.py:74-79 -------------------------------------------------------------
+    def _fpn(self, m, x):
+        blocks = (m.block1, m.block2, m.block3)
+        ys = ops.dilated_convs(x, [b[0] for b in blocks])
+        outs = [self._na(y, bn=b[1], prelu=b[3]) for y, b in zip(ys, blocks)]     # FPN dropout p = 0 (:533)
+        outs.append(ops.mean_bc(x))                                                # action context, broadcast below
+        return _pointwise(ops.cat_channels(outs, bcast=(False, False, False, True)), m.compress)
+
+    # ---- ContextLayer.forward, CISTGCN.py:463-475 --------------------------------------------------
+    def _context(self, m, x7):
+        B, To, V, _ = x7.shape
+        x = x7.view(B, 1, To, V * 3)
+        c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
+        y1 = ops.max_bc(self._na(_pointwise(x, c1[0]), bn=c1[1], prelu=c1[2]))
+        y2 = ops.max_bc(self._na(_collapse_rows(x, c2[0]), bn=c2[1], prelu=c2[2]))
+        ym = ops.mean_bc(self._na(_pointwise(x, c3[0]), bn=c3[1], prelu=c3[2]))
+        heads = [self._na(_linear(y, h[0]), drop=True, prelu=h[2]) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))]
+        y = ops.cat_channels(heads)
+        m.joints = self._na(_linear(y, m.fmap_s[0]), bn=m.fmap_s[1], drop=True)
+        m.displacements = self._na(_linear(y, m.fmap_t[0]), bn=m.fmap_t[1], drop=True)
+        m.seq_joints = ops.contract("bt,bv->btv", m.displacements, m.joints)
+        n = m.norm_map
+        h = self._na(_pointwise(m.seq_joints, n[0]), bn=n[1], drop=True, prelu=n[3])
+        h = self._na(h, pre=ops.se_gate(ops.mean_bc(h), n[4].w1, n[4].w2))
+        h = self._na(_pointwise(h, n[5]), bn=n[6], drop=True, prelu=n[8])
+        m.seq_joints_n = h
+        f = m.fconv
+        h = self._na(_pointwise(h.view(B, 1, To, V), f[0]), bn=f[1], prelu=f[2])
+        h = self._na(_pointwise(h, f[3]), bn=f[4], prelu=f[5])
+        m.seq_joints_dims = h
+        hp = h.permute(0, 2, 3, 1)
+        return self._na(hp, pre=ops.se_gate(ops.mean_bc(hp), m.SE.w1, m.SE.w2))
+
+    # ---- CISTGCN.forward, CISTGCN.py:567-597 -------------------------------------------------------
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != self.n_input or x.shape[2] != self.n_joints or x.shape[3] != 3:
+            raise ValueError("expected input of shape (B, %d, %d, 3), got %s" % (self.n_input, self.n_joints, tuple(x.shape)))
+        ops.begin_step(x.device, bump_seed=self.training and self.dropout > 0.0)
+        self._site = 0
+        h = ops.feature_lift(x)                                         # (B,10,T,V)
+        for blk in self.st_gcnns:
+            h = self._block(blk, h)
+        h = h.permute(0, 2, 1, 3)                                       # NCTV -> NTCV (view)
+        z = self._na(self._fpn(self.txcnns[0], h), prelu=self.prelus[0])
+        for i in range(1, self.n_txcnn_layers):
+            z = self._na(self._fpn(self.txcnns[i], z), prelu=self.prelus[i], add=z, add_post=True)
+        d = self.dim_conversor
+        z = self._na(_pointwise(z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
+        z = self._na(_pointwise(z, d[3]), prelu=d[4])                   # PReLU(3): per-channel slopes (:545)
+        x7 = ops.cumsum_time(z.permute(0, 2, 3, 1))                     # (B,T_out,V,3)
+        act = self._context(self.context_layer, x7)
+        x8 = x7.permute(0, 3, 2, 1)                                     # (B,3,V,T_out) view
+        for blk in self.st_gcnns_o:
+            x8 = self._block(blk, x8)
+        return ops.add3(x[:, -1:], x8.permute(0, 3, 2, 1), act),

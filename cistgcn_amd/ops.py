@@ -1,0 +1,736 @@
+"""Host-side operators of the CIST-GCN path: thin `torch.autograd.Function`s over the C ABI of
+libcistgcn_hip.so.  PyTorch supplies device memory, streams and the autograd tape; every number
+is produced by a HIP kernel.  Views (permute / reshape / slicing) are metadata only: all kernels
+take strides, so layout changes of the reference (`CISTGCN.py:582,588,592,595`) cost nothing.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NormAct, View4
+
+_vp = ctypes.c_void_p
+
+
+# ----------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+def _stream(t):
+    if t.is_cuda:
+        return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    if not _lib._host_pointers_ok:
+        raise RuntimeError("cistgcn_amd operators run on MI355X only: got a %s tensor (no CPU path exists)" % t.device)
+    return None
+
+
+def _chk(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def _view4(t):
+    """(sizes, strides) of a 2/3/4-D tensor as a CgView4 (missing trailing dims have size 1)."""
+    if t.dim() < 2 or t.dim() > 4:
+        raise ValueError("expected a 2..4-D tensor, got %d-D" % t.dim())
+    n = list(t.shape) + [1] * (4 - t.dim())
+    s = list(t.stride()) + [0] * (4 - t.dim())
+    v = View4()
+    for i in range(4):
+        v.n[i] = n[i]
+        v.s[i] = s[i]
+    return v
+
+
+class _Arena:
+    """Per-device f64 scratch that is all-zero at the start of every step: BatchNorm sums and
+    backward reductions take slices from it; one memset per step replaces one per layer."""
+
+    def __init__(self, device, n=1 << 19):
+        self.buf = torch.zeros(n, dtype=torch.float64, device=device)
+        self.cur = 0
+        self.high = 0
+
+    def begin_step(self):
+        if self.high:
+            _lib.call("cg_zero", _ptr(self.buf), self.high * 8, _stream(self.buf))
+        self.cur = 0
+
+    def take(self, n):
+        if self.cur + n > self.buf.numel():
+            raise RuntimeError("cistgcn_amd: step scratch exhausted (missing ops.begin_step()?)")
+        s = self.buf[self.cur:self.cur + n]
+        self.cur += (n + 1) & ~1
+        self.high = max(self.high, self.cur)
+        return s
+
+
+_arenas = {}
+_seeds = {}
+
+
+def _arena(device):
+    a = _arenas.get(device)
+    if a is None:
+        a = _arenas[device] = _Arena(device)
+    return a
+
+
+def seed_state(device):
+    s = _seeds.get(device)
+    if s is None:
+        s = _seeds[device] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
+    return s
+
+
+def manual_seed(seed, device):
+    seed_state(torch.device(device)).fill_(int(seed))
+
+
+def begin_step(device, bump_seed=False):
+    """Start of a forward pass: re-zero the statistics scratch, optionally advance the dropout seed."""
+    device = torch.device(device)
+    _arena(device).begin_step()
+    if bump_seed:
+        s = seed_state(device)
+        _lib.call("cg_seed_bump", _ptr(s), _stream(s))
+
+
+# ----------------------------------------------------------------------------------------------
+# generic contraction
+# ----------------------------------------------------------------------------------------------
+class _Plan:
+    __slots__ = ("tables", "G", "M", "N", "K", "splitk", "a_kfast", "x_kfast", "dense")
+
+
+_plans = {}
+
+
+def _offsets(labels, sizes, strides):
+    off = np.zeros(1, dtype=np.int64)
+    for l in labels:
+        off = (off[:, None] + (np.arange(sizes[l], dtype=np.int64) * strides.get(l, 0))[None, :]).reshape(-1)
+    return off
+
+
+def _min_stride(labels, sizes, strides):
+    vals = [abs(strides.get(l, 0)) for l in labels if sizes[l] > 1]
+    return min(vals) if vals else None
+
+
+def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense):
+    key = (tuple(sorted(sizes.items())), la, lx, ly, tuple(sorted(sa.items())), tuple(sorted(sx.items())),
+           tuple(sorted(sy.items())), oa, ox, oy, bias_label, str(device), y_dense)
+    p = _plans.get(key)
+    if p is not None:
+        return p
+    A, X, Y = set(la), set(lx), set(ly)
+    if (A | X) - (A & X) - Y or Y - (A | X):
+        raise ValueError("contract: every index must appear in two of the three operands (%s,%s->%s)" % (la, lx, ly))
+    g = [l for l in ly if l in A and l in X]
+    m = [l for l in ly if l in A and l not in X]
+    n = [l for l in ly if l in X and l not in A]
+    k = [l for l in lx if l in A and l not in Y]
+    tabs = [_offsets(g, sizes, sa) + oa, _offsets(g, sizes, sx) + ox, _offsets(g, sizes, sy) + oy,
+            _offsets(m, sizes, sa), _offsets(m, sizes, sy),
+            _offsets(m, sizes, {bias_label: 1} if bias_label else {}),
+            _offsets(n, sizes, sx), _offsets(n, sizes, sy),
+            _offsets(k, sizes, sa), _offsets(k, sizes, sx)]
+    flat = np.concatenate(tabs)
+    if flat.size and (flat.max() >= 2 ** 31 or flat.min() < -2 ** 31):
+        raise ValueError("contract: tensor too large for int32 offsets")
+    p = _Plan()
+    p.G, p.M, p.N, p.K = tabs[0].size, tabs[3].size, tabs[6].size, tabs[8].size
+    p.tables = torch.from_numpy(flat.astype(np.int32)).to(device)
+    ka, ma = _min_stride(k, sizes, sa), _min_stride(m, sizes, sa)
+    kx, nx = _min_stride(k, sizes, sx), _min_stride(n, sizes, sx)
+    p.a_kfast = 1 if (ma is None or (ka is not None and ka < ma)) else 0
+    p.x_kfast = 1 if (nx is None or (kx is not None and kx < nx)) else 0
+    blocks = p.G * ((p.M + (15 if p.M <= 16 else 63)) // (16 if p.M <= 16 else 64)) * ((p.N + 63) // 64)
+    p.splitk = 1
+    p.dense = y_dense
+    if y_dense and p.K >= 1024 and blocks < 256:
+        p.splitk = int(max(1, min((p.K + 255) // 256, (512 + blocks - 1) // blocks)))
+    _plans[key] = p
+    return p
+
+
+def _label_strides(t, labels):
+    if t.dim() != len(labels):
+        raise ValueError("contract: operand has %d dims for labels '%s'" % (t.dim(), labels))
+    return {l: s for l, s in zip(labels, t.stride())}
+
+
+def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0):
+    """Y = contraction of a and x per einsum-style `spec`; returns a fresh contiguous tensor.
+    `sa`/`sx` (label -> element stride) and `oa`/`ox` override the operands' own strides, which is
+    how dilated / halo-shifted windows are addressed without materialising them."""
+    ins, ly = spec.split("->")
+    la, lx = ins.split(",")
+    _chk(a, "a"), _chk(x, "x")
+    if sizes is None:
+        sizes = {}
+        for t, ls in ((a, la), (x, lx)):
+            for l, n in zip(ls, t.shape):
+                if sizes.setdefault(l, n) != n:
+                    raise ValueError("contract: size mismatch for index '%s' in %s" % (l, spec))
+    sa = _label_strides(a, la) if sa is None else sa
+    sx = _label_strides(x, lx) if sx is None else sx
+    y = torch.empty([sizes[l] for l in ly], dtype=torch.float32, device=x.device)
+    sy = _label_strides(y, ly)
+    p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label, x.device, True)
+    _lib.call("cg_contract", _ptr(a), _ptr(x), _ptr(y), _ptr(bias), _ptr(p.tables), p.G, p.M, p.N, p.K,
+              p.splitk, p.a_kfast, p.x_kfast, y.numel(), _stream(x))
+    return y
+
+
+_ones = {}
+
+
+def _sum_keep(t, labels, keep):
+    """Sum a tensor over every index except those in `keep` (contraction with a broadcast one)."""
+    one = _ones.get(t.device)
+    if one is None:
+        one = _ones[t.device] = torch.ones(1, dtype=torch.float32, device=t.device)
+    rest = "".join(l for l in labels if l not in keep)
+    if not rest:
+        return t
+    sizes = {l: n for l, n in zip(labels, t.shape)}
+    return _contract_raw("%s,%s->%s" % (labels, rest, keep), t, one, sizes=sizes, sx={l: 0 for l in rest})
+
+
+class _Contract(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, x, bias, spec, bias_label):
+        ctx.spec, ctx.bias_label = spec, bias_label
+        ctx.save_for_backward(a, x)
+        return _contract_raw(spec, a, x, bias, bias_label)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, x = ctx.saved_tensors
+        ins, ly = ctx.spec.split("->")
+        la, lx = ins.split(",")
+        da = dx = db = None
+        if ctx.needs_input_grad[0]:
+            da = _contract_raw("%s,%s->%s" % (ly, lx, la), dy, x)
+        if ctx.needs_input_grad[1]:
+            dx = _contract_raw("%s,%s->%s" % (la, ly, lx), a, dy)
+        if ctx.needs_input_grad[2]:
+            db = _sum_keep(dy, ly, ctx.bias_label)
+        return da, dx, db, None, None
+
+
+def contract(spec, a, x, bias=None, bias_label=None):
+    """einsum-style contraction `spec` = "<a idx>,<x idx>-><y idx>", optional bias along one index."""
+    return _Contract.apply(a, x, bias, spec, bias_label)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused BatchNorm / Dropout / residual / PReLU row kernel
+# ----------------------------------------------------------------------------------------------
+class _NormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pre, add, gamma, beta, alpha, cfg):
+        _chk(x, "x")
+        dev = x.device
+        v = _view4(x)
+        B, C, P = v.n[0], v.n[1], v.n[2] * v.n[3]
+        y = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        a = NormAct()
+        a.x, a.xv, a.y, a.yv = x.data_ptr(), v, y.data_ptr(), _view4(y)
+        if pre is not None:
+            if tuple(pre.shape) != (B, C) or not pre.is_contiguous():
+                raise ValueError("norm_act: gate must be a contiguous (B,C) tensor")
+            a.pre = pre.data_ptr()
+        if add is not None:
+            if add.shape != x.shape:
+                raise ValueError("norm_act: addend shape %s != %s" % (tuple(add.shape), tuple(x.shape)))
+            a.add, a.av = add.data_ptr(), _view4(add)
+        a.add_post = 1 if cfg.get("add_post") else 0
+        bn = cfg.get("bn")
+        save = None
+        if bn is not None:
+            train = cfg["train"]
+            a.bn_mode = 1 if train else 2
+            a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+            a.momentum, a.eps = bn.momentum, bn.eps
+            save = torch.empty(2, C, dtype=torch.float32, device=dev)
+            a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
+            if train:
+                if B * P <= 1:
+                    raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+                stats = cfg.get("stats")
+                if stats is None:
+                    stats = _arena(dev).take(2 * C)
+                    _lib.call("cg_chan_stats", _ptr(x), ctypes.byref(v), _ptr(pre), _ptr(stats), _stream(x))
+                a.stats = stats.data_ptr()
+        p = float(cfg.get("drop_p", 0.0)) if cfg.get("train") else 0.0
+        if p > 0.0:
+            a.drop_p, a.seed, a.salt = p, seed_state(dev).data_ptr(), cfg["salt"]
+        if alpha is not None:
+            a.alpha, a.alpha_n = alpha.data_ptr(), alpha.numel()
+        _lib.call("cg_norm_act_fwd", ctypes.byref(a), _stream(x))
+        ctx.cfg, ctx.p, ctx.mode = cfg, p, a.bn_mode
+        ctx.save_for_backward(x, pre, add, gamma, beta, alpha, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, add, gamma, beta, alpha, save = ctx.saved_tensors
+        cfg, dev = ctx.cfg, x.device
+        v = _view4(x)
+        B, C = v.n[0], v.n[1]
+        a = NormAct()
+        a.x, a.xv = x.data_ptr(), v
+        if pre is not None:
+            a.pre = pre.data_ptr()
+        add_post = 1 if cfg.get("add_post") else 0
+        a.add_post = add_post
+        if add is not None:
+            a.add, a.av = add.data_ptr(), _view4(add)
+        a.bn_mode = ctx.mode
+        bn = cfg.get("bn")
+        if bn is not None:
+            a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            a.momentum, a.eps = bn.momentum, bn.eps
+            a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
+        if ctx.p > 0.0:
+            a.drop_p, a.seed, a.salt = ctx.p, seed_state(dev).data_ptr(), cfg["salt"]
+        nalpha = 0
+        if alpha is not None:
+            nalpha = alpha.numel()
+            a.alpha, a.alpha_n = alpha.data_ptr(), nalpha
+        a.dy, a.dyv = dy.data_ptr(), _view4(dy)
+        need = ctx.needs_input_grad
+        dx = dpre = dadd = dgamma = dbeta = dalpha = None
+        if need[0]:
+            dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            a.dx, a.dxv = dx.data_ptr(), _view4(dx)
+        if pre is not None and need[1]:
+            dpre = torch.empty(B, C, dtype=torch.float32, device=dev)
+            a.dpre = dpre.data_ptr()
+        if add is not None and need[2]:
+            if add_post:
+                dadd = dy
+            else:
+                dadd = torch.empty(add.shape, dtype=torch.float32, device=dev)
+                a.dadd, a.dav = dadd.data_ptr(), _view4(dadd)
+        need_reduce = 1 if (bn is not None or alpha is not None) else 0
+        if need_reduce:
+            a.red = _arena(dev).take(2 * C + nalpha).data_ptr()
+            if bn is not None:
+                g = torch.empty(2, C, dtype=torch.float32, device=dev)
+                dgamma, dbeta = g[0], g[1]
+                a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+            if alpha is not None:
+                dalpha = torch.empty(alpha.shape, dtype=torch.float32, device=dev)
+                a.dalpha = dalpha.data_ptr()
+        _lib.call("cg_norm_act_bwd", ctypes.byref(a), need_reduce, _stream(x))
+        return dx, dpre, dadd, dgamma, dbeta, dalpha, None
+
+
+def norm_act(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None):
+    """y = PReLU(Dropout(BN(x * pre)) [+ add]) [+ add];  every stage optional.
+    `bn` is the parameter holder (an nn.BatchNorm*), `prelu` an nn.PReLU; `stats` are precomputed
+    f64 channel sums of x (the fused ST-GCN kernel emits them)."""
+    cfg = {"bn": bn, "train": bool(train), "add_post": add_post, "drop_p": drop_p, "salt": salt, "stats": stats}
+    gamma = bn.weight if bn is not None else None
+    beta = bn.bias if bn is not None else None
+    alpha = prelu.weight if prelu is not None else None
+    return _NormActFn.apply(x, pre, add, gamma, beta, alpha, cfg)
+
+
+# ----------------------------------------------------------------------------------------------
+# reductions over positions, SE gate
+# ----------------------------------------------------------------------------------------------
+class _ReduceBC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kind):
+        _chk(x)
+        v = _view4(x)
+        out = torch.empty(v.n[0], v.n[1], dtype=torch.float32, device=x.device)
+        arg = torch.empty(v.n[0], v.n[1], dtype=torch.int32, device=x.device) if kind == 1 else None
+        _lib.call("cg_reduce_bc", _ptr(x), ctypes.byref(v), kind, _ptr(out), _ptr(arg), _stream(x))
+        ctx.kind, ctx.shape = kind, x.shape
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        arg, = ctx.saved_tensors
+        dout = dout if dout.is_contiguous() else _copy(dout)
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dout.device)
+        v = _view4(dx)
+        _lib.call("cg_reduce_bc_bwd", _ptr(dout), _ptr(arg), ctx.kind, _ptr(dx), ctypes.byref(v), _stream(dout))
+        return dx, None
+
+
+def mean_bc(x):
+    """(B,C,...) -> (B,C) mean over everything behind the channel axis."""
+    return _ReduceBC.apply(x, 0)
+
+
+def max_bc(x):
+    """(B,C,...) -> (B,C) max over everything behind the channel axis (gradient to the first arg-max)."""
+    return _ReduceBC.apply(x, 1)
+
+
+class _SEGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pooled, w1, w2):
+        B, C = pooled.shape
+        H = w1.shape[0]
+        gate = torch.empty(B, C, dtype=torch.float32, device=pooled.device)
+        _lib.call("cg_se_gate_fwd", _ptr(pooled), _ptr(w1), _ptr(w2), _ptr(gate), B, C, H, _stream(pooled))
+        ctx.save_for_backward(pooled, w1, w2, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        pooled, w1, w2, gate = ctx.saved_tensors
+        B, C = pooled.shape
+        H = w1.shape[0]
+        dgate = dgate if dgate.is_contiguous() else _copy(dgate)
+        dp = torch.empty_like(pooled)
+        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        _lib.call("cg_se_gate_bwd", _ptr(pooled), _ptr(w1), _ptr(w2), _ptr(gate), _ptr(dgate), _ptr(dp), _ptr(dw1),
+                  _ptr(dw2), B, C, H, _stream(pooled))
+        return dp, dw1, dw2
+
+
+def se_gate(pooled, w1, w2):
+    return _SEGate.apply(pooled, w1, w2)
+
+
+# ----------------------------------------------------------------------------------------------
+# strided copies: cat / pad / sums
+# ----------------------------------------------------------------------------------------------
+def _add_into(y, a, b=None, c=None):
+    vy, va = _view4(y), _view4(a)
+    vb = _view4(b) if b is not None else None
+    vc = _view4(c) if c is not None else None
+    _lib.call("cg_add3", _ptr(y), ctypes.byref(vy), _ptr(a), ctypes.byref(va), _ptr(b),
+              ctypes.byref(vb) if vb is not None else None, _ptr(c), ctypes.byref(vc) if vc is not None else None, _stream(y))
+
+
+def _copy(t):
+    y = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    if t.dim() > 4 or t.dim() < 2:
+        flat = t.reshape(1, -1) if t.is_contiguous() else None
+        if flat is None:
+            raise ValueError("copy: unsupported rank")
+        _add_into(y.view(1, -1), flat)
+    else:
+        _add_into(y, t)
+    return y
+
+
+class _Cat(torch.autograd.Function):
+    """Concatenation along the channel axis; inputs flagged `bcast` are (B,C) maps broadcast over
+    the positions (F.interpolate of a 1x1 pool, CISTGCN.py:76)."""
+
+    @staticmethod
+    def forward(ctx, bcast, *ts):
+        ref = next(t for t, bc in zip(ts, bcast) if not bc)
+        chans = [t.shape[1] for t in ts]
+        shape = list(ref.shape)
+        shape[1] = sum(chans)
+        y = torch.empty(shape, dtype=torch.float32, device=ref.device)
+        c0 = 0
+        for t, bc, c in zip(ts, bcast, chans):
+            dst = y.narrow(1, c0, c)
+            src = t.view(t.shape[0], c, *([1] * (ref.dim() - 2))).expand_as(dst) if bc else t
+            _add_into(dst, src)
+            c0 += c
+        ctx.bcast, ctx.chans = bcast, chans
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, c0 = [], 0
+        for i, (bc, c) in enumerate(zip(ctx.bcast, ctx.chans)):
+            g = dy.narrow(1, c0, c)
+            if not ctx.needs_input_grad[i + 1]:
+                g = None
+            elif bc:
+                v = _view4(g)
+                m = torch.empty(g.shape[0], c, dtype=torch.float32, device=dy.device)
+                _lib.call("cg_reduce_bc", _ptr(g), ctypes.byref(v), 2, _ptr(m), None, _stream(dy))
+                g = m
+            outs.append(g)
+            c0 += c
+        return (None,) + tuple(outs)
+
+
+def cat_channels(ts, bcast=None):
+    bcast = tuple(bcast) if bcast is not None else (False,) * len(ts)
+    return _Cat.apply(bcast, *ts)
+
+
+class _Add3(torch.autograd.Function):
+    """a + b + c for 4-D operands; size-1 axes broadcast (the `x[:, -1:]` term of CISTGCN.py:597)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        shape = torch.broadcast_shapes(a.shape, b.shape, c.shape if c is not None else a.shape)
+        y = torch.empty(shape, dtype=torch.float32, device=a.device)
+        _add_into(y, a.expand(shape), b.expand(shape), c.expand(shape) if c is not None else None)
+        ctx.shapes = (a.shape, b.shape, c.shape if c is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs = []
+        labels = "abcd"[:dy.dim()]
+        for i, shp in enumerate(ctx.shapes):
+            if shp is None or not ctx.needs_input_grad[i]:
+                outs.append(None)
+                continue
+            keep = "".join(l for l, n, m in zip(labels, shp, dy.shape) if n == m)
+            g = dy if len(keep) == dy.dim() else _sum_keep(dy, labels, keep).view(shp)
+            outs.append(g)
+        return tuple(outs)
+
+
+def add3(a, b, c=None):
+    return _Add3.apply(a, b, c)
+
+
+# ----------------------------------------------------------------------------------------------
+# dilated 3x3 convolutions of the FPN time extrapolator (CISTGCN.py:54-68)
+# ----------------------------------------------------------------------------------------------
+def _halo(x, pad):
+    """zero halo of `pad` on the last two axes of a (possibly strided) 4-D tensor"""
+    B, C, H, W = x.shape
+    xp = torch.empty(B, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
+    _lib.call("cg_zero", _ptr(xp), xp.numel() * 4, _stream(x))
+    _add_into(xp[:, :, pad:pad + H, pad:pad + W], x)
+    return xp
+
+
+class _DilatedConvs(torch.autograd.Function):
+    """Three 3x3 convolutions of one input with dilation = padding = 1, 2, 3.  The input is copied
+    once into a zero-halo buffer; each convolution is a contraction whose window/dilation lives in
+    the offset tables.  Backward-data is the same contraction on the halo-padded output gradient
+    with negated window strides."""
+    PAD = 3
+
+    @staticmethod
+    def forward(ctx, x, dils, *wb):
+        B, C, H, W = x.shape
+        pad = _DilatedConvs.PAD
+        xp = _halo(x, pad)
+        sB, sC, sH, sW = xp.stride()
+        outs = []
+        for i, d in enumerate(dils):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            sizes = {"b": B, "c": C, "o": w.shape[0], "i": 3, "j": 3, "h": H, "w": W}
+            y = _contract_raw("ocij,bcijhw->bohw", w, xp, b, "o", sizes=sizes,
+                              sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW},
+                              ox=(pad - d) * (sH + sW))
+            outs.append(y)
+        ctx.dils, ctx.shape = dils, x.shape
+        ctx.save_for_backward(xp, *wb[0::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        xp, *ws = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        pad = _DilatedConvs.PAD
+        sB, sC, sH, sW = xp.stride()
+        grads, dxs = [], []
+        for i, d in enumerate(ctx.dils):
+            w, dy = ws[i], dys[i]
+            O = w.shape[0]
+            sizes = {"b": B, "c": C, "o": O, "i": 3, "j": 3, "h": H, "w": W}
+            dw = db = None
+            if ctx.needs_input_grad[2 + 2 * i]:
+                dw = _contract_raw("bohw,bcijhw->ocij", dy, xp, sizes=sizes,
+                                   sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW},
+                                   ox=(pad - d) * (sH + sW))
+            if ctx.needs_input_grad[3 + 2 * i]:
+                db = _sum_keep(dy, "bohw", "o")
+            if ctx.needs_input_grad[0]:
+                dyp = _halo(dy, pad)
+                tB, tO, tH, tW = dyp.stride()
+                # dx[b,c,h,w] = sum_{o,i,j} w[o,c,i,j] * dy[b,o,h-d(i-1),w-d(j-1)]
+                dxs.append(_contract_raw("ocij,boijhw->bchw", w, dyp, sizes=sizes,
+                                         sx={"b": tB, "o": tO, "i": -d * tH, "j": -d * tW, "h": tH, "w": tW},
+                                         ox=(pad + d) * (tH + tW)))
+            grads += [dw, db]
+        dx = None
+        if dxs:
+            dx = torch.empty(ctx.shape, dtype=torch.float32, device=xp.device)
+            _add_into(dx, dxs[0], dxs[1] if len(dxs) > 1 else None, dxs[2] if len(dxs) > 2 else None)
+        return (dx, None) + tuple(grads)
+
+
+def dilated_convs(x, convs):
+    """convs: three nn.Conv2d holders (3x3, dilation = padding = 1,2,3); returns their three outputs."""
+    dils = tuple(int(c.dilation[0]) for c in convs)
+    for c, d in zip(convs, dils):
+        if tuple(c.kernel_size) != (3, 3) or tuple(c.padding) != (d, d) or d > _DilatedConvs.PAD:
+            raise ValueError("dilated_convs: unsupported convolution geometry %s" % (c,))
+    wb = []
+    for c in convs:
+        wb += [c.weight, c.bias]
+    return _DilatedConvs.apply(x, dils, *wb)
+
+
+# ----------------------------------------------------------------------------------------------
+# stage kernels
+# ----------------------------------------------------------------------------------------------
+class _FeatureLift(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x)
+        if x.dim() != 4 or x.shape[-1] != 3:
+            raise ValueError("expected poses of shape (B, T, V, 3), got %s" % (tuple(x.shape),))
+        x = x if x.is_contiguous() else _copy(x)
+        B, T, V, _ = x.shape
+        f = torch.empty(B, 10, T, V, dtype=torch.float32, device=x.device)
+        _lib.call("cg_feature_lift_fwd", _ptr(x), _ptr(f), B, T, V, _stream(x))
+        ctx.save_for_backward(x)
+        return f
+
+    @staticmethod
+    def backward(ctx, df):
+        x, = ctx.saved_tensors
+        B, T, V, _ = x.shape
+        df = df if df.is_contiguous() else _copy(df)
+        dx = torch.empty_like(x)
+        _lib.call("cg_feature_lift_bwd", _ptr(x), _ptr(df), _ptr(dx), B, T, V, _stream(x))
+        return dx
+
+
+def feature_lift(x):
+    return _FeatureLift.apply(x)
+
+
+class _DstdStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_contiguous():
+            raise ValueError("dstd_stats expects a contiguous (B,C,T,V) tensor")
+        B, C, T, V = x.shape
+        out = torch.empty(B, 2 + 2 * T, dtype=torch.float32, device=x.device)
+        _lib.call("cg_dstd_stats_fwd", _ptr(x), _ptr(out), B, C, T, V, _stream(x))
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, = ctx.saved_tensors
+        B, C, T, V = x.shape
+        dout = dout if dout.is_contiguous() else _copy(dout)
+        dx = torch.empty_like(x)
+        _lib.call("cg_dstd_stats_bwd", _ptr(x), _ptr(dout), _ptr(dx), B, C, T, V, _stream(x))
+        return dx
+
+
+def dstd_stats(x):
+    return _DstdStats.apply(x)
+
+
+class _Cumsum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        vx, vy = _view4(x), _view4(y)
+        _lib.call("cg_cumsum", _ptr(x), ctypes.byref(vx), _ptr(y), ctypes.byref(vy), 0, _stream(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+        vy, vx = _view4(dy), _view4(dx)
+        _lib.call("cg_cumsum", _ptr(dy), ctypes.byref(vy), _ptr(dx), ctypes.byref(vx), 1, _stream(dy))
+        return dx
+
+
+def cumsum_time(x):
+    """cumulative sum over axis 1 of a 4-D (possibly strided) tensor"""
+    return _Cumsum.apply(x)
+
+
+class _Mpjpe(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        _chk(pred), _chk(target)
+        if pred.shape != target.shape or pred.shape[-1] != 3:
+            raise AssertionError("mpjpe: predicted %s vs target %s" % (tuple(pred.shape), tuple(target.shape)))
+        pred = pred if pred.is_contiguous() else _copy(pred)
+        target = target if target.is_contiguous() else _copy(target)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.call("cg_mpjpe_fwd", _ptr(pred), _ptr(target), _ptr(loss), pred.numel() // 3, _stream(pred))
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        g = g.reshape(1)
+        d = torch.empty_like(pred)
+        _lib.call("cg_mpjpe_bwd", _ptr(pred), _ptr(target), _ptr(g), _ptr(d), pred.numel() // 3, _stream(pred))
+        return d, None
+
+
+def mpjpe(pred, target):
+    """Mean per-joint position error with full-mean reduction (losses/losses.py:50-61, reduce_axis=[])."""
+    return _Mpjpe.apply(pred, target)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused ST-GCN stage
+# ----------------------------------------------------------------------------------------------
+class _StgcnDomain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, w, bias, domain, want_stats):
+        if not (x.is_contiguous() and adj.is_contiguous() and w.is_contiguous()):
+            raise ValueError("stgcn_domain expects contiguous x (B,C,T,V), Adj and W")
+        B, Cin, T, V = x.shape
+        Cout = w.shape[0]
+        exp = (B, V, T, T) if domain == 0 else (B, T, V, V)
+        if tuple(adj.shape) != exp or w.numel() != Cout * Cin:
+            raise ValueError("stgcn_domain: adjacency %s / weight %s do not match x %s" % (tuple(adj.shape), tuple(w.shape), tuple(x.shape)))
+        y = torch.empty(B, Cout, T, V, dtype=torch.float32, device=x.device)
+        stats = _arena(x.device).take(2 * Cout) if want_stats else None
+        _lib.call("cg_stgcn_domain_fwd", _ptr(x), _ptr(adj), _ptr(w), _ptr(bias), _ptr(y), _ptr(stats),
+                  B, Cin, Cout, T, V, domain, _stream(x))
+        ctx.domain = domain
+        ctx.save_for_backward(x, adj, w)
+        if want_stats:
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        return y, None
+
+    @staticmethod
+    def backward(ctx, dy, _):
+        x, adj, w = ctx.saved_tensors
+        B, Cin, T, V = x.shape
+        Cout = w.shape[0]
+        dy = dy if dy.is_contiguous() else _copy(dy)
+        dx = torch.empty_like(x)
+        dadj = torch.empty_like(adj)
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        _lib.call("cg_stgcn_domain_bwd", _ptr(x), _ptr(adj), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dadj), _ptr(dw), _ptr(db),
+                  B, Cin, Cout, T, V, ctx.domain, _stream(x))
+        return dx, dadj, dw, db, None, None
+
+
+def stgcn_domain(x, adj, w, bias, domain, want_stats=False):
+    """Fused graph product + channel mix (CISTGCN.py:265-266).  domain 0 = "space" (Adj (B,V,T,T)),
+    1 = "time" (Adj (B,T,V,V)).  Returns (y, f64 channel sums of y or None)."""
+    return _StgcnDomain.apply(x, adj, w, bias, domain, want_stats)

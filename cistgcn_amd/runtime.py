@@ -1,0 +1,134 @@
+"""Step runtime around the model: HIP-graph capture of forward + loss + backward, the flat gradient
+buffer, and data-parallel gradient averaging over RCCL (one process per GPU).
+
+The reference has no distributed code at all (train.py:214 pins one GPU); batches are independent
+except for per-replica BatchNorm statistics, so data parallelism = every rank runs the same step
+on its shard and the flat gradient buffer is all-reduced (sum) and scaled by 1/world.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+_CHUNK = 2048
+
+
+class FlatGrads:
+    """One contiguous fp32 buffer holding all parameter gradients, filled by a single gather kernel."""
+
+    def __init__(self, params, device):
+        self.params = [p for p in params if p.requires_grad]
+        sizes = [p.numel() for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.numel = int(self.offsets[-1])
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        ct, cb, cl = [], [], []
+        for t, n in enumerate(sizes):
+            for b in range(0, n, _CHUNK):
+                ct.append(t); cb.append(b); cl.append(min(_CHUNK, n - b))
+        self.n_chunks = len(ct)
+        dev = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
+        self._off = dev(self.offsets[:-1], np.int64)
+        self._ct, self._cb, self._cl = dev(ct, np.int32), dev(cb, np.int32), dev(cl, np.int32)
+        self._ptr_host = torch.zeros(len(sizes), dtype=torch.int64)
+        if torch.device(device).type == "cuda":
+            self._ptr_host = self._ptr_host.pin_memory()
+        self._ptr_dev = torch.zeros(len(sizes), dtype=torch.int64, device=device)
+
+    def _copy(self, direction):
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                raise RuntimeError("FlatGrads: parameter %d has no gradient" % i)
+            if not p.grad.is_contiguous():
+                raise RuntimeError("FlatGrads: non-contiguous gradient")
+            self._ptr_host[i] = p.grad.data_ptr()
+        self._ptr_dev.copy_(self._ptr_host, non_blocking=True)
+        _lib.call("cg_multi_copy", ops._ptr(self._ptr_dev), ops._ptr(self._off), ops._ptr(self._ct), ops._ptr(self._cb),
+                  ops._ptr(self._cl), self.n_chunks, ops._ptr(self.flat), direction, ops._stream(self.flat))
+
+    def gather(self):
+        """p.grad -> flat (one launch)."""
+        self._copy(0)
+        return self.flat
+
+    def scatter(self):
+        """flat -> p.grad (one launch)."""
+        self._copy(1)
+
+
+def allreduce_mean_(flat, group=None):
+    """In-place mean over the data-parallel group: RCCL all-reduce(sum) over xGMI (backend "nccl" on
+    ROCm) or gloo in the CPU tests, then the 1/world scale folded into the same buffer."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.mul_(1.0 / world)
+    return flat
+
+
+def shard_weights(local_batch, group=None):
+    """Weight of this replica's gradient when per-GPU batches differ (BASELINE config 5): B_r / sum B."""
+    import torch.distributed as dist
+    t = torch.tensor([float(local_batch)])
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    total = t.clone()
+    dist.all_reduce(total, group=group)
+    return float(local_batch) * dist.get_world_size(group) / float(total.item())
+
+
+class GraphedStep:
+    """forward + MPJPE + backward (+ flat-gradient gather) of one batch, captured once in a HIP graph
+    and replayed: ~3000 kernel launches collapse into one graph launch, which is what makes the
+    B=16 configuration launch-latency free.  Inputs live in static device buffers (`x`, `target`)."""
+
+    def __init__(self, model, x, target, warmup=3, flat=None):
+        self.model, self.flat = model, flat
+        self.x, self.target = x.clone(), target.clone()
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._step()
+
+    def _step(self):
+        for p in self.params:
+            p.grad = None
+        pred, = self.model(self.x)
+        loss = ops.mpjpe(pred, self.target)
+        loss.backward()
+        if self.flat is not None:
+            self.flat.gather()
+        return loss
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss
+
+
+class EagerStep:
+    """Same step without graph capture (debugging / first-iteration reference)."""
+
+    def __init__(self, model, x, target, flat=None):
+        self.model, self.flat, self.x, self.target = model, flat, x, target
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    def replay(self):
+        for p in self.params:
+            p.grad = None
+        pred, = self.model(self.x)
+        self.loss = ops.mpjpe(pred, self.target)
+        self.loss.backward()
+        if self.flat is not None:
+            self.flat.gather()
+        return self.loss

@@ -1,0 +1,149 @@
+/* cistgcn_hip.h — C ABI of libcistgcn_hip.so, the MI355X (gfx950) kernel library behind the
+ * CIST-GCN forward/backward hot path.
+ *
+ * The reference (QualityMinds/cistgcn) is pure Python on stock PyTorch ops: it has no FFI for this
+ * path (SURVEY.md §2 "Native / kernel / collective inventory: none").  The boundary a maintainer
+ * binds is therefore the set of aten-op groups inside
+ *   human_motion_prediction/models/CISTGCN/CISTGCN.py   (CISTGCN.forward, :567-597)
+ *   human_motion_prediction/models/layers/SE.py
+ *   human_motion_prediction/losses/losses.py:50-61      (mpjpe)
+ * Each entry point below names the reference lines it replaces.  INTEGRATION.md shows the ctypes
+ * binding that goes into the reference's model file.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 data unless the type says otherwise; the caller
+ *    (PyTorch in the shipped host code) owns all memory, nothing is allocated or freed here;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises
+ *    with the host, so every call is capturable into a hipGraph;
+ *  - return value: 0 = ok, > 0 = hipError_t of the failed runtime call / launch,
+ *    -1 = bad argument (null pointer, option without its buffer), -2 = unsupported shape;
+ *  - re-entrant: no global state.
+ */
+#ifndef CISTGCN_HIP_H
+#define CISTGCN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 4-D strided view: n[0] batch, n[1] channel, n[2] x n[3] positions; s[] in elements.
+ * NCTV, NTCV (CISTGCN.py:582) and (N,3,V,T) (:592) views of one buffer differ only in s[]. */
+typedef struct CgView4 {
+  long long n[4];
+  long long s[4];
+} CgView4;
+
+/* ---- generic strided contraction --------------------------------------------------------------
+ * Y[g,m,n] = sum_k A[g,m,k] X[g,k,n] (+ bias[m]); g,m,n,k are composite indices given as int32
+ * element-offset tables, concatenated in `tables` in this order:
+ *   A_g[G] X_g[G] Y_g[G] | A_m[M] Y_m[M] bias_m[M] | X_n[N] Y_n[N] | A_k[K] X_k[K]
+ * Replaces: nn.Conv2d 1x1 / (T,1) / (1,V) / dilated 3x3 (CISTGCN.py:54-72,138-153,165-170,229-234,
+ * 305,323-340,408-418,454-458,541-545), nn.Linear (:341-352,421-440, SE.py), the adjacency
+ * products torch.einsum (:122-124) and torch.matmul / bmm outer products (:187,:471), and the
+ * weight / input gradients of all of them.  splitk > 1 accumulates with fp32 atomics into a dense
+ * output of y_dense_numel = G*M*N elements which is zeroed here first. */
+int cg_contract(const float* A, const float* X, float* Y, const float* bias, const int32_t* tables,
+                int G, int M, int N, int K, int splitk, int a_kfast, int x_kfast,
+                long long y_dense_numel, void* stream);
+
+/* ---- per-channel statistics and the fused BatchNorm / Dropout / PReLU row kernel ---------------
+ * stats[c] = { sum, sum of squares } over batch and positions of x*pre (f64, must be zero on entry).
+ * Replaces the reduction half of nn.BatchNorm{1,2}d in train mode. */
+int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream);
+/* out[c] = sum over batch and positions (bias gradients of the convolutions). */
+int cg_chan_sum(const float* x, const CgView4* xv, float* out, void* stream);
+
+/* y = PReLU( Dropout( (x*pre)*scale + shift ) [+ add] ) [+ add if add_post]
+ * with (scale, shift) from batch statistics (bn_mode 1, also updates running stats exactly like
+ * nn.BatchNorm: momentum, unbiased running_var), running statistics (bn_mode 2) or identity (0).
+ * Replaces every Conv->BN->[Dropout]->[PReLU] tail, `tcn + residual -> PReLU` (CISTGCN.py:266-269),
+ * `PReLU(BN(w*x))` (:388), the SE channel scale (SE.py:20,41) and the residual sums (:390,:586). */
+typedef struct CgNormAct {
+  const float* x;  CgView4 xv;
+  float* y;        CgView4 yv;
+  const float* pre;              /* (B,C) per-sample channel gate or NULL */
+  const float* add; CgView4 av;  /* addend or NULL */
+  int add_post;                  /* 0: before the PReLU, 1: after it */
+  int bn_mode;                   /* 0 none, 1 batch statistics, 2 running statistics */
+  const double* stats;           /* [C][2], bn_mode 1 */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float momentum, eps;
+  float* save_mean; float* save_rstd;   /* [C] written by fwd, read by bwd */
+  float drop_p; const unsigned long long* seed; unsigned int salt;
+  const float* alpha; int alpha_n;      /* PReLU slope(s) (1 or C) or NULL */
+  /* backward only */
+  const float* dy; CgView4 dyv;
+  float* dx; CgView4 dxv;
+  float* dadd; CgView4 dav;
+  float* dpre;
+  double* red;                   /* [2C + alpha_n] f64 scratch, zero on entry */
+  float* dgamma; float* dbeta; float* dalpha;
+} CgNormAct;
+int cg_norm_act_fwd(const CgNormAct* a, void* stream);
+int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream);
+
+/* per-(b,c) mean (kind 0), max with first arg-max (kind 1) or sum (kind 2) over the positions; adjoints of 0/1.
+ * Replaces AdaptiveAvgPool (SE.py:8,27; CISTGCN.py:69,76), .max(-1)[0] chains and .mean((2,3))
+ * (CISTGCN.py:465-467). */
+int cg_reduce_bc(const float* x, const CgView4* xv, int kind, float* out, int32_t* arg, void* stream);
+int cg_reduce_bc_bwd(const float* dout, const int32_t* arg, int kind, float* dx, const CgView4* dxv, void* stream);
+
+/* y = a (+ b) (+ c) on strided views: torch.cat slices (CISTGCN.py:77,378-380,388,468), halo
+ * padding for the dilated FPN convolutions (:54-68), F.interpolate broadcast (:76), the tail
+ * x[:, -1:] + x8^T + act (:595-597). */
+int cg_add3(float* y, const CgView4* yv, const float* a, const CgView4* av, const float* b, const CgView4* bv,
+            const float* c, const CgView4* cv, void* stream);
+int cg_zero(void* p, long long bytes, void* stream);
+
+/* ---- stage kernels --------------------------------------------------------------------------------
+ * feature lift, CISTGCN.py:568-577: x (B,T,V,3) -> (B,10,T,V) = [x, acc, vel, |vel|] and its adjoint */
+int cg_feature_lift_fwd(const float* x, float* f, long long B, long long T, long long V, void* stream);
+int cg_feature_lift_bwd(const float* x, const float* df, float* dx, long long B, long long T, long long V, void* stream);
+/* DSTD_GC._get_stats_, CISTGCN.py:360-371: contiguous (B,C,T,V) -> (B, 2+2T) */
+int cg_dstd_stats_fwd(const float* x, float* out, int B, int C, int T, int V, void* stream);
+int cg_dstd_stats_bwd(const float* x, const float* dout, float* dx, int B, int C, int T, int V, void* stream);
+/* SELayer excitation, SE.py:9-14,30-35: gate = sigmoid(W2 relu(W1 pooled)); W1 (H,C), W2 (C,H) */
+int cg_se_gate_fwd(const float* pooled, const float* W1, const float* W2, float* gate, int B, int C, int H, void* stream);
+int cg_se_gate_bwd(const float* pooled, const float* W1, const float* W2, const float* gate, const float* dgate,
+                   float* dpooled, float* dW1, float* dW2, int B, int C, int H, void* stream);
+/* cumsum over axis 1 of a strided 4-D view (B,L,R1,R2), CISTGCN.py:589 (reverse = adjoint) */
+int cg_cumsum(const float* x, const CgView4* xv, float* y, const CgView4* yv, int reverse, void* stream);
+/* MPJPE, losses/losses.py:50-61 (reduce_axis=[]): pred/target contiguous (N,3); loss is one float */
+int cg_mpjpe_fwd(const float* pred, const float* tgt, float* loss, long long N, void* stream);
+int cg_mpjpe_bwd(const float* pred, const float* tgt, const float* gloss, float* dpred, long long N, void* stream);
+/* advances the device-resident dropout seed (one word) once per training step */
+int cg_seed_bump(unsigned long long* seed, void* stream);
+
+/* ---- fused ST-GCN stage (the dominant kernel) ---------------------------------------------------
+ * Domain_GCNN_layer core, CISTGCN.py:265-266 with :122-124:
+ *   y[b,co,.,.] = bias[co] + sum_ci W[co,ci] * G[b,ci,.,.],
+ *   G = einsum('nctv,nvtq->ncqv', x, Adj)  (domain 0, Adj (B,V,T,T))   or
+ *       einsum('nctv,ntvw->nctw', x, Adj)  (domain 1, Adj (B,T,V,V)).
+ * x, y contiguous (B,C,T,V).  Adjacency is staged in LDS, the graph product and the channel mix
+ * run back to back without the intermediate G touching HBM.  Optional per-channel f64 sums of y
+ * (ystats, [Cout][2], zero on entry) feed the train-mode BatchNorm that follows (:235).
+ * Backward: dx, dAdj, dW, db from dy (dW/db zeroed here, accumulated with fp32 atomics). */
+int cg_stgcn_domain_fwd(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
+                        int B, int Cin, int Cout, int T, int V, int domain, void* stream);
+int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
+                        float* dW, float* dbias, int B, int Cin, int Cout, int T, int V, int domain, void* stream);
+
+/* ---- optimizer on the flat parameter buffer -----------------------------------
+ * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,
+ * bias-corrected moments; optional clip_grad_value_ (environment/train.py:97-98) and gradient
+ * pre-scale (1/world_size after the RCCL all-reduce).  step_count is the 1-based step index. */
+int cg_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, float grad_scale, float clip_value, long long step_count,
+                 void* stream);
+
+/* Gather (direction 0) / scatter (direction 1) between the 698 per-tensor gradient buffers and the
+ * flat fp32 buffer that RCCL all-reduces: ptrs[t] <-> flat + flat_off[t], work pre-chunked
+ * on the host (chunk i = chunk_len[i] elements of tensor chunk_tensor[i] from element chunk_begin[i]). */
+int cg_multi_copy(void* ptrs, const long long* flat_off, const int32_t* chunk_tensor, const int32_t* chunk_begin,
+                  const int32_t* chunk_len, int n_chunks, float* flat, int direction, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,365 @@
+"""Device-agnostic parity checks of the HIP operators against stock-PyTorch references computed on
+the CPU.  The same functions run (a) in `-m "not gpu"` through the test-only HIP shim (tests/hipemu,
+device "cpu") and (b) in `-m gpu` on the MI355X through the real libcistgcn_hip.so (device "cuda").
+
+Tolerance: fp32 north_star bound, max|a-b| <= 1e-4 * max(1, max|ref|) per tensor;
+unit-scale operator tests use the tighter 2e-5.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from cistgcn_amd import ops
+from helpers import assert_close, load_case, make_cfg, state_of
+from oracle import cistgcn_ref as O
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rand(g, *shape, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _leaf(t, device):
+    return t.detach().clone().to(device).requires_grad_(True)
+
+
+def _run(fn_dev, fn_ref, inputs, device, rel=2e-5, what=""):
+    """fn_dev / fn_ref map a list of leaf tensors to one output; compares output and all input grads."""
+    dev_in = [_leaf(t, device) for t in inputs]
+    ref_in = [_leaf(t, "cpu") for t in inputs]
+    ops.begin_step(device)
+    y = fn_dev(*dev_in)
+    r = fn_ref(*ref_in)
+    assert_close(y, r, what + " output", rel=rel)
+    g = _rand(_gen(99), *r.shape)
+    y.backward(g.to(device))
+    r.backward(g)
+    for i, (a, b) in enumerate(zip(dev_in, ref_in)):
+        if b.grad is None:
+            continue
+        assert a.grad is not None, "%s: missing grad for input %d" % (what, i)
+        assert_close(a.grad, b.grad, "%s grad[%d]" % (what, i), rel=rel, floor=max(1e-3, float(b.grad.abs().max())))
+
+
+# ---------------------------------------------------------------------------------------------
+def check_contract(device):
+    g = _gen(1)
+    B, C, O, T, V = 3, 10, 8, 5, 7
+    x = _rand(g, B, C, T, V)
+    cases = [
+        ("oc,bchw->bohw", _rand(g, O, C), x, _rand(g, O), "o"),          # 1x1 conv + bias
+        ("och,bchw->bow", _rand(g, O, C, T), x, None, None),             # (T,1) conv
+        ("ocw,bchw->boh", _rand(g, O, C, V), x, None, None),             # (1,V) conv
+        ("oi,bi->bo", _rand(g, O, 12), _rand(g, B, 12), None, None),      # Linear
+        ("bctv,bvtq->bcqv", x, _rand(g, B, V, T, T), None, None),        # adjacency product, space
+        ("bctv,btvw->bctw", x, _rand(g, B, T, V, V), None, None),        # adjacency product, time
+        ("bvt,bxv->bvtx", _rand(g, B, V, T), _rand(g, B, T, V), None, None),   # rank-1 outer (space)
+        ("bvt,btw->btvw", _rand(g, B, V, T), _rand(g, B, T, V), None, None),   # rank-1 outer (time)
+        ("bt,bv->btv", _rand(g, B, T), _rand(g, B, V), None, None),
+        ("bctv,vtq->bcqv", x, _rand(g, V, T, T), None, None),             # batch-shared adjacency
+    ]
+    for spec, a, xx, bias, bl in cases:
+        ins = [a, xx] + ([bias] if bias is not None else [])
+        def dev(a_, x_, *b_, spec=spec, bl=bl):
+            return ops.contract(spec, a_, x_, b_[0] if b_ else None, bl)
+        def ref(a_, x_, *b_, spec=spec):
+            y = torch.einsum(spec, a_, x_)
+            if b_:
+                shape = [1] * y.dim()
+                shape[spec.split("->")[1].index("o")] = -1
+                y = y + b_[0].view(shape)
+            return y
+        _run(dev, ref, ins, device, what="contract " + spec)
+    # strided (permuted) operand: NTCV view of an NCTV buffer, as in CISTGCN.py:582
+    w = _rand(g, 6, T)
+    _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_.permute(0, 2, 1, 3)),
+         lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_.permute(0, 2, 1, 3)), [w, x], device, what="contract permuted")
+    # many output rows/cols (several tiles, both tile shapes) and a long K (split-K path in the weight grad)
+    xb = _rand(g, 40, 70, 9, 11)
+    wb = _rand(g, 130, 70, scale=0.1)
+    _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_), lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_),
+         [wb, xb], device, rel=1e-4, what="contract tiled/split-K")
+
+
+def check_norm_act(device):
+    g = _gen(2)
+    B, C, T, V = 4, 6, 5, 7
+    x = _rand(g, B, C, T, V, scale=3.0) + 1.5
+    add = _rand(g, B, C, T, V)
+    pre = _rand(g, B, C)
+
+    def make_bn():
+        bn = nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.3 * _rand(g, C)); bn.bias.copy_(0.3 * _rand(g, C))
+            bn.running_mean.copy_(_rand(g, C)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        return bn
+
+    for train in (True, False):
+        for use_pre in (False, True):
+            for add_mode in (None, "pre", "post"):
+                for alpha_n in (0, 1, C):
+                    bn_ref = make_bn()
+                    bn_dev = nn.BatchNorm2d(C)
+                    bn_dev.load_state_dict(bn_ref.state_dict())
+                    bn_dev.to(device)
+                    bn_ref.train(train)
+                    pr_ref = nn.PReLU(alpha_n) if alpha_n else None
+                    pr_dev = None
+                    if pr_ref is not None:
+                        with torch.no_grad():
+                            pr_ref.weight.copy_(0.25 + 0.2 * _rand(g, alpha_n))
+                        pr_dev = nn.PReLU(alpha_n)
+                        pr_dev.load_state_dict(pr_ref.state_dict())
+                        pr_dev.to(device)
+                    ins = [x] + ([pre] if use_pre else []) + ([add] if add_mode else [])
+
+                    def split(ts):
+                        ts = list(ts)
+                        x_ = ts.pop(0)
+                        p_ = ts.pop(0) if use_pre else None
+                        a_ = ts.pop(0) if add_mode else None
+                        return x_, p_, a_
+
+                    def dev(*ts):
+                        x_, p_, a_ = split(ts)
+                        return ops.norm_act(x_, bn=bn_dev, train=train, pre=p_, add=a_, add_post=add_mode == "post", prelu=pr_dev)
+
+                    def ref(*ts):
+                        x_, p_, a_ = split(ts)
+                        v = x_ * p_[:, :, None, None] if p_ is not None else x_
+                        u = bn_ref(v)
+                        if add_mode == "pre":
+                            u = u + a_
+                        if pr_ref is not None:
+                            u = pr_ref(u)
+                        if add_mode == "post":
+                            u = u + a_
+                        return u
+
+                    what = "norm_act train=%s pre=%s add=%s alpha=%d" % (train, use_pre, add_mode, alpha_n)
+                    _run(dev, ref, ins, device, what=what)
+                    for (n1, pd), (_, pr) in zip(bn_dev.named_parameters(), bn_ref.named_parameters()):
+                        assert_close(pd.grad, pr.grad, what + " d" + n1, rel=2e-5, floor=max(1e-3, float(pr.grad.abs().max())))
+                    if pr_ref is not None:
+                        assert_close(pr_dev.weight.grad, pr_ref.weight.grad, what + " dalpha", rel=2e-5,
+                                     floor=max(1e-3, float(pr_ref.weight.grad.abs().max())))
+                    for k in ("running_mean", "running_var", "num_batches_tracked"):
+                        assert_close(getattr(bn_dev, k).float(), getattr(bn_ref, k).float(), what + " " + k, rel=2e-5)
+    # BatchNorm1d on (B,C) and (B,C,L), no-BN PReLU-only, strided input and mm-scale statistics
+    for shape in ((6, C), (4, C, 9)):
+        bn_ref = nn.BatchNorm1d(C)
+        bn_dev = nn.BatchNorm1d(C).to(device)
+        xs = _rand(g, *shape, scale=350.0) + 50.0
+        _run(lambda x_: ops.norm_act(x_, bn=bn_dev, train=True), lambda x_: bn_ref(x_), [xs], device, what="bn1d %s" % (shape,))
+        assert_close(bn_dev.running_var, bn_ref.running_var, "bn1d running_var", rel=2e-5)
+    pr = nn.PReLU()
+    prd = nn.PReLU().to(device)
+    xs = _rand(g, B, T, C, V)
+    _run(lambda x_: ops.norm_act(x_.permute(0, 2, 1, 3), prelu=prd), lambda x_: pr(x_.permute(0, 2, 1, 3)), [xs], device,
+         what="prelu on permuted view")
+    # train-mode BN refuses a single value per channel exactly like nn.BatchNorm (SURVEY appendix "Minimum batch")
+    try:
+        ops.norm_act(torch.zeros(1, C, device=device), bn=nn.BatchNorm1d(C).to(device), train=True)
+        raise AssertionError("expected ValueError for one value per channel")
+    except ValueError:
+        pass
+
+
+def check_dropout(device):
+    """Dropout cannot match the CPU RNG stream; check rate, scale and fwd/bwd mask agreement."""
+    p = 0.3
+    ops.manual_seed(123, device)
+    x = torch.ones(8, 16, 10, 22, device=device, requires_grad=True)
+    ops.begin_step(device, bump_seed=True)
+    y = ops.norm_act(x, train=True, drop_p=p, salt=7)
+    vals = y.detach().cpu()
+    kept = vals != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.02
+    assert torch.allclose(vals[kept], torch.full_like(vals[kept], 1 / (1 - p)))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad.cpu(), vals)                        # same mask and scale in backward
+    y2 = ops.norm_act(x.detach(), train=True, drop_p=p, salt=8)   # another site -> another mask
+    assert not torch.equal(y2.cpu(), vals)
+    ops.begin_step(device, bump_seed=True)                        # next step -> another mask
+    y3 = ops.norm_act(x.detach(), train=True, drop_p=p, salt=7)
+    assert not torch.equal(y3.cpu(), vals)
+    y4 = ops.norm_act(x.detach(), train=False, drop_p=p, salt=7)  # eval: identity
+    assert torch.equal(y4.cpu(), torch.ones_like(vals))
+
+
+def check_reduce_and_gate(device):
+    g = _gen(3)
+    x = _rand(g, 3, 5, 4, 6)
+    _run(ops.mean_bc, lambda t: t.mean((2, 3)), [x], device, what="mean_bc")
+    _run(ops.max_bc, lambda t: t.flatten(2).max(-1)[0], [x], device, what="max_bc")
+    _run(lambda t: ops.max_bc(t.permute(0, 2, 3, 1)), lambda t: t.permute(0, 2, 3, 1).flatten(2).max(-1)[0], [x], device,
+         what="max_bc permuted")
+    C, H = 9, 2
+    _run(ops.se_gate, lambda p, w1, w2: torch.sigmoid(F.linear(F.relu(F.linear(p, w1)), w2)),
+         [_rand(g, 4, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate")
+
+
+def check_copies(device):
+    g = _gen(4)
+    a, b, c = _rand(g, 2, 3, 4, 5), _rand(g, 2, 6, 4, 5), _rand(g, 2, 2)
+    _run(lambda a_, b_, c_: ops.cat_channels([a_, b_, c_], bcast=(False, False, True)),
+         lambda a_, b_, c_: torch.cat((a_, b_, c_[:, :, None, None].expand(-1, -1, 4, 5)), 1), [a, b, c], device, what="cat")
+    _run(lambda a_, b_: ops.cat_channels([a_, b_]), lambda a_, b_: torch.cat((a_, b_), 1), [_rand(g, 3, 4), _rand(g, 3, 7)],
+         device, what="cat 2-D")
+    x, y, z = _rand(g, 2, 6, 5, 3), _rand(g, 2, 3, 5, 4), _rand(g, 2, 4, 5, 3)
+    _run(lambda x_, y_, z_: ops.add3(x_[:, -1:], y_.permute(0, 3, 2, 1), z_),
+         lambda x_, y_, z_: x_[:, -1:] + y_.permute(0, 3, 2, 1) + z_, [x, y, z], device, what="tail add3")
+    _run(lambda t: ops.cumsum_time(t.permute(0, 2, 3, 1)), lambda t: t.permute(0, 2, 3, 1).cumsum(1), [_rand(g, 2, 3, 6, 4)],
+         device, what="cumsum")
+
+
+def check_dilated_convs(device):
+    g = _gen(5)
+    B, Cin, Cout, H, W = 2, 5, 4, 10, 7
+    convs_ref = [nn.Conv2d(Cin, Cout, 3, padding=d, dilation=d) for d in (1, 2, 3)]
+    convs_dev = [nn.Conv2d(Cin, Cout, 3, padding=d, dilation=d) for d in (1, 2, 3)]
+    for r, d in zip(convs_ref, convs_dev):
+        d.load_state_dict(r.state_dict())
+        d.to(device)
+    base = _rand(g, B, H, Cin, W)          # consumed through a permuted (NTCV-style) view
+    _run(lambda t: torch.cat(ops.dilated_convs(t.permute(0, 2, 1, 3), convs_dev), 1),
+         lambda t: torch.cat([c(t.permute(0, 2, 1, 3)) for c in convs_ref], 1), [base], device, what="dilated convs")
+    for r, d in zip(convs_ref, convs_dev):
+        assert_close(d.weight.grad, r.weight.grad, "dilated dW", rel=2e-5, floor=float(r.weight.grad.abs().max()))
+        assert_close(d.bias.grad, r.bias.grad, "dilated db", rel=2e-5, floor=float(r.bias.grad.abs().max()))
+
+
+def check_stage_kernels(device):
+    g = _gen(6)
+    x = 50 + 350 * _rand(g, 3, 6, 5, 3)
+    x[1, 2, 3] = x[1, 3, 3]                 # one zero velocity: sub-gradient 0 of |vel|
+    _run(ops.feature_lift, lambda t: O.CISTGCN.feature_lift(t).contiguous(), [x], device, rel=1e-5, what="feature_lift")
+    xn = _rand(g, 3, 5, 6, 7)
+    _run(ops.dstd_stats, O.CISTGCN.block_stats, [xn], device, what="dstd_stats")
+    pred, tgt = 50 + 350 * _rand(g, 4, 25, 22, 3), 50 + 350 * _rand(g, 4, 25, 22, 3)
+    pd = _leaf(pred, device)
+    pr = _leaf(pred, "cpu")
+    ld = ops.mpjpe(pd, tgt.to(device))
+    lr = O.mpjpe(pr, tgt)
+    assert_close(ld, lr, "mpjpe", rel=1e-6)
+    ld.backward(); lr.backward()
+    assert_close(pd.grad, pr.grad, "mpjpe grad", rel=1e-5, floor=float(pr.grad.abs().max()))
+
+
+def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22))):
+    g = _gen(7)
+    for (B, Cin, Cout, T, V) in shapes:
+        for domain in (0, 1):
+            x = _rand(g, B, Cin, T, V)
+            adj = _rand(g, B, V, T, T, scale=0.3) if domain == 0 else _rand(g, B, T, V, V, scale=0.3)
+            w, bias = _rand(g, Cout, Cin, scale=0.3), _rand(g, Cout)
+            spec = "bctv,bvtq->bcqv" if domain == 0 else "bctv,btvw->bctw"
+            what = "stgcn_domain B%d Cin%d Cout%d T%d V%d dom%d" % (B, Cin, Cout, T, V, domain)
+            _run(lambda x_, a_, w_, b_: ops.stgcn_domain(x_, a_, w_, b_, domain)[0],
+                 lambda x_, a_, w_, b_: torch.einsum("oc,bchw->bohw", w_, torch.einsum(spec, x_, a_)) + b_.view(1, -1, 1, 1),
+                 [x, adj, w, bias], device, rel=5e-5, what=what)
+            ops.begin_step(device)
+            y, st = ops.stgcn_domain(x.to(device), adj.to(device), w.to(device), bias.to(device), domain, want_stats=True)
+            yc = y.detach().cpu().double()
+            ref = torch.stack((yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3))), 1).reshape(-1)
+            assert_close(st.cpu(), ref, what + " channel sums", rel=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole model against the oracle and against the golden vectors of the real reference
+# ---------------------------------------------------------------------------------------------
+def _attr(net, dotted):
+    obj = net
+    for part in dotted.split("."):
+        obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+    return obj
+
+
+def build_pair(C, T, V, device, state=None, seed=0, fused=True):
+    from cistgcn_amd.models import CISTGCN_0
+    torch.manual_seed(seed)
+    ora = O.CISTGCN(*make_cfg(C, T, V))
+    torch.manual_seed(seed)
+    net = CISTGCN_0(*make_cfg(C, T, V))
+    if state is not None:
+        ora.load_state_dict(state)
+    net.load_state_dict(ora.state_dict(), strict=True)
+    net.fused_domain = fused
+    return net.to(device), ora
+
+
+def check_model_golden(device, name, modes=("eval", "train"), fused=True):
+    """Product model vs the vectors the real reference produced (tests/golden, tools/gen_golden.py)."""
+    from helpers import grad_summary
+    rec = load_case(name)
+    C, T, V, B = [int(v) for v in rec["meta"]]
+    for mode in modes:
+        net, _ = build_pair(C, T, V, device, state_of(rec), fused=fused)
+        net.train(mode == "train")
+        x = torch.from_numpy(rec["x"]).to(device).requires_grad_(True)
+        tgt = torch.from_numpy(rec["target"]).to(device)
+        pred, = net(x)
+        loss = ops.mpjpe(pred, tgt)
+        loss.backward()
+        assert_close(pred, rec[mode + "/pred"], "%s %s pred" % (name, mode))
+        assert_close(loss, rec[mode + "/loss"], "%s %s loss" % (name, mode))
+        assert_close(x.grad, rec[mode + "/dx"], "%s %s dL/dx" % (name, mode), floor=float(np.abs(rec[mode + "/dx"]).max()))
+        for k, ref in rec.items():
+            if k.startswith(mode + "/attr/"):
+                got = _attr(net, k[len(mode + "/attr/"):]).detach()
+                assert_close(got[: ref.shape[0]], ref, "%s %s" % (name, k))
+        if mode != "train":
+            continue
+        grads = dict(net.named_parameters())
+        for k, ref in rec.items():
+            if k.startswith("train/grad/"):
+                assert_close(grads[k[len("train/grad/"):]].grad, ref, "%s %s" % (name, k), rel=1e-3, floor=1e-2)
+            elif k.startswith("train/gradsum/"):
+                got = grad_summary(grads[k[len("train/gradsum/"):]].grad)
+                scale = max(1e-2, ref[2])
+                assert np.abs(got[3:] - ref[3:]).max() <= 1e-3 * scale, "%s %s" % (name, k)
+                assert abs(got[2] - ref[2]) <= 1e-3 * scale, "%s %s norm" % (name, k)
+            elif k.startswith("train/state_after/"):
+                assert_close(net.state_dict()[k[len("train/state_after/"):]], ref, "%s %s" % (name, k))
+
+
+def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=True):
+    """Product model vs the CPU oracle on fresh seeded inputs (any size the oracle finishes in seconds)."""
+    g = _gen(1000 + seed)
+    net, ora = build_pair(C, T, V, device, seed=seed, fused=fused)
+    with torch.no_grad():                      # move off the init so Adj / gates are numerically alive
+        for p in ora.parameters():
+            p.add_(0.3 * torch.randn(p.shape, generator=g) / max(1.0, float(p[0].numel()) ** 0.5 if p.dim() > 1 else 3.0))
+    net.load_state_dict(ora.state_dict())
+    x = 50 + scale * torch.randn(B, T, V, 3, generator=g)
+    tgt = x[:, -1:] + 20 * torch.randn(B, 25, V, 3, generator=g)
+    ora.train(); net.train()
+    with torch.no_grad():                      # settle running statistics on both sides identically
+        ora(x)
+    net.load_state_dict(ora.state_dict())
+    ora.train(mode == "train"); net.train(mode == "train")
+    xo = x.clone().requires_grad_(True)
+    xd = x.clone().to(device).requires_grad_(True)
+    po, = ora(xo)
+    pd, = net(xd)
+    lo = O.mpjpe(po, tgt)
+    ld = ops.mpjpe(pd, tgt.to(device))
+    lo.backward(); ld.backward()
+    assert_close(pd, po, "pred")
+    assert_close(ld, lo, "loss")
+    assert_close(xd.grad, xo.grad, "dL/dx", floor=float(xo.grad.abs().max()))
+    gd = dict(net.named_parameters())
+    for k, p in ora.named_parameters():
+        assert_close(gd[k].grad, p.grad, "grad " + k, rel=1e-3, floor=max(1e-2, float(p.grad.norm())))
+    for k in ("st_gcnns.0.dsgn.Adj", "st_gcnns.2.tsgn.Adj", "st_gcnns_o.0.dsgn.Adj", "st_gcnns.1.w1", "st_gcnns_o.0.w2",
+              "context_layer.joints", "context_layer.seq_joints_dims"):
+        assert_close(_attr(net, k), _attr(ora, k), k)
+    sd, so = net.state_dict(), ora.state_dict()
+    for k in so:
+        if "running" in k or "num_batches" in k:
+            assert_close(sd[k].float(), so[k].float(), k)

@@ -1,0 +1,36 @@
+"""TEST-ONLY: compile the shipped .hip sources with g++ against the HIP shim in this directory,
+producing tests/hipemu/_build/libcistgcn_emu.so (git-ignored; never shipped, never loaded by the
+product package)."""
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "cistgcn_amd", "csrc")
+OUT = os.path.join(HERE, "_build", "libcistgcn_emu.so")
+
+
+def build(force=False):
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h")]
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in deps):
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    objs = []
+    for s in srcs + [os.path.join(HERE, "emu_runtime.cpp")]:
+        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
+        cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes",
+               "-I", HERE, "-I", CSRC, "-c", s, "-o", o]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed on %s:\n%s" % (s, res.stderr[-4000:]))
+        objs.append(o)
+    res = subprocess.run(["g++", "-shared", "-pthread", "-o", OUT] + objs, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stderr[-4000:])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

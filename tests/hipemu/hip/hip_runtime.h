@@ -1,0 +1,81 @@
+// TEST-ONLY shim: lets the CPU-only build container execute the *same* .hip kernel sources that
+// ship for gfx950, by mapping every HIP thread of a workgroup to an OS thread (real barriers, real
+// shared memory semantics, wave-level shuffles through a per-wave exchange slot).  It exists so
+// that indexing / synchronisation bugs surface in `pytest -m "not gpu"`; it is never shipped,
+// never loaded by the product package, and has nothing to do with performance.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+extern thread_local dim3 threadIdx;
+extern dim3 blockIdx, blockDim, gridDim;
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_DYNAMIC_SHARED(type, var) extern type var[];
+
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+typedef void* hipStream_t;
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+
+using std::max;
+using std::min;
+
+namespace hipemu {
+void syncthreads();
+void wave_barrier(int wave);
+void* wave_slot(int wave, int lane);   // 16 bytes per lane
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+}  // namespace hipemu
+
+static inline void __syncthreads() { hipemu::syncthreads(); }
+
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+  static_assert(sizeof(T) <= 16, "shuffle payload");
+  const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64;
+  *reinterpret_cast<T*>(hipemu::wave_slot(wave, lane)) = v;
+  hipemu::wave_barrier(wave);
+  const int src = lane + (int)delta;
+  T r = v;
+  if (src < 64 && (src / width) == (lane / width) && wave * 64 + src < (int)blockDim.x) r = *reinterpret_cast<T*>(hipemu::wave_slot(wave, src));
+  hipemu::wave_barrier(wave);
+  return r;
+}
+
+template <typename T>
+static inline T hipemu_atomic_add_fp(T* p, T v) {
+  using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+  U* up = reinterpret_cast<U*>(p);
+  U old = __atomic_load_n(up, __ATOMIC_RELAXED);
+  for (;;) {
+    T cur; memcpy(&cur, &old, sizeof(T));
+    T nv = cur + v; U nu; memcpy(&nu, &nv, sizeof(T));
+    if (__atomic_compare_exchange_n(up, &old, nu, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) return cur;
+  }
+}
+static inline float atomicAdd(float* p, float v) { return hipemu_atomic_add_fp(p, v); }
+static inline double atomicAdd(double* p, double v) { return hipemu_atomic_add_fp(p, v); }
+static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol of
+include/cistgcn_hip.h, the nn.Module surface mirrors the reference, and nothing runs on the CPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import CASES, load_case, make_cfg, state_of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cistgcn_amd import _lib, build
+    path = build.build()
+    header = open(os.path.join(ROOT, "include", "cistgcn_hip.h")).read()
+    declared = set(re.findall(r"^int (cg_\w+)\(", header, flags=re.M))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    handle = ctypes.CDLL(path)
+    for name in declared:
+        assert hasattr(handle, name), name
+    _lib.declare(handle)
+
+
+def test_registry_and_choose_net_errors():
+    from cistgcn_amd import models
+    assert models.CISTGCN_0 is models.CISTGCN_eval
+    assert models.CISTGCN_0.__name__ == "CISTGCN"          # callers branch on the class name (test.py:99)
+    assert models.CISTGCN_0.__module__.endswith("models.CISTGCN.CISTGCN")
+    with pytest.raises(ValueError):
+        models.choose_net("NoSuchNet", None)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_matches_reference_manifest(name):
+    from cistgcn_amd.models import CISTGCN_0
+    rec = load_case(name)
+    C, T, V, _ = [int(v) for v in rec["meta"]]
+    net = CISTGCN_0(*make_cfg(C, T, V))
+    ref = state_of(rec)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in sd)
+    net.load_state_dict(ref, strict=True)
+
+
+def test_same_seed_same_init_as_oracle():
+    from cistgcn_amd.models import CISTGCN_0
+    from oracle import cistgcn_ref as O
+    torch.manual_seed(0)
+    a = CISTGCN_0(*make_cfg(16, 10, 22)).state_dict()
+    torch.manual_seed(0)
+    b = O.CISTGCN(*make_cfg(16, 10, 22)).state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in b)
+
+
+def test_ctor_keeps_config_lists_intact():
+    from cistgcn_amd.models import CISTGCN_0
+    arch, learn = make_cfg(8, 10, 22)
+    CISTGCN_0(arch, learn)
+    CISTGCN_0(arch, learn)
+    assert arch.model_params.input_gcn.model_complexity == [8] * 4
+    assert arch.model_params.output_gcn.model_complexity == [3]
+
+
+def test_no_cpu_path():
+    from cistgcn_amd import _lib, ops
+    from cistgcn_amd.models import CISTGCN_0
+    _lib._host_pointers_ok = False
+    net = CISTGCN_0(*make_cfg(8, 10, 22))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(2, 10, 22, 3))
+    with pytest.raises(RuntimeError):
+        ops.mpjpe(torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "cistgcn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f

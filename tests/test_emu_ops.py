@@ -1,0 +1,24 @@
+"""Operator parity on the CPU-only box: the shipped .hip kernels, compiled by g++ against the
+test-only HIP shim (tests/hipemu), are checked against stock-PyTorch references."""
+import pytest
+
+import checks
+import emu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_kernels():
+    emu.install()
+    yield
+    emu.uninstall()
+
+
+@pytest.mark.parametrize("check", [checks.check_contract, checks.check_norm_act, checks.check_dropout,
+                                   checks.check_reduce_and_gate, checks.check_copies, checks.check_dilated_convs,
+                                   checks.check_stage_kernels], ids=lambda f: f.__name__)
+def test_operator(check):
+    check("cpu")
+
+
+def test_stgcn_domain_small():
+    checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9)))
