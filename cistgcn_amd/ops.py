@@ -75,7 +75,16 @@ _arenas = {}
 _seeds = {}
 
 
+def _dev(device):
+    """Canonical device key ("cuda" and "cuda:0" must name the same scratch and seed)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def _arena(device):
+    device = _dev(device)
     a = _arenas.get(device)
     if a is None:
         a = _arenas[device] = _Arena(device)
@@ -83,6 +92,7 @@ def _arena(device):
 
 
 def seed_state(device):
+    device = _dev(device)
     s = _seeds.get(device)
     if s is None:
         s = _seeds[device] = torch.full((1,), 0x5DEECE66D, dtype=torch.int64, device=device)
@@ -90,12 +100,12 @@ def seed_state(device):
 
 
 def manual_seed(seed, device):
-    seed_state(torch.device(device)).fill_(int(seed))
+    seed_state(device).fill_(int(seed))
 
 
 def begin_step(device, bump_seed=False):
     """Start of a forward pass: re-zero the statistics scratch, optionally advance the dropout seed."""
-    device = torch.device(device)
+    device = _dev(device)
     _arena(device).begin_step()
     if bump_seed:
         s = seed_state(device)

@@ -280,12 +280,12 @@ def _attr(net, dotted):
     return obj
 
 
-def build_pair(C, T, V, device, state=None, seed=0, fused=True):
+def build_pair(C, T, V, device, state=None, seed=0, fused=True, **cfg_kw):
     from cistgcn_amd.models import CISTGCN_0
     torch.manual_seed(seed)
-    ora = O.CISTGCN(*make_cfg(C, T, V))
+    ora = O.CISTGCN(*make_cfg(C, T, V, **cfg_kw))
     torch.manual_seed(seed)
-    net = CISTGCN_0(*make_cfg(C, T, V))
+    net = CISTGCN_0(*make_cfg(C, T, V, **cfg_kw))
     if state is not None:
         ora.load_state_dict(state)
     net.load_state_dict(ora.state_dict(), strict=True)
@@ -308,7 +308,7 @@ def check_model_golden(device, name, modes=("eval", "train"), fused=True):
         loss.backward()
         assert_close(pred, rec[mode + "/pred"], "%s %s pred" % (name, mode))
         assert_close(loss, rec[mode + "/loss"], "%s %s loss" % (name, mode))
-        assert_close(x.grad, rec[mode + "/dx"], "%s %s dL/dx" % (name, mode), floor=float(np.abs(rec[mode + "/dx"]).max()))
+        assert_close(x.grad, rec[mode + "/dx"], "%s %s dL/dx" % (name, mode), floor=1e-1)
         for k, ref in rec.items():
             if k.startswith(mode + "/attr/"):
                 got = _attr(net, k[len(mode + "/attr/"):]).detach()
@@ -328,34 +328,50 @@ def check_model_golden(device, name, modes=("eval", "train"), fused=True):
                 assert_close(net.state_dict()[k[len("train/state_after/"):]], ref, "%s %s" % (name, k))
 
 
-def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=True):
+def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=True, **cfg_kw):
     """Product model vs the CPU oracle on fresh seeded inputs (any size the oracle finishes in seconds)."""
     g = _gen(1000 + seed)
-    net, ora = build_pair(C, T, V, device, seed=seed, fused=fused)
+    net, ora = build_pair(C, T, V, device, seed=seed, fused=fused, **cfg_kw)
+    To = cfg_kw.get("To", 25)
     with torch.no_grad():                      # move off the init so Adj / gates are numerically alive
         for p in ora.parameters():
             p.add_(0.3 * torch.randn(p.shape, generator=g) / max(1.0, float(p[0].numel()) ** 0.5 if p.dim() > 1 else 3.0))
     net.load_state_dict(ora.state_dict())
     x = 50 + scale * torch.randn(B, T, V, 3, generator=g)
-    tgt = x[:, -1:] + 20 * torch.randn(B, 25, V, 3, generator=g)
+    tgt = x[:, -1:] + 20 * torch.randn(B, To, V, 3, generator=g)
     ora.train(); net.train()
     with torch.no_grad():                      # settle running statistics on both sides identically
         ora(x)
     net.load_state_dict(ora.state_dict())
     ora.train(mode == "train"); net.train(mode == "train")
+    import copy
+    ora64 = copy.deepcopy(ora).double()        # ground truth: the same algorithm in fp64
     xo = x.clone().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
     xd = x.clone().to(device).requires_grad_(True)
     po, = ora(xo)
+    p64, = ora64(x64)
     pd, = net(xd)
     lo = O.mpjpe(po, tgt)
+    l64 = O.mpjpe(p64, tgt.double())
     ld = ops.mpjpe(pd, tgt.to(device))
-    lo.backward(); ld.backward()
+    lo.backward(); l64.backward(); ld.backward()
     assert_close(pd, po, "pred")
     assert_close(ld, lo, "loss")
-    assert_close(xd.grad, xo.grad, "dL/dx", floor=float(xo.grad.abs().max()))
-    gd = dict(net.named_parameters())
+
+    def as_accurate_as_cpu(got, cpu32, ref64, what):
+        """The HIP result must be as close to the fp64 truth as the reference's own fp32 CPU path is (x8 slack),
+        or within 1e-4 relative (floor 1e-2) of it."""
+        ref64 = ref64.detach()
+        e_hip = float((got.detach().cpu().double() - ref64).abs().max())
+        e_cpu = float((cpu32.detach().double() - ref64).abs().max())
+        bound = max(8.0 * e_cpu, 1e-4 * max(1e-2, float(ref64.abs().max())))
+        assert e_hip <= bound, "%s: HIP err vs fp64 %.3e > bound %.3e (CPU fp32 err vs fp64 %.3e)" % (what, e_hip, bound, e_cpu)
+
+    as_accurate_as_cpu(xd.grad, xo.grad, x64.grad, "dL/dx")
+    gd, g64 = dict(net.named_parameters()), dict(ora64.named_parameters())
     for k, p in ora.named_parameters():
-        assert_close(gd[k].grad, p.grad, "grad " + k, rel=1e-3, floor=max(1e-2, float(p.grad.norm())))
+        as_accurate_as_cpu(gd[k].grad, p.grad, g64[k].grad, "grad " + k)
     for k in ("st_gcnns.0.dsgn.Adj", "st_gcnns.2.tsgn.Adj", "st_gcnns_o.0.dsgn.Adj", "st_gcnns.1.w1", "st_gcnns_o.0.w2",
               "context_layer.joints", "context_layer.seq_joints_dims"):
         assert_close(_attr(net, k), _attr(ora, k), k)

@@ -10,11 +10,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
 
-def make_cfg(C, T, V, dropout=0.0, To=25):
+def make_cfg(C, T, V, dropout=0.0, To=25, hidden=64):
     """Attribute-style config with the schema of the reference YAML (train_h36m.yaml:1-28)."""
     arch = NS(model_params=NS(
         input_n=T, output_n=To, joints=V, n_txcnn_layers=4, txc_kernel_size=3, reduction=8,
-        hidden_dim=64, clipping=15,
+        hidden_dim=hidden, clipping=15,
         input_gcn=NS(model_complexity=[C] * 4, interpretable=[True] * 5),
         output_gcn=NS(model_complexity=[3], interpretable=[True])))
     return arch, NS(dropout=dropout)

@@ -74,4 +74,4 @@ def test_graph_replay_matches_eager():
     loss.backward()
     assert abs(loss.item() - loss_g) <= 1e-5 * max(1.0, abs(loss.item()))
     for a, p in zip(grads_g, net.parameters()):
-        assert torch.allclose(a, p.grad, rtol=1e-3, atol=1e-4 * max(1e-2, float(p.grad.abs().max())))
+        assert torch.allclose(a, p.grad, rtol=1e-3, atol=max(1e-5, 1e-4 * float(p.grad.abs().max())))   # atomics reorder sums

@@ -23,12 +23,13 @@ import torch
 REF_ROOT = "/root/reference"
 OUT_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
-# name -> (C, T_in, V, B)
+# name -> (C, T_in, V, B).  B >= 4: several train-mode BatchNorms normalise over the batch axis only
+# (SURVEY appendix 'Minimum batch'); with 2-3 samples their backward is numerically degenerate.
 CASES = {
     "h36m_c8_t10_v22": (8, 10, 22, 4),     # reference-YAML H3.6M shape (train_h36m.yaml:4-6)
-    "h36m_c8_t50_v22": (8, 50, 22, 3),     # BASELINE.json configs[0]/[1] shape
-    "amass_c16_t10_v18": (16, 10, 18, 3),  # reference-YAML AMASS joints (train_amass.yaml:5)
-    "cmu_c8_t50_v25": (8, 50, 25, 2),      # BASELINE.json "25-joint" shape
+    "h36m_c8_t50_v22": (8, 50, 22, 4),     # BASELINE.json configs[0]/[1] shape
+    "amass_c16_t10_v18": (16, 10, 18, 4),  # reference-YAML AMASS joints (train_amass.yaml:5)
+    "cmu_c8_t50_v25": (8, 50, 25, 4),      # BASELINE.json "25-joint" shape
 }
 FULL_GRADS = {"h36m_c8_t10_v22"}
 
@@ -86,8 +87,8 @@ def attrs(net, nblocks):
     out = {}
     blocks = [("st_gcnns.%d" % i, net.st_gcnns[i]) for i in nblocks] + [("st_gcnns_o.0", net.st_gcnns_o[0])]
     for name, blk in blocks:
-        out[name + ".dsgn.Adj"] = blk.dsgn.Adj[:2]
-        out[name + ".tsgn.Adj"] = blk.tsgn.Adj[:2]
+        out[name + ".dsgn.Adj"] = blk.dsgn.Adj[:1]
+        out[name + ".tsgn.Adj"] = blk.tsgn.Adj[:1]
     for i, blk in enumerate(net.st_gcnns):
         out["st_gcnns.%d.w1" % i], out["st_gcnns.%d.w2" % i] = blk.w1, blk.w2
     out["st_gcnns_o.0.w1"], out["st_gcnns_o.0.w2"] = net.st_gcnns_o[0].w1, net.st_gcnns_o[0].w2

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench (default + wide workload).  Logs under gpurun_out/.
+# One GPU-box session: parity tests, smoke, bench, rocprof kernel stats.  Logs under gpurun_out/.
 # A step that is killed by its timeout stops the session (no further GPU work after a hang).
 set -u
 mkdir -p gpurun_out
@@ -14,11 +14,11 @@ run() {  # name, timeout, command...
 }
 : > gpurun_out/session.log
 run build 300 python -c "import __graft_entry__ as g; g.build()"
-run pytest_gpu 900 python -m pytest tests -m gpu -q -x --timeout 600 "$@"
-tail -5 gpurun_out/pytest_gpu.log
+run pytest_gpu 900 python -m pytest tests -m gpu -q --timeout 600
+grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -3
 run smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
 tail -2 gpurun_out/smoke.log
 run bench_default 600 python bench.py --steps 50 --warmup 10
-tail -1 gpurun_out/bench_default.log
-run bench_c64 600 python bench.py --steps 10 --warmup 3 --workload cistgcn64_b256_t50_v22 --no-cpu-baseline
-tail -1 gpurun_out/bench_c64.log
+tail -c 300 gpurun_out/bench_default.log
+run profile 900 bash tools/gpu_profile.sh cistgcn8_b16_t50_v22
+tail -40 gpurun_out/profile.log
