@@ -47,7 +47,7 @@ class NormAct(ctypes.Structure):
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
-    "cg_contract": [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, LL, P],
+    "cg_contract": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, LL, P],
     "cg_chan_stats": [P, POINTER(View4), P, P, P],
     "cg_chan_sum": [P, POINTER(View4), P, P],
     "cg_norm_act_fwd": [POINTER(NormAct), P],
@@ -67,7 +67,8 @@ _SIGNATURES = {
     "cg_mpjpe_bwd": [P, P, P, P, LL, P],
     "cg_seed_bump": [P, P],
     "cg_stgcn_domain_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cg_stgcn_domain_bwd_ws_floats": [c_int, c_int],
     "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }
@@ -79,7 +80,7 @@ def declare(handle):
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(handle, name)     # AttributeError if the library does not export it
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_longlong if name.endswith("_ws_floats") else c_int
     return handle
 
 

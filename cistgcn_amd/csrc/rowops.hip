@@ -10,14 +10,14 @@
 // :305-358), SELayer scale (SE.py:20,41).
 #include "cg_common.h"
 
-#define CG_ROW_LOOP(P_, p_) for (long long p_ = threadIdx.x; p_ < (P_); p_ += blockDim.x)
+// Row loop: p runs over the n2*n3 positions of one (batch, channel) row; (i2, i3) are derived once per
+// element with one 32-bit division and shared by every view of the kernel (all views have the same dims).
+#define CG_ROW_LOOP(P_, p_) for (int p_ = threadIdx.x; p_ < (int)(P_); p_ += blockDim.x)
+#define CG_POS(v_, p_) const int i2_ = (p_) / (int)(v_).n[3]; const int i3_ = (p_) - i2_ * (int)(v_).n[3];
+#define CG_OFF(v_) ((long long)i2_ * (v_).s[2] + (long long)i3_ * (v_).s[3])
 
 __device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c) {
   return (long long)b * v.s[0] + (long long)c * v.s[1];
-}
-__device__ __forceinline__ long long cg_pos_off(const CgView4& v, long long p) {
-  const long long i2 = p / v.n[3], i3 = p - i2 * v.n[3];
-  return i2 * v.s[2] + i3 * v.s[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -32,7 +32,8 @@ __global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, co
   const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
   double s = 0.0, q = 0.0;
   CG_ROW_LOOP(P, p) {
-    const float v = x[base + cg_pos_off(xv, p)] * w;
+    CG_POS(xv, p)
+    const float v = x[base + CG_OFF(xv)] * w;
     s += (double)v;
     q += (double)v * (double)v;
   }
@@ -62,7 +63,7 @@ __global__ void cg_chan_sum_kernel(const float* __restrict__ x, CgView4 xv, floa
   double s = 0.0;
   for (int b = 0; b < xv.n[0]; ++b) {
     const long long base = cg_row_base(xv, b, c);
-    CG_ROW_LOOP(P, p) s += (double)x[base + cg_pos_off(xv, p)];
+    CG_ROW_LOOP(P, p) { CG_POS(xv, p) s += (double)x[base + CG_OFF(xv)]; }
   }
   s = cg_block_sum(s, red);
   if (threadIdx.x == 0) out[c] = (float)s;
@@ -102,6 +103,9 @@ struct CgNormAct {
   float* dgamma; float* dbeta; float* dalpha;
 };
 
+// u = (v - mean) * scale + shift, scale = gamma * rstd, shift = beta: the mean is subtracted FIRST (as
+// nn.BatchNorm does); the folded form v*scale + (beta - mean*scale) cancels catastrophically when
+// |mean| >> std.
 struct CgChanAffine { float scale, shift, mean, rstd; };
 
 __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c, bool backward) {
@@ -132,7 +136,7 @@ __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c
     if (blockIdx.y == 0 && threadIdx.x == 0) { a.save_mean[c] = r.mean; a.save_rstd[c] = r.rstd; }
   }
   r.scale = a.gamma[c] * r.rstd;
-  r.shift = a.beta[c] - r.mean * r.scale;
+  r.shift = a.beta[c];
   return r;
 }
 
@@ -146,26 +150,27 @@ __global__ void cg_norm_act_fwd_kernel(CgNormAct a) {
   const long long bx = cg_row_base(a.xv, b, c), by = cg_row_base(a.yv, b, c);
   const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
   CG_ROW_LOOP(P, p) {
-    float u = a.x[bx + cg_pos_off(a.xv, p)] * w * af.scale + af.shift;
+    CG_POS(a.xv, p)
+    float u = (a.x[bx + CG_OFF(a.xv)] * w - af.mean) * af.scale + af.shift;
     if (a.drop_p > 0.f) u *= cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
-    if (a.add && !a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
+    if (a.add && !a.add_post) u += a.add[ba + CG_OFF(a.av)];
     if (a.alpha) u = u > 0.f ? u : alpha * u;
-    if (a.add && a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
-    a.y[by + cg_pos_off(a.yv, p)] = u;
+    if (a.add && a.add_post) u += a.add[ba + CG_OFF(a.av)];
+    a.y[by + CG_OFF(a.yv)] = u;
   }
 }
 
 // gradient at the affine output (after PReLU and dropout are undone); also returns pre-activation u
 __device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChanAffine& af, float w, float alpha,
                                                 unsigned long long seed, int b, int c, long long C, long long P,
-                                                long long p, long long bx, long long ba, long long bdy,
-                                                float& v, float& u, float& gu) {
-  v = a.x[bx + cg_pos_off(a.xv, p)] * w;
+                                                int p, int i2_, int i3_, long long bx, long long ba, long long bdy,
+                                                float& v, float& u, float& gu, float& g) {
+  v = a.x[bx + CG_OFF(a.xv)] * w;
   float keep = 1.f;
   if (a.drop_p > 0.f) keep = cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
-  u = (v * af.scale + af.shift) * keep;
-  if (a.add && !a.add_post) u += a.add[ba + cg_pos_off(a.av, p)];
-  const float g = a.dy[bdy + cg_pos_off(a.dyv, p)];
+  u = ((v - af.mean) * af.scale + af.shift) * keep;
+  if (a.add && !a.add_post) u += a.add[ba + CG_OFF(a.av)];
+  g = a.dy[bdy + CG_OFF(a.dyv)];
   gu = a.alpha ? (u > 0.f ? g : alpha * g) : g;
   return gu * keep;
 }
@@ -183,11 +188,12 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a) {
   const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
   CG_ROW_LOOP(P, p) {
-    float v, u, gu;
-    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, bx, ba, bdy, v, u, gu);
+    CG_POS(a.xv, p)
+    float v, u, gu, g;
+    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, i2_, i3_, bx, ba, bdy, v, u, gu, g);
     s1 += (double)gh;
     s2 += (double)gh * (double)((v - af.mean) * af.rstd);
-    if (a.alpha && !(u > 0.f)) sa += (double)a.dy[bdy + cg_pos_off(a.dyv, p)] * (double)u;
+    if (a.alpha && !(u > 0.f)) sa += (double)g * (double)u;
   }
   s1 = cg_block_sum(s1, red);
   s2 = cg_block_sum(s2, red + 16);
@@ -220,14 +226,15 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a) {
   }
   double sp = 0.0;
   CG_ROW_LOOP(P, p) {
-    float v, u, gu;
-    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, bx, ba, bdy, v, u, gu);
+    CG_POS(a.xv, p)
+    float v, u, gu, g;
+    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, i2_, i3_, bx, ba, bdy, v, u, gu, g);
     float gv;
     if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
     else gv = gh * af.scale;
-    if (a.dx) a.dx[bdx + cg_pos_off(a.dxv, p)] = gv * w;
-    if (a.dadd) a.dadd[bda + cg_pos_off(a.dav, p)] = gu;
-    if (a.dpre) sp += (double)gv * (double)a.x[bx + cg_pos_off(a.xv, p)];
+    if (a.dx) a.dx[bdx + CG_OFF(a.dxv)] = gv * w;
+    if (a.dadd) a.dadd[bda + CG_OFF(a.dav)] = gu;
+    if (a.dpre) sp += (double)gv * (double)a.x[bx + CG_OFF(a.xv)];
   }
   if (a.dpre) {
     sp = cg_block_sum(sp, red);
@@ -298,13 +305,14 @@ __global__ void cg_reduce_bc_kernel(const float* __restrict__ x, CgView4 xv, int
   const long long base = cg_row_base(xv, b, c);
   if (kind != 1) {
     double s = 0.0;
-    CG_ROW_LOOP(P, p) s += (double)x[base + cg_pos_off(xv, p)];
+    CG_ROW_LOOP(P, p) { CG_POS(xv, p) s += (double)x[base + CG_OFF(xv)]; }
     s = cg_block_sum(s, red);
     if (threadIdx.x == 0) out[(long long)b * C + c] = kind == 0 ? (float)(s / (double)P) : (float)s;
   } else {
     float best = -INFINITY; int bi = 0x7fffffff;
     CG_ROW_LOOP(P, p) {
-      const float v = x[base + cg_pos_off(xv, p)];
+      CG_POS(xv, p)
+      const float v = x[base + CG_OFF(xv)];
       if (v > best || (v == best && (int)p < bi) || bi == 0x7fffffff) { best = v; bi = (int)p; }
     }
     sv[threadIdx.x] = best; si[threadIdx.x] = bi;
@@ -339,7 +347,7 @@ __global__ void cg_reduce_bc_bwd_kernel(const float* __restrict__ dout, const in
   const float g = dout[(long long)b * C + c];
   const int hit = kind == 1 ? arg[(long long)b * C + c] : -1;
   const float gm = g / (float)P;
-  CG_ROW_LOOP(P, p) dx[base + cg_pos_off(dxv, p)] = kind == 0 ? gm : ((int)p == hit ? g : 0.f);
+  CG_ROW_LOOP(P, p) { CG_POS(dxv, p) dx[base + CG_OFF(dxv)] = kind == 0 ? gm : (p == hit ? g : 0.f); }
 }
 
 extern "C" int cg_reduce_bc_bwd(const float* dout, const int32_t* arg, int kind, float* dx, const CgView4* dxv, void* stream_) {
@@ -360,10 +368,11 @@ __global__ void cg_add3_kernel(float* __restrict__ y, CgView4 yv, const float* _
   const long long by = cg_row_base(yv, b, c), ba = cg_row_base(av, b, c);
   const long long bb = b_ ? cg_row_base(bv, b, c) : 0, bc = c_ ? cg_row_base(cv, b, c) : 0;
   CG_ROW_LOOP(P, p) {
-    float v = a[ba + cg_pos_off(av, p)];
-    if (b_) v += b_[bb + cg_pos_off(bv, p)];
-    if (c_) v += c_[bc + cg_pos_off(cv, p)];
-    y[by + cg_pos_off(yv, p)] = v;
+    CG_POS(yv, p)
+    float v = a[ba + CG_OFF(av)];
+    if (b_) v += b_[bb + CG_OFF(bv)];
+    if (c_) v += c_[bc + CG_OFF(cv)];
+    y[by + CG_OFF(yv)] = v;
   }
 }
 

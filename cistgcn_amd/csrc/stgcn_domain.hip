@@ -159,7 +159,12 @@ template <int DOMAIN>
 __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
                                                                   const float* __restrict__ W, const float* __restrict__ dy,
                                                                   float* __restrict__ dx, float* __restrict__ dadj,
-                                                                  float* __restrict__ dW, float* __restrict__ dbias, CgDomainGeom g) {
+                                                                  float* __restrict__ dW, float* __restrict__ dbias, int replicas,
+                                                                  CgDomainGeom g) {
+  // weight/bias gradients are accumulated with fp32 atomics; spreading the workgroups over `replicas`
+  // copies keeps same-address contention low (summed by cg_dom_fold_replicas_kernel afterwards)
+  dW += (long long)(blockIdx.x % replicas) * (g.Cout * g.Cin + g.Cout);
+  if (dbias) dbias = dW + g.Cout * g.Cin;
   float* sA = reinterpret_cast<float*>(cg_dyn_lds);
   float* sX = sA + g.GT * g.J * g.Jp;
   float* sG = sX + ((g.Cin * g.GT * g.J + 3) & ~3);
@@ -289,6 +294,18 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* _
   }
 }
 
+__global__ void cg_dom_fold_replicas_kernel(const float* __restrict__ ws, int replicas, int n_w, int n_b,
+                                            float* __restrict__ dW, float* __restrict__ dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_w + n_b) return;
+  float s = 0.f;
+  for (int r = 0; r < replicas; ++r) s += ws[(long long)r * (n_w + n_b) + i];
+  if (i < n_w) dW[i] = s;
+  else if (dbias) dbias[i - n_w] = s;
+}
+
+#define CG_DOM_REPLICAS 32
+
 // ---- host side -------------------------------------------------------------------------------------
 static size_t cg_dom_lds_bytes(const CgDomainGeom& g, bool bwd) {
   size_t f = (size_t)g.GT * g.J * g.Jp + (((size_t)g.Cin * g.GT * g.J + 3) & ~(size_t)3) + (size_t)g.Cinp * g.PP;
@@ -347,15 +364,20 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   return cg_launch_status();
 }
 
+extern "C" long long cg_stgcn_domain_bwd_ws_floats(int Cin, int Cout) {
+  return (long long)CG_DOM_REPLICAS * ((long long)Cout * Cin + Cout);
+}
+
 extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
-                                   float* dW, float* dbias, int B, int Cin, int Cout, int T, int V, int domain, void* stream_) {
-  if (!x || !adj || !W || !dy || !dx || !dadj || !dW) return CG_EARG;
+                                   float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain,
+                                   void* stream_) {
+  if (!x || !adj || !W || !dy || !dx || !dadj || !dW || !ws) return CG_EARG;
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, true);
   if (st != CG_OK) return st;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(dW, 0, (size_t)Cout * Cin * sizeof(float), stream);
-  if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), stream);
+  const int n_w = Cout * Cin, n_b = Cout;
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)CG_DOM_REPLICAS * (n_w + n_b) * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   const size_t lds = cg_dom_lds_bytes(g, true);
   dim3 grid((unsigned)(B * g.ntiles)), block(256);
@@ -364,7 +386,12 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<0>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, dW, dbias, g);
-  else hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<1>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, dW, dbias, g);
+  float* wsb = ws + n_w;   // non-null marker: bias partials live behind the weight partials of each replica
+  if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<0>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, ws, wsb, CG_DOM_REPLICAS, g);
+  else hipLaunchKernelGGL(cg_stgcn_domain_bwd_kernel<1>, grid, block, lds, stream, x, adj, W, dy, dx, dadj, ws, wsb, CG_DOM_REPLICAS, g);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  hipLaunchKernelGGL(cg_dom_fold_replicas_kernel, dim3((unsigned)((n_w + n_b + 255) / 256)), dim3(256), 0, stream, ws, CG_DOM_REPLICAS,
+                     n_w, n_b, dW, dbias);
   return cg_launch_status();
 }

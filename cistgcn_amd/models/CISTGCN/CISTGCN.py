@@ -147,29 +147,32 @@ class ContextLayer(nn.Module):
 
 
 # ---- linear maps as contractions (weights are viewed, never copied) ------------------------------
-def _pointwise(x, conv):
+# Each helper returns (y, stats): stats are the f64 per-channel sums of y from the contraction epilogue
+# when `stats=True` (a train-mode BatchNorm follows), else None.
+def _pointwise(x, conv, stats=False):
     """1x1 convolution over the channel axis of a 3-D or 4-D (possibly strided) tensor."""
     w = conv.weight.view(conv.out_channels, conv.in_channels)
     spec = "oc,bchw->bohw" if x.dim() == 4 else "oc,bcv->bov"
-    return ops.contract(spec, w, x, conv.bias, "o" if conv.bias is not None else None)
+    bl = "o" if conv.bias is not None else None
+    return ops.contract_stats(spec, w, x, conv.bias, bl) if stats else (ops.contract(spec, w, x, conv.bias, bl), None)
 
 
-def _collapse_rows(x, conv):
+def _collapse_rows(x, conv, stats=False):
     """(H,1) convolution that spans the whole axis 2: (B,C,H,W) -> (B,O,1,W)."""
     w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[2])
-    y = ops.contract("och,bchw->bow", w, x)
-    return y.view(y.shape[0], y.shape[1], 1, y.shape[2])
+    y, st = ops.contract_stats("och,bchw->bow", w, x) if stats else (ops.contract("och,bchw->bow", w, x), None)
+    return y.view(y.shape[0], y.shape[1], 1, y.shape[2]), st
 
 
-def _collapse_cols(x, conv):
+def _collapse_cols(x, conv, stats=False):
     """(1,W) convolution that spans the whole axis 3: (B,C,H,W) -> (B,O,H,1)."""
     w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[3])
-    y = ops.contract("ocw,bchw->boh", w, x)
-    return y.view(y.shape[0], y.shape[1], y.shape[2], 1)
+    y, st = ops.contract_stats("ocw,bchw->boh", w, x) if stats else (ops.contract("ocw,bchw->boh", w, x), None)
+    return y.view(y.shape[0], y.shape[1], y.shape[2], 1), st
 
 
-def _linear(x, lin):
-    return ops.contract("oi,bi->bo", lin.weight, x)
+def _linear(x, lin, stats=False):
+    return ops.contract_stats("oi,bi->bo", lin.weight, x) if stats else (ops.contract("oi,bi->bo", lin.weight, x), None)
 
 
 class CISTGCN(nn.Module):
@@ -221,9 +224,18 @@ class CISTGCN(nn.Module):
 
     # ---- fused row op with per-call dropout site id -------------------------------------------
     def _na(self, x, bn=None, prelu=None, drop=False, **kw):
+        """x is a tensor or the (y, channel-sums) pair returned by the linear-map helpers."""
+        if isinstance(x, tuple):
+            x, st = x
+            if st is not None:
+                kw["stats"] = st
         self._site += 1
         return ops.norm_act(x, bn=bn, train=self.training, prelu=prelu, drop_p=self.dropout if drop else 0.0,
                             salt=self._site, **kw)
+
+    def _lin(self, fn, x, layer, bn=True):
+        """linear map `fn` followed (bn=True) by a BatchNorm: ask the kernel for channel sums in train mode"""
+        return fn(x, layer, stats=bn and self.training)
 
     # ---- Map2Adj.forward, CISTGCN.py:183-189 ----------------------------------------------------
     def _adjacency(self, layer, x):
@@ -231,9 +243,9 @@ class CISTGCN(nn.Module):
         B, _, T, V = x.shape
 
         def tower(t, collapse):
-            h = self._na(_pointwise(x, t[0]), bn=t[1], prelu=t[2])
-            h = self._na(collapse(h, t[3]), bn=t[4], drop=True)
-            return _pointwise(h, t[6])
+            h = self._na(self._lin(_pointwise, x, t[0]), bn=t[1], prelu=t[2])
+            h = self._na(self._lin(collapse, h, t[3]), bn=t[4], drop=True)
+            return _pointwise(h, t[6])[0]
 
         q = tower(m.time_compress, _collapse_rows).view(B, T, V)     # q[b,tau,v]
         s = tower(m.joint_compress, _collapse_cols).view(B, V, T)    # s[b,v,t]
@@ -242,36 +254,35 @@ class CISTGCN(nn.Module):
         else:
             o = ops.contract("bvt,btw->btvw", s, q)                  # o[b,t,v,w]  = s[b,v,t] q[b,t,w]
         e = m.expansor
-        h = self._na(_pointwise(o, e[0]), bn=e[1], drop=True, prelu=e[3])
-        return _pointwise(h, e[4])
+        h = self._na(self._lin(_pointwise, o, e[0]), bn=e[1], drop=True, prelu=e[3])
+        return _pointwise(h, e[4])[0]
 
     # ---- Domain_GCNN_layer.forward, CISTGCN.py:259-269 -------------------------------------------
     def _domain(self, layer, xn):
-        res = xn if isinstance(layer.residual, nn.Identity) else self._na(_pointwise(xn, layer.residual[0]), bn=layer.residual[1])
+        res = xn if isinstance(layer.residual, nn.Identity) else self._na(self._lin(_pointwise, xn, layer.residual[0]), bn=layer.residual[1])
         conv = layer.tcn[0]
-        stats = None
         if layer.interpretable:
             adj = self._adjacency(layer, xn)
             layer.Adj = adj
             if self.fused_domain:
                 w = conv.weight.view(conv.out_channels, conv.in_channels)
-                y, stats = ops.stgcn_domain(xn, adj, w, conv.bias, 0 if layer.domain == "space" else 1, self.training)
+                y = ops.stgcn_domain(xn, adj, w, conv.bias, 0 if layer.domain == "space" else 1, self.training)
             else:
                 spec = "bctv,bvtq->bcqv" if layer.domain == "space" else "bctv,btvw->bctw"
-                y = _pointwise(ops.contract(spec, xn, adj), conv)
+                y = self._lin(_pointwise, ops.contract(spec, xn, adj), conv)
         else:
             layer.Adj = xn
             spec = "bctv,vtq->bcqv" if layer.domain == "space" else "bctv,tvw->bctw"
-            y = _pointwise(ops.contract(spec, xn, layer.gcn.A), conv)
-        return self._na(y, bn=layer.tcn[1], drop=True, add=res, prelu=layer.prelu, stats=stats)
+            y = self._lin(_pointwise, ops.contract(spec, xn, layer.gcn.A), conv)
+        return self._na(y, bn=layer.tcn[1], drop=True, add=res, prelu=layer.prelu)
 
     # ---- gate path of DSTD_GC.forward, CISTGCN.py:378-384 ----------------------------------------
     def _gate(self, conv, mp, xn, stats):
-        h = self._na(_collapse_rows(xn, conv[0]), bn=conv[1], drop=True, prelu=conv[3])
-        h = self._na(_collapse_cols(h, conv[4]), bn=conv[5], drop=True, prelu=conv[7])
+        h = self._na(self._lin(_collapse_rows, xn, conv[0]), bn=conv[1], drop=True, prelu=conv[3])
+        h = self._na(self._lin(_collapse_cols, h, conv[4]), bn=conv[5], drop=True, prelu=conv[7])
         h = ops.cat_channels([h.view(h.shape[0], -1), stats])
-        h = self._na(_linear(h, mp[0]), bn=mp[1], drop=True, prelu=mp[3])
-        return _linear(h, mp[4])
+        h = self._na(self._lin(_linear, h, mp[0]), bn=mp[1], drop=True, prelu=mp[3])
+        return _linear(h, mp[4])[0]
 
     # ---- DSTD_GC.forward, CISTGCN.py:373-390 ------------------------------------------------------
     def _block(self, m, x):
@@ -284,9 +295,9 @@ class CISTGCN(nn.Module):
         a = self._na(x1, pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1])
         b = self._na(x2, pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])
         c = m.compressor
-        h = self._na(_pointwise(ops.cat_channels([a, b]), c[0]), bn=c[1], prelu=c[2])
+        h = self._na(self._lin(_pointwise, ops.cat_channels([a, b]), c[0]), bn=c[1], prelu=c[2])
         gate = ops.se_gate(ops.mean_bc(h), c[3].w1, c[3].w2)
-        res = xn if isinstance(m.residual, nn.Identity) else self._na(_pointwise(xn, m.residual[0]), bn=m.residual[1])
+        res = xn if isinstance(m.residual, nn.Identity) else self._na(self._lin(_pointwise, xn, m.residual[0]), bn=m.residual[1])
         return self._na(h, pre=gate, add=res, add_post=True)
 
     # ---- FPN.forward, CISTGCN.py:74-79 -------------------------------------------------------------
@@ -295,29 +306,29 @@ class CISTGCN(nn.Module):
         ys = ops.dilated_convs(x, [b[0] for b in blocks])
         outs = [self._na(y, bn=b[1], prelu=b[3]) for y, b in zip(ys, blocks)]     # FPN dropout p = 0 (:533)
         outs.append(ops.mean_bc(x))                                                # action context, broadcast below
-        return _pointwise(ops.cat_channels(outs, bcast=(False, False, False, True)), m.compress)
+        return _pointwise(ops.cat_channels(outs, bcast=(False, False, False, True)), m.compress)[0]
 
     # ---- ContextLayer.forward, CISTGCN.py:463-475 --------------------------------------------------
     def _context(self, m, x7):
         B, To, V, _ = x7.shape
         x = x7.view(B, 1, To, V * 3)
         c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
-        y1 = ops.max_bc(self._na(_pointwise(x, c1[0]), bn=c1[1], prelu=c1[2]))
-        y2 = ops.max_bc(self._na(_collapse_rows(x, c2[0]), bn=c2[1], prelu=c2[2]))
-        ym = ops.mean_bc(self._na(_pointwise(x, c3[0]), bn=c3[1], prelu=c3[2]))
-        heads = [self._na(_linear(y, h[0]), drop=True, prelu=h[2]) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))]
+        y1 = ops.max_bc(self._na(self._lin(_pointwise, x, c1[0]), bn=c1[1], prelu=c1[2]))
+        y2 = ops.max_bc(self._na(self._lin(_collapse_rows, x, c2[0]), bn=c2[1], prelu=c2[2]))
+        ym = ops.mean_bc(self._na(self._lin(_pointwise, x, c3[0]), bn=c3[1], prelu=c3[2]))
+        heads = [self._na(_linear(y, h[0])[0], drop=True, prelu=h[2]) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))]
         y = ops.cat_channels(heads)
-        m.joints = self._na(_linear(y, m.fmap_s[0]), bn=m.fmap_s[1], drop=True)
-        m.displacements = self._na(_linear(y, m.fmap_t[0]), bn=m.fmap_t[1], drop=True)
+        m.joints = self._na(self._lin(_linear, y, m.fmap_s[0]), bn=m.fmap_s[1], drop=True)
+        m.displacements = self._na(self._lin(_linear, y, m.fmap_t[0]), bn=m.fmap_t[1], drop=True)
         m.seq_joints = ops.contract("bt,bv->btv", m.displacements, m.joints)
         n = m.norm_map
-        h = self._na(_pointwise(m.seq_joints, n[0]), bn=n[1], drop=True, prelu=n[3])
+        h = self._na(self._lin(_pointwise, m.seq_joints, n[0]), bn=n[1], drop=True, prelu=n[3])
         h = self._na(h, pre=ops.se_gate(ops.mean_bc(h), n[4].w1, n[4].w2))
-        h = self._na(_pointwise(h, n[5]), bn=n[6], drop=True, prelu=n[8])
+        h = self._na(self._lin(_pointwise, h, n[5]), bn=n[6], drop=True, prelu=n[8])
         m.seq_joints_n = h
         f = m.fconv
-        h = self._na(_pointwise(h.view(B, 1, To, V), f[0]), bn=f[1], prelu=f[2])
-        h = self._na(_pointwise(h, f[3]), bn=f[4], prelu=f[5])
+        h = self._na(self._lin(_pointwise, h.view(B, 1, To, V), f[0]), bn=f[1], prelu=f[2])
+        h = self._na(self._lin(_pointwise, h, f[3]), bn=f[4], prelu=f[5])
         m.seq_joints_dims = h
         hp = h.permute(0, 2, 3, 1)
         return self._na(hp, pre=ops.se_gate(ops.mean_bc(hp), m.SE.w1, m.SE.w2))
@@ -336,8 +347,8 @@ class CISTGCN(nn.Module):
         for i in range(1, self.n_txcnn_layers):
             z = self._na(self._fpn(self.txcnns[i], z), prelu=self.prelus[i], add=z, add_post=True)
         d = self.dim_conversor
-        z = self._na(_pointwise(z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
-        z = self._na(_pointwise(z, d[3]), prelu=d[4])                   # PReLU(3): per-channel slopes (:545)
+        z = self._na(self._lin(_pointwise, z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
+        z = self._na(_pointwise(z, d[3])[0], prelu=d[4])                # PReLU(3): per-channel slopes (:545)
         x7 = ops.cumsum_time(z.permute(0, 2, 3, 1))                     # (B,T_out,V,3)
         act = self._context(self.context_layer, x7)
         x8 = x7.permute(0, 3, 2, 1)                                     # (B,3,V,T_out) view

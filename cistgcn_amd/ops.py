@@ -66,6 +66,8 @@ class _Arena:
         if self.cur + n > self.buf.numel():
             raise RuntimeError("cistgcn_amd: step scratch exhausted (missing ops.begin_step()?)")
         s = self.buf[self.cur:self.cur + n]
+        if _ARENA_CHECK and float(s.abs().sum()) != 0.0:      # debugging aid: a slice must be all-zero when handed out
+            raise RuntimeError("cistgcn_amd: dirty scratch slice at %d (+%d): %s" % (self.cur, n, s.tolist()))
         self.cur += (n + 1) & ~1
         self.high = max(self.high, self.cur)
         return s
@@ -73,6 +75,7 @@ class _Arena:
 
 _arenas = {}
 _seeds = {}
+_ARENA_CHECK = bool(int(__import__("os").environ.get("CISTGCN_ARENA_CHECK", "0")))
 
 
 def _dev(device):
@@ -165,8 +168,9 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
     blocks = p.G * ((p.M + (15 if p.M <= 16 else 63)) // (16 if p.M <= 16 else 64)) * ((p.N + 63) // 64)
     p.splitk = 1
     p.dense = y_dense
-    if y_dense and p.K >= 1024 and blocks < 256:
-        p.splitk = int(max(1, min((p.K + 255) // 256, (512 + blocks - 1) // blocks)))
+    if y_dense and p.K >= 256 and blocks < 512:
+        # few output tiles and a long reduction (weight / bias gradients): spread K over workgroups
+        p.splitk = int(max(1, min((p.K + 127) // 128, (1024 + blocks - 1) // blocks)))
     _plans[key] = p
     return p
 
@@ -177,7 +181,7 @@ def _label_strides(t, labels):
     return {l: s for l, s in zip(labels, t.stride())}
 
 
-def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0):
+def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None):
     """Y = contraction of a and x per einsum-style `spec`; returns a fresh contiguous tensor.
     `sa`/`sx` (label -> element stride) and `oa`/`ox` override the operands' own strides, which is
     how dilated / halo-shifted windows are addressed without materialising them."""
@@ -194,10 +198,13 @@ def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, s
     sx = _label_strides(x, lx) if sx is None else sx
     y = torch.empty([sizes[l] for l in ly], dtype=torch.float32, device=x.device)
     sy = _label_strides(y, ly)
-    p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label, x.device, True)
-    _lib.call("cg_contract", _ptr(a), _ptr(x), _ptr(y), _ptr(bias), _ptr(p.tables), p.G, p.M, p.N, p.K,
+    p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label or stats_label, x.device, True)
+    stats = None
+    if stats_label is not None and p.splitk == 1:
+        stats = _arena(x.device).take(2 * sizes[stats_label])     # f64 channel sums of y for the BatchNorm that follows
+    _lib.call("cg_contract", _ptr(a), _ptr(x), _ptr(y), _ptr(bias), _ptr(stats), _ptr(p.tables), p.G, p.M, p.N, p.K,
               p.splitk, p.a_kfast, p.x_kfast, y.numel(), _stream(x))
-    return y
+    return (y, stats) if stats_label is not None else y
 
 
 _ones = {}
@@ -217,13 +224,18 @@ def _sum_keep(t, labels, keep):
 
 class _Contract(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, x, bias, spec, bias_label):
+    def forward(ctx, a, x, bias, spec, bias_label, stats_label):
         ctx.spec, ctx.bias_label = spec, bias_label
         ctx.save_for_backward(a, x)
-        return _contract_raw(spec, a, x, bias, bias_label)
+        if stats_label is None:
+            return _contract_raw(spec, a, x, bias, bias_label), None
+        y, stats = _contract_raw(spec, a, x, bias, bias_label, stats_label=stats_label)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _=None):
         a, x = ctx.saved_tensors
         ins, ly = ctx.spec.split("->")
         la, lx = ins.split(",")
@@ -234,12 +246,18 @@ class _Contract(torch.autograd.Function):
             dx = _contract_raw("%s,%s->%s" % (la, ly, lx), a, dy)
         if ctx.needs_input_grad[2]:
             db = _sum_keep(dy, ly, ctx.bias_label)
-        return da, dx, db, None, None
+        return da, dx, db, None, None, None
 
 
 def contract(spec, a, x, bias=None, bias_label=None):
     """einsum-style contraction `spec` = "<a idx>,<x idx>-><y idx>", optional bias along one index."""
-    return _Contract.apply(a, x, bias, spec, bias_label)
+    return _Contract.apply(a, x, bias, spec, bias_label, None)[0]
+
+
+def contract_stats(spec, a, x, bias=None, bias_label=None, stats_label="o"):
+    """contraction + f64 per-channel (sum, sum of squares) of the result along `stats_label` from the kernel's
+    epilogue; stats is None when the plan needs split-K (the caller then reduces separately)."""
+    return _Contract.apply(a, x, bias, spec, bias_label, stats_label)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -735,8 +753,9 @@ class _StgcnDomain(torch.autograd.Function):
         dadj = torch.empty_like(adj)
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.lib().cg_stgcn_domain_bwd_ws_floats(Cin, Cout), dtype=torch.float32, device=x.device)
         _lib.call("cg_stgcn_domain_bwd", _ptr(x), _ptr(adj), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dadj), _ptr(dw), _ptr(db),
-                  B, Cin, Cout, T, V, ctx.domain, _stream(x))
+                  _ptr(ws), B, Cin, Cout, T, V, ctx.domain, _stream(x))
         return dx, dadj, dw, db, None, None
 
 

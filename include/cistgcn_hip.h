@@ -41,8 +41,10 @@ typedef struct CgView4 {
  * 305,323-340,408-418,454-458,541-545), nn.Linear (:341-352,421-440, SE.py), the adjacency
  * products torch.einsum (:122-124) and torch.matmul / bmm outer products (:187,:471), and the
  * weight / input gradients of all of them.  splitk > 1 accumulates with fp32 atomics into a dense
- * output of y_dense_numel = G*M*N elements which is zeroed here first. */
-int cg_contract(const float* A, const float* X, float* Y, const float* bias, const int32_t* tables,
+ * output of y_dense_numel = G*M*N elements which is zeroed here first.  `stats` (optional, f64
+ * [channels][2], zero on entry, splitk == 1 only) receives per-channel sum / sum of squares of Y,
+ * channel = bias_m[m]: the reduction half of the BatchNorm that follows the convolution. */
+int cg_contract(const float* A, const float* X, float* Y, const float* bias, double* stats, const int32_t* tables,
                 int G, int M, int N, int K, int splitk, int a_kfast, int x_kfast,
                 long long y_dense_numel, void* stream);
 
@@ -123,11 +125,14 @@ int cg_seed_bump(unsigned long long* seed, void* stream);
  * x, y contiguous (B,C,T,V).  Adjacency is staged in LDS, the graph product and the channel mix
  * run back to back without the intermediate G touching HBM.  Optional per-channel f64 sums of y
  * (ystats, [Cout][2], zero on entry) feed the train-mode BatchNorm that follows (:235).
- * Backward: dx, dAdj, dW, db from dy (dW/db zeroed here, accumulated with fp32 atomics). */
+ * Backward: dx, dAdj, dW, db from dy.  dW/db partial sums go through `ws`, a caller-owned scratch of
+ * cg_stgcn_domain_bwd_ws_floats(Cin, Cout) floats (zeroed here; replicated accumulators keep the fp32
+ * atomics off a single address), and are folded into dW/db by a second tiny kernel. */
 int cg_stgcn_domain_fwd(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                         int B, int Cin, int Cout, int T, int V, int domain, void* stream);
+long long cg_stgcn_domain_bwd_ws_floats(int Cin, int Cout);
 int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
-                        float* dW, float* dbias, int B, int Cin, int Cout, int T, int V, int domain, void* stream);
+                        float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain, void* stream);
 
 /* ---- optimizer on the flat parameter buffer -----------------------------------
  * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,

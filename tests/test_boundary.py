@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     from cistgcn_amd import _lib, build
     path = build.build()
     header = open(os.path.join(ROOT, "include", "cistgcn_hip.h")).read()
-    declared = set(re.findall(r"^int (cg_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|long long) (cg_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     handle = ctypes.CDLL(path)
     for name in declared:

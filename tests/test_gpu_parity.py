@@ -46,6 +46,15 @@ def test_model_matches_oracle_wide(cfg, mode):
     checks.check_model_vs_oracle("cuda", C, T, V, B, mode)
 
 
+@pytest.mark.parametrize("cfg", [(8, 10, 22, 8), (64, 10, 22, 8), (32, 50, 25, 4)], ids=str)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_gradients_as_accurate_as_cpu_fp32(cfg, mode):
+    # kink-free network (all PReLU slopes 1): HIP gradient error vs an fp64 run must be within 8x the error of the
+    # reference's own fp32 CPU arithmetic
+    C, T, V, B = cfg
+    checks.check_model_vs_oracle("cuda", C, T, V, B, mode, smooth=True)
+
+
 def test_cpu_tensors_are_refused():
     from cistgcn_amd import ops
     with pytest.raises(RuntimeError):

@@ -21,4 +21,6 @@ tail -2 gpurun_out/smoke.log
 run bench_default 600 python bench.py --steps 50 --warmup 10
 tail -c 300 gpurun_out/bench_default.log
 run profile 900 bash tools/gpu_profile.sh cistgcn8_b16_t50_v22
-tail -40 gpurun_out/profile.log
+grep -A 14 '"Name"' gpurun_out/profile.log | cut -c1-150
+run profile64 900 bash tools/gpu_profile.sh cistgcn64_b256_t50_v22
+grep -A 14 '"Name"' gpurun_out/profile64.log | cut -c1-150
