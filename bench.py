@@ -42,8 +42,8 @@ def make_cfg(C, T, V, dropout):
     return arch, NS(dropout=dropout)
 
 
-def synth(B, T, V, rank):
-    g = torch.Generator().manual_seed(1234 + rank)
+def synth(B, T, V, rank, base=1234):
+    g = torch.Generator().manual_seed(base + rank)
     x = 50 + 350 * torch.randn(B, T, V, 3, generator=g)
     tgt = x[:, -1:] + 20 * torch.randn(B, 25, V, 3, generator=g)
     return x, tgt
@@ -116,6 +116,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
+                         "multi-rank code path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,12 +127,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if args.backend == "gloo":
+        local = local % max(1, torch.cuda.device_count())     # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from cistgcn_amd import _lib, ops
     from cistgcn_amd.models import CISTGCN_0
@@ -138,8 +147,8 @@ def main():
     C, B, T, V = WORKLOADS[args.workload]
     torch.manual_seed(0)
     net = CISTGCN_0(*make_cfg(C, T, V, args.dropout)).to(device).train()
-    ops.manual_seed(1234 + rank, device)
-    x, tgt = synth(B, T, V, rank)
+    ops.manual_seed(args.data_seed + rank, device)
+    x, tgt = synth(B, T, V, rank, args.data_seed)
     x, tgt = x.to(device), tgt.to(device)
     flat = FlatGrads(net.parameters(), device) if world > 1 else None
     step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat))
@@ -167,7 +176,10 @@ def main():
         el = float(t.item())
     loss = float(step.loss.item())
     if not (loss == loss):
-        raise SystemExit("bench.py: loss is NaN")
+        bad = [k for k, p in net.named_parameters() if not bool(torch.isfinite(p).all())]
+        badg = [k for k, p in net.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
+        raise SystemExit("bench.py: loss is NaN on rank %d (x finite: %s, non-finite params: %s, non-finite grads: %d e.g. %s)"
+                         % (rank, bool(torch.isfinite(x).all()), bad[:3], len(badg), badg[:3]))
 
     out = {
         "metric": "sequences/sec (fwd+bwd) H3.6M 22-joint 50->25" if (T, V) == (50, 22) else "sequences/sec (fwd+bwd)",
@@ -176,6 +188,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "C": C, "per_gpu_batch": B, "global_batch": B * world, "T_in": T, "T_out": 25,
                    "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph,
+                   "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
                    "loss": loss},
     }
     if rank == 0 and world == 1:

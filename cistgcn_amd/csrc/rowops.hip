@@ -14,6 +14,9 @@
 // element with one 32-bit division and shared by every view of the kernel (all views have the same dims).
 #define CG_ROW_LOOP(P_, p_) for (int p_ = threadIdx.x; p_ < (int)(P_); p_ += blockDim.x)
 #define CG_POS(v_, p_) const int i2_ = (p_) / (int)(v_).n[3]; const int i3_ = (p_) - i2_ * (int)(v_).n[3];
+// Chunked rows: a workgroup owns channel c and the batch rows [b0, b0 + nb); e runs over nb * P elements.
+#define CG_CHUNK_LOOP(nb_, P_, e_) for (int e_ = threadIdx.x; e_ < (nb_) * (int)(P_); e_ += blockDim.x)
+#define CG_CHUNK_ROW(e_, P_, b0_) const int br_ = (e_) / (int)(P_); const int p = (e_) - br_ * (int)(P_); const int b = (b0_) + br_;
 #define CG_OFF(v_) ((long long)i2_ * (v_).s[2] + (long long)i3_ * (v_).s[3])
 
 __device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c) {
@@ -24,16 +27,17 @@ __device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c)
 // per-channel sums  stats[c] = { sum_{b,p} v, sum v^2 },  v = x * pre[b,c]
 // ---------------------------------------------------------------------------------------------
 __global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, const float* __restrict__ pre,
-                                     double* __restrict__ stats) {
+                                     double* __restrict__ stats, int rb) {
   __shared__ double red[32];
-  const int c = blockIdx.x, b = blockIdx.y;
-  const long long P = xv.n[2] * xv.n[3];
-  const long long base = cg_row_base(xv, b, c);
-  const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  const int P = (int)(xv.n[2] * xv.n[3]);
+  const int nb = min(rb, (int)xv.n[0] - b0);
   double s = 0.0, q = 0.0;
-  CG_ROW_LOOP(P, p) {
+  CG_CHUNK_LOOP(nb, P, e) {
+    CG_CHUNK_ROW(e, P, b0)
     CG_POS(xv, p)
-    const float v = x[base + CG_OFF(xv)] * w;
+    const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
+    const float v = x[cg_row_base(xv, b, c) + CG_OFF(xv)] * w;
     s += (double)v;
     q += (double)v * (double)v;
   }
@@ -45,13 +49,26 @@ __global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, co
   }
 }
 
+// rows of one channel handled per workgroup: ~4096 elements, so that the block reduction and the f64 atomics
+// are amortised (a (B,C) BatchNorm1d input becomes one workgroup per channel)
+static int cg_rows_per_block(const CgView4& v) {
+  const long long P = v.n[2] * v.n[3];
+  long long rb = 4096 / (P > 0 ? P : 1);
+  if (rb < 1) rb = 1;
+  if (rb > v.n[0]) rb = v.n[0];
+  // small problems: keep at least ~512 workgroups in flight rather than amortising
+  while (rb > 1 && v.n[1] * ((v.n[0] + rb - 1) / rb) < 512) rb = (rb + 1) / 2;
+  return (int)rb;
+}
+
 extern "C" int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !xv || !stats) return CG_EARG;
   const long long P = xv->n[2] * xv->n[3];
   if (xv->n[0] <= 0 || xv->n[1] <= 0 || P <= 0 || xv->n[0] > 65535) return CG_ESHAPE;
-  dim3 grid((unsigned)xv->n[1], (unsigned)xv->n[0]), block(P <= 256 ? 64 : 256);
-  hipLaunchKernelGGL(cg_chan_stats_kernel, grid, block, 0, stream, x, *xv, pre, stats);
+  const int rb = cg_rows_per_block(*xv);
+  dim3 grid((unsigned)xv->n[1], (unsigned)((xv->n[0] + rb - 1) / rb)), block(P * rb <= 256 ? 64 : 256);
+  hipLaunchKernelGGL(cg_chan_stats_kernel, grid, block, 0, stream, x, *xv, pre, stats, rb);
   return cg_launch_status();
 }
 
@@ -140,57 +157,59 @@ __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c
   return r;
 }
 
-__global__ void cg_norm_act_fwd_kernel(CgNormAct a) {
-  const int c = blockIdx.x, b = blockIdx.y;
-  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+__global__ void cg_norm_act_fwd_kernel(CgNormAct a, int rb) {
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  const long long C = a.xv.n[1];
+  const int P = (int)(a.xv.n[2] * a.xv.n[3]);
+  const int nb = min(rb, (int)a.xv.n[0] - b0);
   const CgChanAffine af = cg_chan_affine(a, c, false);
-  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
-  const long long bx = cg_row_base(a.xv, b, c), by = cg_row_base(a.yv, b, c);
-  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
-  CG_ROW_LOOP(P, p) {
+  CG_CHUNK_LOOP(nb, P, e) {
+    CG_CHUNK_ROW(e, P, b0)
     CG_POS(a.xv, p)
-    float u = (a.x[bx + CG_OFF(a.xv)] * w - af.mean) * af.scale + af.shift;
+    const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+    float u = (a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)] * w - af.mean) * af.scale + af.shift;
     if (a.drop_p > 0.f) u *= cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
-    if (a.add && !a.add_post) u += a.add[ba + CG_OFF(a.av)];
+    const float ad = a.add ? a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)] : 0.f;
+    if (a.add && !a.add_post) u += ad;
     if (a.alpha) u = u > 0.f ? u : alpha * u;
-    if (a.add && a.add_post) u += a.add[ba + CG_OFF(a.av)];
-    a.y[by + CG_OFF(a.yv)] = u;
+    if (a.add && a.add_post) u += ad;
+    a.y[cg_row_base(a.yv, b, c) + CG_OFF(a.yv)] = u;
   }
 }
 
 // gradient at the affine output (after PReLU and dropout are undone); also returns pre-activation u
-__device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChanAffine& af, float w, float alpha,
-                                                unsigned long long seed, int b, int c, long long C, long long P,
-                                                int p, int i2_, int i3_, long long bx, long long ba, long long bdy,
-                                                float& v, float& u, float& gu, float& g) {
-  v = a.x[bx + CG_OFF(a.xv)] * w;
+__device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChanAffine& af, float alpha,
+                                                unsigned long long seed, int b, int c, long long C, int P,
+                                                int p, int i2_, int i3_, float& w, float& v, float& u, float& gu, float& g) {
+  w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+  v = a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)] * w;
   float keep = 1.f;
   if (a.drop_p > 0.f) keep = cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
   u = ((v - af.mean) * af.scale + af.shift) * keep;
-  if (a.add && !a.add_post) u += a.add[ba + CG_OFF(a.av)];
-  g = a.dy[bdy + CG_OFF(a.dyv)];
+  if (a.add && !a.add_post) u += a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)];
+  g = a.dy[cg_row_base(a.dyv, b, c) + CG_OFF(a.dyv)];
   gu = a.alpha ? (u > 0.f ? g : alpha * g) : g;
   return gu * keep;
 }
 
 // pass 1 of backward: per-channel sums of g and g*xhat (f64), d alpha
-__global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a) {
+__global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a, int rb) {
   __shared__ double red[48];
-  const int c = blockIdx.x, b = blockIdx.y;
-  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  const long long C = a.xv.n[1];
+  const int P = (int)(a.xv.n[2] * a.xv.n[3]);
+  const int nb = min(rb, (int)a.xv.n[0] - b0);
   const CgChanAffine af = cg_chan_affine(a, c, true);
-  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
-  const long long bx = cg_row_base(a.xv, b, c), bdy = cg_row_base(a.dyv, b, c);
-  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
-  CG_ROW_LOOP(P, p) {
+  CG_CHUNK_LOOP(nb, P, e) {
+    CG_CHUNK_ROW(e, P, b0)
     CG_POS(a.xv, p)
-    float v, u, gu, g;
-    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, i2_, i3_, bx, ba, bdy, v, u, gu, g);
+    float w, v, u, gu, g;
+    const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
     s1 += (double)gh;
     s2 += (double)gh * (double)((v - af.mean) * af.rstd);
     if (a.alpha && !(u > 0.f)) sa += (double)g * (double)u;
@@ -206,18 +225,15 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a) {
 }
 
 // pass 2 of backward: dx, d add, d pre (row sums), and the per-channel parameter gradients
-__global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a) {
+__global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a, int rb) {
   __shared__ double red[16];
-  const int c = blockIdx.x, b = blockIdx.y;
-  const long long C = a.xv.n[1], P = a.xv.n[2] * a.xv.n[3];
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;     // rb == 1 whenever the per-row gate gradient is requested
+  const long long C = a.xv.n[1];
+  const int P = (int)(a.xv.n[2] * a.xv.n[3]);
+  const int nb = min(rb, (int)a.xv.n[0] - b0);
   const CgChanAffine af = cg_chan_affine(a, c, true);
-  const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
-  const long long bx = cg_row_base(a.xv, b, c), bdy = cg_row_base(a.dyv, b, c);
-  const long long ba = a.add ? cg_row_base(a.av, b, c) : 0;
-  const long long bdx = a.dx ? cg_row_base(a.dxv, b, c) : 0;
-  const long long bda = a.dadd ? cg_row_base(a.dav, b, c) : 0;
   float m1 = 0.f, m2 = 0.f;
   if (a.bn_mode == 1) {
     const double cnt = (double)a.xv.n[0] * (double)P;
@@ -225,22 +241,23 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a) {
     m2 = (float)(a.red[2 * c + 1] / cnt);
   }
   double sp = 0.0;
-  CG_ROW_LOOP(P, p) {
+  CG_CHUNK_LOOP(nb, P, e) {
+    CG_CHUNK_ROW(e, P, b0)
     CG_POS(a.xv, p)
-    float v, u, gu, g;
-    const float gh = cg_norm_act_gh(a, af, w, alpha, seed, b, c, C, P, p, i2_, i3_, bx, ba, bdy, v, u, gu, g);
+    float w, v, u, gu, g;
+    const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
     float gv;
     if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
     else gv = gh * af.scale;
-    if (a.dx) a.dx[bdx + CG_OFF(a.dxv)] = gv * w;
-    if (a.dadd) a.dadd[bda + CG_OFF(a.dav)] = gu;
-    if (a.dpre) sp += (double)gv * (double)a.x[bx + CG_OFF(a.xv)];
+    if (a.dx) a.dx[cg_row_base(a.dxv, b, c) + CG_OFF(a.dxv)] = gv * w;
+    if (a.dadd) a.dadd[cg_row_base(a.dav, b, c) + CG_OFF(a.dav)] = gu;
+    if (a.dpre) sp += (double)gv * (double)a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)];
   }
   if (a.dpre) {
     sp = cg_block_sum(sp, red);
-    if (threadIdx.x == 0) a.dpre[(long long)b * C + c] = (float)sp;
+    if (threadIdx.x == 0) a.dpre[(long long)b0 * C + c] = (float)sp;
   }
-  if (b == 0 && threadIdx.x == 0) {
+  if (b0 == 0 && threadIdx.x == 0) {
     if (a.bn_mode != 0) {
       if (a.dgamma) a.dgamma[c] = (float)a.red[2 * c + 1];
       if (a.dbeta) a.dbeta[c] = (float)a.red[2 * c];
@@ -265,13 +282,15 @@ static int cg_norm_act_check(const CgNormAct* a, bool fwd) {
 }
 
 static dim3 cg_row_block(const CgView4& v) { return dim3(v.n[2] * v.n[3] <= 256 ? 64 : 256); }
+static dim3 cg_chunk_block(const CgView4& v, int rb) { return dim3(v.n[2] * v.n[3] * rb <= 256 ? 64 : 256); }
 
 extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) {
   int st = cg_norm_act_check(a, true);
   if (st != CG_OK) return st;
   if (!a->y) return CG_EARG;
-  dim3 grid((unsigned)a->xv.n[1], (unsigned)a->xv.n[0]);
-  hipLaunchKernelGGL(cg_norm_act_fwd_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+  const int rb = cg_rows_per_block(a->xv);
+  dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rb - 1) / rb));
+  hipLaunchKernelGGL(cg_norm_act_fwd_kernel, grid, cg_chunk_block(a->xv, rb), 0, (hipStream_t)stream_, *a, rb);
   return cg_launch_status();
 }
 
@@ -281,13 +300,16 @@ extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream
   if (st != CG_OK) return st;
   if (!a->dy) return CG_EARG;
   if ((a->bn_mode != 0 || a->alpha) && !a->red) return CG_EARG;
-  dim3 grid((unsigned)a->xv.n[1], (unsigned)a->xv.n[0]);
+  const int rb = cg_rows_per_block(a->xv);
   if (need_reduce) {
-    hipLaunchKernelGGL(cg_norm_act_bwd_reduce_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+    dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rb - 1) / rb));
+    hipLaunchKernelGGL(cg_norm_act_bwd_reduce_kernel, grid, cg_chunk_block(a->xv, rb), 0, (hipStream_t)stream_, *a, rb);
     st = cg_launch_status();
     if (st != CG_OK) return st;
   }
-  hipLaunchKernelGGL(cg_norm_act_bwd_apply_kernel, grid, cg_row_block(a->xv), 0, (hipStream_t)stream_, *a);
+  const int rba = a->dpre ? 1 : rb;      // the gate gradient is one sum per (batch, channel) row
+  dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rba - 1) / rba));
+  hipLaunchKernelGGL(cg_norm_act_bwd_apply_kernel, grid, cg_chunk_block(a->xv, rba), 0, (hipStream_t)stream_, *a, rba);
   return cg_launch_status();
 }
 

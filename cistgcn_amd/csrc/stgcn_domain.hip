@@ -25,7 +25,16 @@ struct CgDomainGeom {
   int GT, ntiles;      // groups per tile, tiles per sample
   int NG, J, Jp, PP;   // groups per sample, contraction length, padded, positions per tile
   int Cinp, Coutp;
+  int xt, XS;          // xt = 1: x slice stored channel-fastest [GT][J][XS] (XS = Cinp + 4) so that the graph
+                       // product reads four input channels per ds_read_b128 (4x4 register tile, Cin >= 16)
 };
+
+__device__ __forceinline__ int cg_dom_x_index(const CgDomainGeom& g, int ci, int grp, int j) {
+  return g.xt ? (grp * g.J + j) * g.XS + ci : (ci * g.GT + grp) * g.J + j;
+}
+__device__ __forceinline__ int cg_dom_x_floats(const CgDomainGeom& g) {
+  return g.xt ? g.GT * g.J * g.XS : ((g.Cin * g.GT * g.J + 3) & ~3);
+}
 
 template <int DOMAIN>
 __device__ __forceinline__ long long cg_dom_off(const CgDomainGeom& g, int grp, int j) {
@@ -40,7 +49,7 @@ __device__ __forceinline__ void cg_dom_stage_inputs(const CgDomainGeom& g, const
   const int J = g.J, Jp = g.Jp, GT = g.GT;
   // adjacency slabs are contiguous in HBM: (ng, J, J)
   for (int e = tid; e < GT * J * Jp; e += nt) sA[e] = 0.f;
-  for (int e = tid; e < g.Cin * GT * J; e += nt) sX[e] = 0.f;
+  for (int e = tid; e < cg_dom_x_floats(g); e += nt) sX[e] = 0.f;
   __syncthreads();
   for (int e = tid; e < ng * J * J; e += nt) {
     const int o = e % J, r = e / J;            // r = grp*J + j
@@ -50,12 +59,12 @@ __device__ __forceinline__ void cg_dom_stage_inputs(const CgDomainGeom& g, const
     const int run = ng * J;                    // contiguous (grp, j) run per channel
     for (int e = tid; e < g.Cin * run; e += nt) {
       const int ci = e / run, r = e - ci * run;
-      sX[ci * GT * J + r] = xb[(long long)ci * g.T * g.V + (long long)g0 * g.V + r];
+      sX[cg_dom_x_index(g, ci, r / J, r % J)] = xb[(long long)ci * g.T * g.V + (long long)g0 * g.V + r];
     }
   } else {
     for (int e = tid; e < g.Cin * J * ng; e += nt) {
       const int grp = e % ng, r = e / ng, j = r % J, ci = r / J;
-      sX[(ci * GT + grp) * J + j] = xb[(long long)ci * g.T * g.V + (long long)j * g.V + g0 + grp];
+      sX[cg_dom_x_index(g, ci, grp, j)] = xb[(long long)ci * g.T * g.V + (long long)j * g.V + g0 + grp];
     }
   }
 }
@@ -63,6 +72,32 @@ __device__ __forceinline__ void cg_dom_stage_inputs(const CgDomainGeom& g, const
 // sG[ci][grp*Jp + o] = sum_j sX[ci][grp][j] * sA[grp][j][o]   (rows ci >= Cin of sG are zeroed)
 __device__ __forceinline__ void cg_dom_graph_product(const CgDomainGeom& g, const float* sA, const float* sX, float* sG) {
   const int J = g.J, Jp = g.Jp, GT = g.GT, oq = Jp / 4;
+  if (g.xt) {   // 4 input channels x 4 outputs per work item, both operands as ds_read_b128
+    for (int idx = threadIdx.x; idx < (g.Cinp / 4) * GT * oq; idx += blockDim.x) {
+      const int oc = idx % oq, r = idx / oq, grp = r % GT, iq = r / GT;
+      float acc[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+      const float* xr = sX + (grp * J) * g.XS + 4 * iq;
+      const float* ar = sA + (grp * J) * Jp + 4 * oc;
+      for (int j = 0; j < J; ++j) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + j * g.XS);
+        const float4 av = *reinterpret_cast<const float4*>(ar + j * Jp);
+        const float x4[4] = {xv.x, xv.y, xv.z, xv.w};
+        const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(x4[a], a4[q], acc[a][q]);
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float4*>(sG + (4 * iq + a) * g.PP + grp * Jp + 4 * oc) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < g.Cinp * GT * oq; idx += blockDim.x) {
     const int oc = idx % oq, r = idx / oq;     // r = ci*GT + grp
     const int grp = r % GT, ci = r / GT;
@@ -87,7 +122,7 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* _
                                                                   float* __restrict__ y, double* __restrict__ ystats, CgDomainGeom g) {
   float* sA = reinterpret_cast<float*>(cg_dyn_lds);
   float* sX = sA + g.GT * g.J * g.Jp;
-  float* sG = sX + ((g.Cin * g.GT * g.J + 3) & ~3);
+  float* sG = sX + cg_dom_x_floats(g);
   float* sWt = sG + g.Cinp * g.PP;
   double* sStat = reinterpret_cast<double*>(sWt + g.Cin * g.Coutp);
 
@@ -167,7 +202,7 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* _
   if (dbias) dbias = dW + g.Cout * g.Cin;
   float* sA = reinterpret_cast<float*>(cg_dyn_lds);
   float* sX = sA + g.GT * g.J * g.Jp;
-  float* sG = sX + ((g.Cin * g.GT * g.J + 3) & ~3);
+  float* sG = sX + cg_dom_x_floats(g);
   float* sDG = sG + g.Cinp * g.PP;
   float* sDY = sDG + g.Cinp * g.PP;
   float* sW = sDY + g.Coutp * g.PP;        // [Coutp][Cinp]
@@ -242,7 +277,7 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* _
     const int oc = idx % oq, r = idx / oq, j = r % J, grp = r / J;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int ci = 0; ci < g.Cin; ++ci) {
-      const float xv = sX[(ci * GT + grp) * J + j];
+      const float xv = sX[cg_dom_x_index(g, ci, grp, j)];
       const float4 d = *reinterpret_cast<const float4*>(sDG + ci * PP + grp * Jp + 4 * oc);
       acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y);
       acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
@@ -308,7 +343,8 @@ __global__ void cg_dom_fold_replicas_kernel(const float* __restrict__ ws, int re
 
 // ---- host side -------------------------------------------------------------------------------------
 static size_t cg_dom_lds_bytes(const CgDomainGeom& g, bool bwd) {
-  size_t f = (size_t)g.GT * g.J * g.Jp + (((size_t)g.Cin * g.GT * g.J + 3) & ~(size_t)3) + (size_t)g.Cinp * g.PP;
+  const size_t xf = g.xt ? (size_t)g.GT * g.J * g.XS : (((size_t)g.Cin * g.GT * g.J + 3) & ~(size_t)3);
+  size_t f = (size_t)g.GT * g.J * g.Jp + xf + (size_t)g.Cinp * g.PP;
   if (bwd) f += (size_t)g.Cinp * g.PP + (size_t)g.Coutp * g.PP + (size_t)g.Coutp * g.Cinp;
   else f += (size_t)g.Cin * g.Coutp;
   size_t bytes = f * sizeof(float);
@@ -324,6 +360,8 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   g.Jp = (g.J + 3) & ~3;
   g.Cinp = (Cin + 3) & ~3;
   g.Coutp = (Cout + 3) & ~3;
+  g.xt = Cin >= 16 ? 1 : 0;
+  g.XS = g.Cinp + 4;
   // groups per tile: the largest tile that keeps the LDS image <= 64 KiB (two workgroups per CU) and
   // the grid >= 1024 workgroups; a single group is accepted up to the full 160 KiB.
   int best = 0;

@@ -36,15 +36,22 @@ class FlatGrads:
         if torch.device(device).type == "cuda":
             self._ptr_host = self._ptr_host.pin_memory()
         self._ptr_dev = torch.zeros(len(sizes), dtype=torch.int64, device=device)
+        self._last_ptrs = None
 
     def _copy(self, direction):
+        ptrs = []
         for i, p in enumerate(self.params):
             if p.grad is None:
                 raise RuntimeError("FlatGrads: parameter %d has no gradient" % i)
             if not p.grad.is_contiguous():
                 raise RuntimeError("FlatGrads: non-contiguous gradient")
-            self._ptr_host[i] = p.grad.data_ptr()
-        self._ptr_dev.copy_(self._ptr_host, non_blocking=True)
+            ptrs.append(p.grad.data_ptr())
+        if ptrs != self._last_ptrs:
+            # the pointer table only changes when autograd hands out new gradient buffers; under HIP-graph replay
+            # the buffers are static and this upload happens once
+            self._ptr_host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            self._ptr_dev.copy_(self._ptr_host)          # synchronous: the host staging buffer is reused
+            self._last_ptrs = ptrs
         _lib.call("cg_multi_copy", ops._ptr(self._ptr_dev), ops._ptr(self._off), ops._ptr(self._ct), ops._ptr(self._cb),
                   ops._ptr(self._cl), self.n_chunks, ops._ptr(self.flat), direction, ops._stream(self.flat))
 
@@ -81,10 +88,24 @@ def shard_weights(local_batch, group=None):
     return float(local_batch) * dist.get_world_size(group) / float(total.item())
 
 
+_GRAPH_ATTRS = ("Adj", "w1", "w2", "joints", "displacements", "seq_joints", "seq_joints_n", "seq_joints_dims")
+
+
+def _drop_graph_attributes(model):
+    """The interpretation attributes are un-detached graph tensors (as in the reference, CISTGCN.py:262,381-382,
+    469-473); forget the ones of a finished pass so that its autograd graph is released."""
+    for m in model.modules():
+        for k in _GRAPH_ATTRS:
+            if k in m.__dict__:
+                del m.__dict__[k]
+
+
 class GraphedStep:
-    """forward + MPJPE + backward (+ flat-gradient gather) of one batch, captured once in a HIP graph
-    and replayed: ~3000 kernel launches collapse into one graph launch, which is what makes the
-    B=16 configuration launch-latency free.  Inputs live in static device buffers (`x`, `target`)."""
+    """forward + MPJPE + backward of one batch, captured once in a HIP graph and replayed: the ~2 k
+    kernel launches of a step collapse into one graph launch, which is what makes the B=16
+    configuration viable.  Inputs live in static device buffers (`x`, `target`).  With `flat`, the
+    gradients (static buffers under replay) are gathered into the flat all-reduce buffer by one
+    kernel launched right after the graph."""
 
     def __init__(self, model, x, target, warmup=3, flat=None):
         self.model, self.flat = model, flat
@@ -97,6 +118,7 @@ class GraphedStep:
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _drop_graph_attributes(model)      # Adj / w1 / ... of the warm-up pass keep its autograd graph (and streams) alive
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
@@ -107,12 +129,12 @@ class GraphedStep:
         pred, = self.model(self.x)
         loss = ops.mpjpe(pred, self.target)
         loss.backward()
-        if self.flat is not None:
-            self.flat.gather()
         return loss
 
     def replay(self):
         self.graph.replay()
+        if self.flat is not None:
+            self.flat.gather()
         return self.loss
 
 

@@ -251,7 +251,7 @@ def check_stage_kernels(device):
     assert_close(pd.grad, pr.grad, "mpjpe grad", rel=1e-5, floor=float(pr.grad.abs().max()))
 
 
-def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22))):
+def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22), (2, 64, 64, 10, 22), (2, 32, 10, 50, 25))):
     g = _gen(7)
     for (B, Cin, Cout, T, V) in shapes:
         for domain in (0, 1):
@@ -370,11 +370,11 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
 
     def as_accurate_as_cpu(got, cpu32, ref64, what):
         """The HIP result must be as close to the fp64 truth as the reference's own fp32 CPU path is (x8 slack),
-        or within 1e-4 relative (floor 1e-2) of it."""
+        or within 2e-4 relative (floor 1e-2) of it."""
         ref64 = ref64.detach()
         e_hip = float((got.detach().cpu().double() - ref64).abs().max())
         e_cpu = float((cpu32.detach().double() - ref64).abs().max())
-        bound = max(8.0 * e_cpu, 1e-4 * max(1e-2, float(ref64.abs().max())))
+        bound = max(8.0 * e_cpu, 2e-4 * max(1e-2, float(ref64.abs().max())))
         assert e_hip <= bound, "%s: HIP err vs fp64 %.3e > bound %.3e (CPU fp32 err vs fp64 %.3e)" % (what, e_hip, bound, e_cpu)
 
     gd, g64 = dict(net.named_parameters()), dict(ora64.named_parameters())
@@ -387,7 +387,7 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
         assert_grads_close({k: p.grad for k, p in gd.items()}, {k: p.grad for k, p in ora.named_parameters()}, "vs oracle")
     for k in ("st_gcnns.0.dsgn.Adj", "st_gcnns.2.tsgn.Adj", "st_gcnns_o.0.dsgn.Adj", "st_gcnns.1.w1", "st_gcnns_o.0.w2",
               "context_layer.joints", "context_layer.seq_joints_dims"):
-        assert_close(_attr(net, k), _attr(ora, k), k)
+        assert_close(_attr(net, k), _attr(ora, k), k, rel=1e-4 if mode == "eval" else 1e-3)   # train: BN over a few samples
     sd, so = net.state_dict(), ora.state_dict()
     for k in so:
         if "running" in k or "num_batches" in k:

@@ -61,19 +61,22 @@ def grad_summary(g):
 def assert_grads_close(named_got, named_ref, what=""):
     """Parameter-gradient comparison that tolerates PReLU-kink sign flips.
 
-    A pre-activation that lies within fp32 rounding of 0 may take the other PReLU branch in another fp32
-    implementation (the CPU path does it too against fp64: tools/diag_sites.py).  One flipped element perturbs
-    every gradient upstream of it by O(|dy| of that element) - small against the model's gradient scale but not
-    against a tensor whose own gradient is a cancelling sum.  Rule per tensor:
-        max|a-b| <= max(1e-3 * max(1e-2, max|ref_k|), 2e-3 * median_k max|ref_k|)
-    A real defect shows up as O(1) relative error on whole groups of tensors and still fails."""
-    scales = {k: float(np.abs(np.asarray(v)).max()) if np.asarray(v).size else 0.0 for k, v in named_ref.items()}
-    med = float(np.median([s for s in scales.values() if s > 0.0] or [0.0]))
+    A pre-activation within fp32 rounding of 0 may take the other PReLU branch in another fp32 implementation
+    (the reference's CPU path does it too against its own fp64 run: tools/diag_sites.py prints the flip counts).
+    One flipped element changes dy there by (1-alpha)*dy, i.e. a few percent of every weight-gradient entry of that
+    output channel (sum of ~N random terms, one of them changed) and of scalar gradients such as a PReLU slope.
+    So with the real slopes tensors are compared in relative L2 norm with a 5 % bound (plus a floor for
+    analytically-zero gradients); a real defect gives O(100 %) and still fails.  The tight bound (1e-4) is enforced on
+    the kink-free network in checks.check_model_vs_oracle(smooth=True)."""
+    def arr(v):
+        return np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float64)
+    norms = {k: float(np.linalg.norm(arr(v))) / max(1, arr(v).size) ** 0.5 for k, v in named_ref.items()}   # rms
+    med = float(np.median([s for s in norms.values() if s > 0.0] or [0.0]))
     for k, ref in named_ref.items():
-        got = named_got[k]
-        if isinstance(got, torch.Tensor):
-            got = got.detach().cpu().numpy()
-        ref = np.asarray(ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else ref)
-        err = float(np.abs(np.asarray(got, dtype=np.float64) - ref.astype(np.float64)).max()) if ref.size else 0.0
-        bound = max(1e-3 * max(1e-2, scales[k]), 2e-3 * med)
-        assert err <= bound, "%s grad %s: max err %.3e > bound %.3e (|ref| %.3e, median scale %.3e)" % (what, k, err, bound, scales[k], med)
+        ref, got = arr(ref), arr(named_got[k])
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        err = float(np.linalg.norm(got - ref)) / max(1, ref.size) ** 0.5
+        # scalar-like tensors (PReLU slopes, 3-channel BN) are single cancelling sums: one flip moves them by O(10 %)
+        rel, floor = (5e-2, 2e-3) if ref.size >= 16 else (0.25, 2e-2)
+        bound = max(rel * norms[k], floor * med)
+        assert err <= bound, "%s grad %s: rms err %.3e > bound %.3e (rms|ref| %.3e, median rms %.3e)" % (what, k, err, bound, norms[k], med)
