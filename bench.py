@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--workload", default="cistgcn8_b16_t50_v22", choices=sorted(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--branches", action="store_true", help="EXPERIMENTAL: capture independent branches on forked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
@@ -151,7 +152,7 @@ def main():
     x, tgt = synth(B, T, V, rank, args.data_seed)
     x, tgt = x.to(device), tgt.to(device)
     flat = FlatGrads(net.parameters(), device) if world > 1 else None
-    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat))
+    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat, branches=args.branches))
 
     def one():
         step.replay()
@@ -187,7 +188,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "C": C, "per_gpu_batch": B, "global_batch": B * world, "T_in": T, "T_out": 25,
-                   "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph,
+                   "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph, "graph_branches": bool(args.branches and not args.no_graph),
                    "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
                    "loss": loss},
     }

@@ -221,6 +221,36 @@ class CISTGCN(nn.Module):
         for part in (self.st_gcnns_o, self.st_gcnns, self.txcnns):
             _init_small(part, 0.1, False)
         self._site = 0
+        self.branch_streams = False   # True: independent branches of a block run on forked HIP streams (runtime.GraphedStep)
+        self._streams, self._next_stream = [], 0
+
+    # ---- fork / join of independent branches -----------------------------------------------------
+    def _parallel(self, thunks, inputs):
+        """Evaluate independent sub-graphs.  With `branch_streams` each one is issued on its own side stream,
+        forked from the current stream and joined afterwards; captured in a HIP graph they become parallel
+        branches, so the many small kernels of the gate / tower / domain paths overlap instead of queueing.
+        Tensors that cross streams are recorded on the consuming stream (caching-allocator contract)."""
+        if not (self.branch_streams and inputs[0].is_cuda) or len(thunks) < 2:
+            return [t() for t in thunks]
+        cur = torch.cuda.current_stream()
+        if not self._streams:
+            self._streams = [torch.cuda.Stream(device=inputs[0].device) for _ in range(16)]
+        results = []
+        for t in thunks:
+            s = self._streams[self._next_stream % len(self._streams)]
+            self._next_stream += 1
+            s.wait_stream(cur)
+            for x in inputs:
+                x.record_stream(s)
+            with torch.cuda.stream(s):
+                out = t()
+            results.append((out, s))
+        for out, s in results:
+            cur.wait_stream(s)
+            for o in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(o, torch.Tensor):
+                    o.record_stream(cur)
+        return [out for out, _ in results]
 
     # ---- fused row op with per-call dropout site id -------------------------------------------
     def _na(self, x, bn=None, prelu=None, drop=False, **kw):
@@ -247,8 +277,8 @@ class CISTGCN(nn.Module):
             h = self._na(self._lin(collapse, h, t[3]), bn=t[4], drop=True)
             return _pointwise(h, t[6])[0]
 
-        q = tower(m.time_compress, _collapse_rows).view(B, T, V)     # q[b,tau,v]
-        s = tower(m.joint_compress, _collapse_cols).view(B, V, T)    # s[b,v,t]
+        q, s = self._parallel([lambda: tower(m.time_compress, _collapse_rows), lambda: tower(m.joint_compress, _collapse_cols)], [x])
+        q, s = q.view(B, T, V), s.view(B, V, T)                       # q[b,tau,v], s[b,v,t]
         if layer.domain == "space":
             o = ops.contract("bvt,bxv->bvtx", s, q)                  # o[b,v,t,tau] = s[b,v,t] q[b,tau,v]
         else:
@@ -288,10 +318,9 @@ class CISTGCN(nn.Module):
     def _block(self, m, x):
         xn = self._na(x, bn=m.global_norm)
         stats = ops.dstd_stats(xn)                      # computed once; the reference evaluates it twice (:377,:379)
-        m.w1 = self._gate(m.conv_s, m.map_s, xn, stats)
-        m.w2 = self._gate(m.conv_t, m.map_t, xn, stats)
-        x1 = self._domain(m.dsgn, xn)
-        x2 = self._domain(m.tsgn, xn)
+        m.w1, m.w2, x1, x2 = self._parallel([lambda: self._gate(m.conv_s, m.map_s, xn, stats),
+                                             lambda: self._gate(m.conv_t, m.map_t, xn, stats),
+                                             lambda: self._domain(m.dsgn, xn), lambda: self._domain(m.tsgn, xn)], [xn, stats])
         a = self._na(x1, pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1])
         b = self._na(x2, pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])
         c = m.compressor
@@ -313,9 +342,10 @@ class CISTGCN(nn.Module):
         B, To, V, _ = x7.shape
         x = x7.view(B, 1, To, V * 3)
         c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
-        y1 = ops.max_bc(self._na(self._lin(_pointwise, x, c1[0]), bn=c1[1], prelu=c1[2]))
-        y2 = ops.max_bc(self._na(self._lin(_collapse_rows, x, c2[0]), bn=c2[1], prelu=c2[2]))
-        ym = ops.mean_bc(self._na(self._lin(_pointwise, x, c3[0]), bn=c3[1], prelu=c3[2]))
+        y1, y2, ym = self._parallel([
+            lambda: ops.max_bc(self._na(self._lin(_pointwise, x, c1[0]), bn=c1[1], prelu=c1[2])),
+            lambda: ops.max_bc(self._na(self._lin(_collapse_rows, x, c2[0]), bn=c2[1], prelu=c2[2])),
+            lambda: ops.mean_bc(self._na(self._lin(_pointwise, x, c3[0]), bn=c3[1], prelu=c3[2]))], [x])
         heads = [self._na(_linear(y, h[0])[0], drop=True, prelu=h[2]) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))]
         y = ops.cat_channels(heads)
         m.joints = self._na(self._lin(_linear, y, m.fmap_s[0]), bn=m.fmap_s[1], drop=True)
@@ -338,7 +368,7 @@ class CISTGCN(nn.Module):
         if x.dim() != 4 or x.shape[1] != self.n_input or x.shape[2] != self.n_joints or x.shape[3] != 3:
             raise ValueError("expected input of shape (B, %d, %d, 3), got %s" % (self.n_input, self.n_joints, tuple(x.shape)))
         ops.begin_step(x.device, bump_seed=self.training and self.dropout > 0.0)
-        self._site = 0
+        self._site, self._next_stream = 0, 0
         h = ops.feature_lift(x)                                         # (B,10,T,V)
         for blk in self.st_gcnns:
             h = self._block(blk, h)
@@ -350,8 +380,10 @@ class CISTGCN(nn.Module):
         z = self._na(self._lin(_pointwise, z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
         z = self._na(_pointwise(z, d[3])[0], prelu=d[4])                # PReLU(3): per-channel slopes (:545)
         x7 = ops.cumsum_time(z.permute(0, 2, 3, 1))                     # (B,T_out,V,3)
-        act = self._context(self.context_layer, x7)
-        x8 = x7.permute(0, 3, 2, 1)                                     # (B,3,V,T_out) view
-        for blk in self.st_gcnns_o:
-            x8 = self._block(blk, x8)
+        def output_blocks():
+            x8 = x7.permute(0, 3, 2, 1)                                 # (B,3,V,T_out) view
+            for blk in self.st_gcnns_o:
+                x8 = self._block(blk, x8)
+            return x8
+        act, x8 = self._parallel([lambda: self._context(self.context_layer, x7), output_blocks], [x7])
         return ops.add3(x[:, -1:], x8.permute(0, 3, 2, 1), act),

@@ -107,8 +107,11 @@ class GraphedStep:
     gradients (static buffers under replay) are gathered into the flat all-reduce buffer by one
     kernel launched right after the graph."""
 
-    def __init__(self, model, x, target, warmup=3, flat=None):
+    def __init__(self, model, x, target, warmup=3, flat=None, branches=False):
         self.model, self.flat = model, flat
+        # EXPERIMENTAL (off): independent branches on forked streams -> parallel graph branches.  ROCm 7.2's
+        # hipStreamEndCapture crashes on this many forked streams (round-1 GPU run), so the step is one linear chain.
+        model.branch_streams = bool(branches)
         self.x, self.target = x.clone(), target.clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
         side = torch.cuda.Stream()

@@ -61,7 +61,7 @@ def test_cpu_tensors_are_refused():
         ops.feature_lift(torch.zeros(2, 10, 22, 3))
 
 
-def test_graph_replay_matches_eager():
+def test_graph_replay_matches_eager(branches=False):
     """fwd+loss+bwd captured in a HIP graph replays to the same numbers (bench.py's step)."""
     from cistgcn_amd import ops
     from cistgcn_amd.runtime import GraphedStep
@@ -72,12 +72,13 @@ def test_graph_replay_matches_eager():
     tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
     net.dropout = 0.0
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    step = GraphedStep(net, x, tgt, warmup=2)
+    step = GraphedStep(net, x, tgt, warmup=2, branches=branches)
     net.load_state_dict(sd)
     loss_g = step.replay().item()
     grads_g = [p.grad.clone() for p in net.parameters()]
     net.load_state_dict(sd)
     net.zero_grad()
+    net.branch_streams = False
     pred, = net(x)
     loss = ops.mpjpe(pred, tgt)
     loss.backward()
