@@ -44,11 +44,30 @@ class NormAct(ctypes.Structure):
     ]
 
 
+class ContractDesc(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("bias", c_void_p), ("stats", c_void_p), ("tab", c_void_p),
+                ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("splitk", c_int), ("kchunk", c_int),
+                ("a_kfast", c_int), ("x_kfast", c_int), ("block0", c_longlong)]
+
+
+class StatsArgs(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("xv", View4), ("pre", c_void_p), ("stats", c_void_p)]
+
+
+class CopyItem(ctypes.Structure):
+    _fields_ = [("y", c_void_p), ("yv", View4), ("a", c_void_p), ("av", View4)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
     "cg_contract": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, LL, P],
+    "cg_contract_many": [POINTER(ContractDesc), c_int, P],
     "cg_chan_stats": [P, POINTER(View4), P, P, P],
+    "cg_chan_stats_many": [POINTER(StatsArgs), c_int, P],
+    "cg_norm_act_fwd_many": [POINTER(NormAct), c_int, P],
+    "cg_norm_act_bwd_many": [POINTER(NormAct), POINTER(c_int), c_int, P],
+    "cg_copy_many": [POINTER(CopyItem), c_int, P],
     "cg_chan_sum": [P, POINTER(View4), P, P],
     "cg_norm_act_fwd": [POINTER(NormAct), P],
     "cg_norm_act_bwd": [POINTER(NormAct), c_int, P],

@@ -17,13 +17,28 @@
 // Per K-step the kernel needs one dependent global load per operand element (offset tables are in
 // LDS / registers), and the loads of step s+1 are issued before the FMAs of step s so that their
 // latency overlaps the compute (register prefetch, single LDS tile).
+//
+// One launch runs up to CG_MAX_BATCH independent contractions ("horizontal fusion"): the descriptors
+// travel by value in the kernel arguments and every workgroup looks up the problem its block id
+// falls into.  The model issues the same-depth maps of its parallel branches (gate s/t, the four
+// Map2Adj towers, residual maps, and in backward every dA / dX / bias sum of a stage) as one launch.
+struct CgContractDesc {
+  const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
+  int G, M, N, K, splitk, kchunk, a_kfast, x_kfast;
+  long long block0;          // first block id of this problem inside the launch
+};
+#define CG_MAX_BATCH 16
+struct CgContractBatch { int n; int pad; CgContractDesc d[CG_MAX_BATCH]; };
+
 template <int BM, int TM>
-__global__ __launch_bounds__(256) void cg_contract_kernel(
-    const float* __restrict__ A, const float* __restrict__ X, float* __restrict__ Y,
-    const float* __restrict__ bias, double* __restrict__ stats, const int32_t* __restrict__ tab,
-    int G, int M, int N, int K, int splitk, int kchunk, int a_kfast, int x_kfast) {
+__device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long long bid, float* As_, float* Xs_,
+                                                 int32_t* sKA, int32_t* sKX, double* sStat_) {
   constexpr int BN = 64, TN = 4;
-  const int32_t* gA = tab;
+  const float* __restrict__ A = d.A; const float* __restrict__ X = d.X; float* __restrict__ Y = d.Y;
+  const float* __restrict__ bias = d.bias; double* __restrict__ stats = d.stats;
+  const int G = d.G, M = d.M, N = d.N, K = d.K, splitk = d.splitk, kchunk = d.kchunk;
+  const int a_kfast = d.a_kfast, x_kfast = d.x_kfast;
+  const int32_t* gA = d.tab;
   const int32_t* gX = gA + G;
   const int32_t* gY = gX + G;
   const int32_t* mA = gY + G;
@@ -33,16 +48,12 @@ __global__ __launch_bounds__(256) void cg_contract_kernel(
   const int32_t* nY = nX + N;
   const int32_t* kA = nY + N;
   const int32_t* kX = kA + K;
-
-  __shared__ float As[CG_BK][BM + 1];
-  __shared__ float Xs[CG_BK][BN + 1];
-  __shared__ int32_t sKA[CG_KT];
-  __shared__ int32_t sKX[CG_KT];
-  __shared__ double sStat[BM][2];   // per-row sum / sum of squares of this tile (train-mode BN epilogue)
+  float (*As)[BM + 1] = reinterpret_cast<float (*)[BM + 1]>(As_);
+  float (*Xs)[BN + 1] = reinterpret_cast<float (*)[BN + 1]>(Xs_);
+  double (*sStat)[2] = reinterpret_cast<double (*)[2]>(sStat_);
 
   const int tiles_n = (N + BN - 1) / BN;
   const int tiles_m = (M + BM - 1) / BM;
-  long long bid = blockIdx.x;
   const int tn = (int)(bid % tiles_n); bid /= tiles_n;
   const int tm = (int)(bid % tiles_m); bid /= tiles_m;
   const int sk = (int)(bid % splitk);  bid /= splitk;
@@ -62,7 +73,6 @@ __global__ __launch_bounds__(256) void cg_contract_kernel(
 
   constexpr int A_PER = (BM * CG_BK) / 256;   // 4 (BM=64) or 1 (BM=16)
   constexpr int X_PER = (BN * CG_BK) / 256;   // 4
-  // fixed (row, k-lane) / (col, k-lane) of the elements this thread stages, and their row/col offsets
   int a_mm[A_PER], a_kk[A_PER], x_nn[X_PER], x_kk[X_PER];
   long long a_off[A_PER], x_off[X_PER];
   const long long baseA = gA[g], baseX = gX[g];
@@ -154,7 +164,51 @@ __global__ __launch_bounds__(256) void cg_contract_kernel(
   }
 }
 
-// include/cistgcn_hip.h : cg_contract
+__global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch batch) {
+  __shared__ float As[CG_BK * 65];
+  __shared__ float Xs[CG_BK * 65];
+  __shared__ int32_t sKA[CG_KT];
+  __shared__ int32_t sKX[CG_KT];
+  __shared__ double sStat[64 * 2];
+  long long bid = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < batch.n; ++i)
+    if (bid >= batch.d[i].block0) pi = i;
+  const CgContractDesc& d = batch.d[pi];
+  bid -= d.block0;
+  if (d.M <= 16) cg_contract_body<16, 1>(d, bid, As, Xs, sKA, sKX, sStat);
+  else cg_contract_body<64, 4>(d, bid, As, Xs, sKA, sKX, sStat);
+}
+
+static long long cg_contract_blocks(CgContractDesc& d) {
+  int kchunk = (d.K + d.splitk - 1) / d.splitk;
+  d.kchunk = ((kchunk + CG_BK - 1) / CG_BK) * CG_BK;
+  const int BM = d.M <= 16 ? 16 : 64;
+  return (long long)((d.N + 63) / 64) * ((d.M + BM - 1) / BM) * d.splitk * d.G;
+}
+
+// include/cistgcn_hip.h : cg_contract_many.  Split-K outputs must be zero on entry (the host zeroes the one
+// buffer they are carved from).
+extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream_) {
+  if (!descs || n <= 0 || n > CG_MAX_BATCH) return CG_EARG;
+  CgContractBatch batch;
+  batch.n = n; batch.pad = 0;
+  long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    CgContractDesc d = descs[i];
+    if (!d.A || !d.X || !d.Y || !d.tab) return CG_EARG;
+    if (d.G <= 0 || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.splitk <= 0) return CG_ESHAPE;
+    if (d.stats && d.splitk > 1) return CG_EARG;
+    d.block0 = total;
+    total += cg_contract_blocks(d);
+    batch.d[i] = d;
+  }
+  if (total > 2147483647LL) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_contract_many_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
+}
+
+// include/cistgcn_hip.h : cg_contract (single problem; zeroes a split-K output itself)
 extern "C" int cg_contract(const float* A, const float* X, float* Y, const float* bias, double* stats, const int32_t* tables,
                            int G, int M, int N, int K, int splitk, int a_kfast, int x_kfast,
                            long long y_dense_numel, void* stream_) {
@@ -163,22 +217,12 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   if (G <= 0 || M <= 0 || N <= 0 || K <= 0 || splitk <= 0) return CG_ESHAPE;
   if (stats && splitk > 1) return CG_EARG;   // channel sums need final values
   if (splitk > 1) {
-    // split-K accumulates with atomics into a dense, zero-initialised output
     if (y_dense_numel != (long long)G * M * N) return CG_ESHAPE;
     hipError_t e = hipMemsetAsync(Y, 0, (size_t)y_dense_numel * sizeof(float), stream);
     if (e != hipSuccess) return (int)e;
   }
-  int kchunk = (K + splitk - 1) / splitk;
-  kchunk = ((kchunk + CG_BK - 1) / CG_BK) * CG_BK;
-  const bool small_m = M <= 16;
-  const int BM = small_m ? 16 : 64;
-  const long long tiles = (long long)((N + 63) / 64) * ((M + BM - 1) / BM);
-  const long long blocks = tiles * splitk * G;
-  if (blocks > 2147483647LL) return CG_ESHAPE;
-  dim3 grid((unsigned)blocks), block(256);
-  if (small_m)
-    hipLaunchKernelGGL((cg_contract_kernel<16, 1>), grid, block, 0, stream, A, X, Y, bias, stats, tables, G, M, N, K, splitk, kchunk, a_kfast, x_kfast);
-  else
-    hipLaunchKernelGGL((cg_contract_kernel<64, 4>), grid, block, 0, stream, A, X, Y, bias, stats, tables, G, M, N, K, splitk, kchunk, a_kfast, x_kfast);
-  return cg_launch_status();
+  CgContractDesc d;
+  d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.block0 = 0;
+  return cg_contract_many(&d, 1, stream_);
 }

@@ -26,10 +26,30 @@ __device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c)
 // ---------------------------------------------------------------------------------------------
 // per-channel sums  stats[c] = { sum_{b,p} v, sum v^2 },  v = x * pre[b,c]
 // ---------------------------------------------------------------------------------------------
-__global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, const float* __restrict__ pre,
-                                     double* __restrict__ stats, int rb) {
+// rows of one channel handled per workgroup: ~4096 elements, so that the block reduction and the f64 atomics
+// are amortised (a (B,C) BatchNorm1d input becomes one workgroup per channel)
+static int cg_rows_per_block(const CgView4& v) {
+  const long long P = v.n[2] * v.n[3];
+  long long rb = 4096 / (P > 0 ? P : 1);
+  if (rb < 1) rb = 1;
+  if (rb > v.n[0]) rb = v.n[0];
+  // small problems: keep at least ~512 workgroups in flight rather than amortising
+  while (rb > 1 && v.n[1] * ((v.n[0] + rb - 1) / rb) < 512) rb = (rb + 1) / 2;
+  return (int)rb;
+}
+
+#define CG_ROW_MAX_BATCH 6     // problems per launch of the row kernels (kernel-argument budget)
+struct CgStatsItem { const float* x; CgView4 xv; const float* pre; double* stats; int rb; int pad; };
+struct CgStatsBatch { int n; int pad; CgStatsItem it[CG_ROW_MAX_BATCH]; };
+
+__global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
   __shared__ double red[32];
+  const CgStatsItem& it = batch.it[blockIdx.z];
+  const CgView4& xv = it.xv;
+  const int rb = it.rb;
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (c >= xv.n[1] || b0 >= xv.n[0]) return;
+  const float* __restrict__ x = it.x; const float* __restrict__ pre = it.pre;
   const int P = (int)(xv.n[2] * xv.n[3]);
   const int nb = min(rb, (int)xv.n[0] - b0);
   double s = 0.0, q = 0.0;
@@ -44,32 +64,41 @@ __global__ void cg_chan_stats_kernel(const float* __restrict__ x, CgView4 xv, co
   s = cg_block_sum(s, red);
   q = cg_block_sum(q, red + 16);
   if (threadIdx.x == 0) {
-    atomicAdd(&stats[2 * c], s);
-    atomicAdd(&stats[2 * c + 1], q);
+    atomicAdd(&it.stats[2 * c], s);
+    atomicAdd(&it.stats[2 * c + 1], q);
   }
 }
 
-// rows of one channel handled per workgroup: ~4096 elements, so that the block reduction and the f64 atomics
-// are amortised (a (B,C) BatchNorm1d input becomes one workgroup per channel)
-static int cg_rows_per_block(const CgView4& v) {
-  const long long P = v.n[2] * v.n[3];
-  long long rb = 4096 / (P > 0 ? P : 1);
-  if (rb < 1) rb = 1;
-  if (rb > v.n[0]) rb = v.n[0];
-  // small problems: keep at least ~512 workgroups in flight rather than amortising
-  while (rb > 1 && v.n[1] * ((v.n[0] + rb - 1) / rb) < 512) rb = (rb + 1) / 2;
-  return (int)rb;
+struct CgStatsArgs { const float* x; CgView4 xv; const float* pre; double* stats; };
+
+// include/cistgcn_hip.h : cg_chan_stats_many (up to CG_ROW_MAX_BATCH tensors per launch)
+extern "C" int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream_) {
+  if (!items || n <= 0 || n > CG_ROW_MAX_BATCH) return CG_EARG;
+  CgStatsBatch batch;
+  batch.n = n; batch.pad = 0;
+  long long gx = 1, gy = 1, big = 0;
+  for (int i = 0; i < n; ++i) {
+    const CgStatsArgs& a = items[i];
+    if (!a.x || !a.stats) return CG_EARG;
+    const long long P = a.xv.n[2] * a.xv.n[3];
+    if (a.xv.n[0] <= 0 || a.xv.n[1] <= 0 || P <= 0) return CG_ESHAPE;
+    const int rb = cg_rows_per_block(a.xv);
+    batch.it[i].x = a.x; batch.it[i].xv = a.xv; batch.it[i].pre = a.pre; batch.it[i].stats = a.stats; batch.it[i].rb = rb; batch.it[i].pad = 0;
+    gx = gx > a.xv.n[1] ? gx : a.xv.n[1];
+    const long long chunks = (a.xv.n[0] + rb - 1) / rb;
+    gy = gy > chunks ? gy : chunks;
+    if (P * rb > 256) big = 1;
+  }
+  if (gy > 65535 || gx > 2147483647LL) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_chan_stats_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)n), dim3(big ? 256 : 64), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
 }
 
 extern "C" int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
   if (!x || !xv || !stats) return CG_EARG;
-  const long long P = xv->n[2] * xv->n[3];
-  if (xv->n[0] <= 0 || xv->n[1] <= 0 || P <= 0 || xv->n[0] > 65535) return CG_ESHAPE;
-  const int rb = cg_rows_per_block(*xv);
-  dim3 grid((unsigned)xv->n[1], (unsigned)((xv->n[0] + rb - 1) / rb)), block(P * rb <= 256 ? 64 : 256);
-  hipLaunchKernelGGL(cg_chan_stats_kernel, grid, block, 0, stream, x, *xv, pre, stats, rb);
-  return cg_launch_status();
+  CgStatsArgs a;
+  a.x = x; a.xv = *xv; a.pre = pre; a.stats = stats;
+  return cg_chan_stats_many(&a, 1, stream_);
 }
 
 // per-channel plain sum in f32 output (bias gradients): out[c] = sum_{b,p} x
@@ -124,6 +153,7 @@ struct CgNormAct {
 // nn.BatchNorm does); the folded form v*scale + (beta - mean*scale) cancels catastrophically when
 // |mean| >> std.
 struct CgChanAffine { float scale, shift, mean, rstd; };
+struct CgNormActBatch { int n; int rb[CG_ROW_MAX_BATCH]; int pad; CgNormAct a[CG_ROW_MAX_BATCH]; };
 
 __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c, bool backward) {
   CgChanAffine r;
@@ -157,8 +187,11 @@ __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c
   return r;
 }
 
-__global__ void cg_norm_act_fwd_kernel(CgNormAct a, int rb) {
+__global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
+  const CgNormAct& a = batch.a[blockIdx.z];
+  const int rb = batch.rb[blockIdx.z];
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (c >= a.xv.n[1] || b0 >= a.xv.n[0]) return;
   const long long C = a.xv.n[1];
   const int P = (int)(a.xv.n[2] * a.xv.n[3]);
   const int nb = min(rb, (int)a.xv.n[0] - b0);
@@ -195,9 +228,12 @@ __device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChan
 }
 
 // pass 1 of backward: per-channel sums of g and g*xhat (f64), d alpha
-__global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a, int rb) {
+__global__ void cg_norm_act_bwd_reduce_kernel(CgNormActBatch batch) {
   __shared__ double red[48];
+  const CgNormAct& a = batch.a[blockIdx.z];
+  const int rb = batch.rb[blockIdx.z];
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (c >= a.xv.n[1] || b0 >= a.xv.n[0]) return;
   const long long C = a.xv.n[1];
   const int P = (int)(a.xv.n[2] * a.xv.n[3]);
   const int nb = min(rb, (int)a.xv.n[0] - b0);
@@ -225,9 +261,12 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormAct a, int rb) {
 }
 
 // pass 2 of backward: dx, d add, d pre (row sums), and the per-channel parameter gradients
-__global__ void cg_norm_act_bwd_apply_kernel(CgNormAct a, int rb) {
+__global__ void cg_norm_act_bwd_apply_kernel(CgNormActBatch batch) {
   __shared__ double red[16];
-  const int c = blockIdx.x, b0 = blockIdx.y * rb;     // rb == 1 whenever the per-row gate gradient is requested
+  const CgNormAct& a = batch.a[blockIdx.z];
+  const int rb = batch.rb[blockIdx.z];                // rb == 1 whenever the per-row gate gradient is requested
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (c >= a.xv.n[1] || b0 >= a.xv.n[0]) return;
   const long long C = a.xv.n[1];
   const int P = (int)(a.xv.n[2] * a.xv.n[3]);
   const int nb = min(rb, (int)a.xv.n[0] - b0);
@@ -284,33 +323,62 @@ static int cg_norm_act_check(const CgNormAct* a, bool fwd) {
 static dim3 cg_row_block(const CgView4& v) { return dim3(v.n[2] * v.n[3] <= 256 ? 64 : 256); }
 static dim3 cg_chunk_block(const CgView4& v, int rb) { return dim3(v.n[2] * v.n[3] * rb <= 256 ? 64 : 256); }
 
-extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) {
-  int st = cg_norm_act_check(a, true);
-  if (st != CG_OK) return st;
-  if (!a->y) return CG_EARG;
-  const int rb = cg_rows_per_block(a->xv);
-  dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rb - 1) / rb));
-  hipLaunchKernelGGL(cg_norm_act_fwd_kernel, grid, cg_chunk_block(a->xv, rb), 0, (hipStream_t)stream_, *a, rb);
+// kind: 0 forward, 1 backward reduce, 2 backward apply
+static int cg_norm_act_launch(const CgNormAct* arr, const int* sel, int n, int kind, hipStream_t stream) {
+  CgNormActBatch batch;
+  batch.n = n; batch.pad = 0;
+  long long gx = 1, gy = 1, big = 0;
+  for (int i = 0; i < n; ++i) {
+    const CgNormAct& a = arr[sel ? sel[i] : i];
+    int rb = cg_rows_per_block(a.xv);
+    if (kind == 2 && a.dpre) rb = 1;      // the gate gradient is one sum per (batch, channel) row
+    batch.a[i] = a; batch.rb[i] = rb;
+    gx = gx > a.xv.n[1] ? gx : a.xv.n[1];
+    const long long chunks = (a.xv.n[0] + rb - 1) / rb;
+    gy = gy > chunks ? gy : chunks;
+    if (a.xv.n[2] * a.xv.n[3] * rb > 256) big = 1;
+  }
+  if (gy > 65535) return CG_ESHAPE;
+  dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n), block(big ? 256 : 64);
+  if (kind == 0) hipLaunchKernelGGL(cg_norm_act_fwd_kernel, grid, block, 0, stream, batch);
+  else if (kind == 1) hipLaunchKernelGGL(cg_norm_act_bwd_reduce_kernel, grid, block, 0, stream, batch);
+  else hipLaunchKernelGGL(cg_norm_act_bwd_apply_kernel, grid, block, 0, stream, batch);
   return cg_launch_status();
 }
 
-// `red` must be zero on entry (the host hands out slices of the per-step zeroed arena).
-extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream_) {
-  int st = cg_norm_act_check(a, false);
-  if (st != CG_OK) return st;
-  if (!a->dy) return CG_EARG;
-  if ((a->bn_mode != 0 || a->alpha) && !a->red) return CG_EARG;
-  const int rb = cg_rows_per_block(a->xv);
-  if (need_reduce) {
-    dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rb - 1) / rb));
-    hipLaunchKernelGGL(cg_norm_act_bwd_reduce_kernel, grid, cg_chunk_block(a->xv, rb), 0, (hipStream_t)stream_, *a, rb);
-    st = cg_launch_status();
+// include/cistgcn_hip.h : cg_norm_act_fwd_many / cg_norm_act_bwd_many (up to CG_ROW_MAX_BATCH row problems per launch)
+extern "C" int cg_norm_act_fwd_many(const CgNormAct* arr, int n, void* stream_) {
+  if (!arr || n <= 0 || n > CG_ROW_MAX_BATCH) return CG_EARG;
+  for (int i = 0; i < n; ++i) {
+    int st = cg_norm_act_check(&arr[i], true);
+    if (st != CG_OK) return st;
+    if (!arr[i].y) return CG_EARG;
+  }
+  return cg_norm_act_launch(arr, nullptr, n, 0, (hipStream_t)stream_);
+}
+
+// `red` of every problem must be zero on entry (slices of the per-step zeroed arena).
+extern "C" int cg_norm_act_bwd_many(const CgNormAct* arr, const int* need_reduce, int n, void* stream_) {
+  if (!arr || !need_reduce || n <= 0 || n > CG_ROW_MAX_BATCH) return CG_EARG;
+  int sel[CG_ROW_MAX_BATCH], nr = 0;
+  for (int i = 0; i < n; ++i) {
+    int st = cg_norm_act_check(&arr[i], false);
+    if (st != CG_OK) return st;
+    if (!arr[i].dy) return CG_EARG;
+    if ((arr[i].bn_mode != 0 || arr[i].alpha) && !arr[i].red) return CG_EARG;
+    if (need_reduce[i]) sel[nr++] = i;
+  }
+  if (nr > 0) {
+    int st = cg_norm_act_launch(arr, sel, nr, 1, (hipStream_t)stream_);
     if (st != CG_OK) return st;
   }
-  const int rba = a->dpre ? 1 : rb;      // the gate gradient is one sum per (batch, channel) row
-  dim3 grid((unsigned)a->xv.n[1], (unsigned)((a->xv.n[0] + rba - 1) / rba));
-  hipLaunchKernelGGL(cg_norm_act_bwd_apply_kernel, grid, cg_chunk_block(a->xv, rba), 0, (hipStream_t)stream_, *a, rba);
-  return cg_launch_status();
+  return cg_norm_act_launch(arr, nullptr, n, 2, (hipStream_t)stream_);
+}
+
+extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) { return cg_norm_act_fwd_many(a, 1, stream_); }
+
+extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream_) {
+  return cg_norm_act_bwd_many(a, &need_reduce, 1, stream_);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -406,6 +474,40 @@ extern "C" int cg_add3(float* y, const CgView4* yv, const float* a, const CgView
   dim3 grid((unsigned)yv->n[1], (unsigned)yv->n[0]);
   hipLaunchKernelGGL(cg_add3_kernel, grid, cg_row_block(*yv), 0, (hipStream_t)stream_, y, *yv, a, *av,
                      b, b ? *bv : zero, c, c ? *cv : zero);
+  return cg_launch_status();
+}
+
+// up to four strided copies in one launch (the slices of a channel concatenation)
+struct CgCopyItem { float* y; CgView4 yv; const float* a; CgView4 av; };
+struct CgCopyBatch { int n; int pad; CgCopyItem it[4]; };
+
+__global__ void cg_copy_many_kernel(CgCopyBatch batch) {
+  const CgCopyItem& it = batch.it[blockIdx.z];
+  const int c = blockIdx.x, b = blockIdx.y;
+  if (c >= it.yv.n[1] || b >= it.yv.n[0]) return;
+  const int P = (int)(it.yv.n[2] * it.yv.n[3]);
+  const long long by = cg_row_base(it.yv, b, c), ba = cg_row_base(it.av, b, c);
+  CG_ROW_LOOP(P, p) {
+    CG_POS(it.yv, p)
+    it.y[by + CG_OFF(it.yv)] = it.a[ba + CG_OFF(it.av)];
+  }
+}
+
+extern "C" int cg_copy_many(const CgCopyItem* items, int n, void* stream_) {
+  if (!items || n <= 0 || n > 4) return CG_EARG;
+  CgCopyBatch batch;
+  batch.n = n; batch.pad = 0;
+  long long gx = 1, gy = 1, big = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].y || !items[i].a) return CG_EARG;
+    const CgView4& v = items[i].yv;
+    if (v.n[0] <= 0 || v.n[1] <= 0 || v.n[2] * v.n[3] <= 0 || v.n[0] > 65535) return CG_ESHAPE;
+    batch.it[i] = items[i];
+    gx = gx > v.n[1] ? gx : v.n[1];
+    gy = gy > v.n[0] ? gy : v.n[0];
+    if (v.n[2] * v.n[3] > 256) big = 1;
+  }
+  hipLaunchKernelGGL(cg_copy_many_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)n), dim3(big ? 256 : 64), 0, (hipStream_t)stream_, batch);
   return cg_launch_status();
 }
 

@@ -175,6 +175,33 @@ def _linear(x, lin, stats=False):
     return ops.contract_stats("oi,bi->bo", lin.weight, x) if stats else (ops.contract("oi,bi->bo", lin.weight, x), None)
 
 
+# ---- the same maps as contraction items for ops.contract_many (one launch per stage) ---------------
+def _pw_item(x, conv, stats):
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    spec = "oc,bchw->bohw" if x.dim() == 4 else "oc,bcv->bov"
+    return (spec, w, x, conv.bias, "o" if conv.bias is not None else None, "o" if stats else None), None
+
+
+def _rows_item(x, conv, stats):
+    w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[2])
+    return ("och,bchw->bow", w, x, None, None, "o" if stats else None), (lambda y: y.view(y.shape[0], y.shape[1], 1, y.shape[2]))
+
+
+def _cols_item(x, conv, stats):
+    w = conv.weight.view(conv.out_channels, conv.in_channels, x.shape[3])
+    return ("ocw,bchw->boh", w, x, None, None, "o" if stats else None), (lambda y: y.view(y.shape[0], y.shape[1], y.shape[2], 1))
+
+
+def _lin_item(x, lin, stats):
+    return ("oi,bi->bo", lin.weight, x, None, None, "o" if stats else None), None
+
+
+def _run_items(items):
+    """items: list of (contraction item, view-fixup) -> list of (y, channel sums)"""
+    outs = ops.contract_many([it for it, _ in items])
+    return [((post(y) if post is not None else y), st) for (y, st), (_, post) in zip(outs, items)]
+
+
 class CISTGCN(nn.Module):
     """
     Shape:
@@ -194,6 +221,7 @@ class CISTGCN(nn.Module):
         self.dropout = float(learn.dropout)
         self.in_ch = 10
         self.fused_domain = True     # False: graph product and channel mix as two generic contractions
+        self.staged = True           # True: same-depth ops of a block's parallel branches share one launch
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
@@ -329,11 +357,112 @@ class CISTGCN(nn.Module):
         res = xn if isinstance(m.residual, nn.Identity) else self._na(self._lin(_pointwise, xn, m.residual[0]), bn=m.residual[1])
         return self._na(h, pre=gate, add=res, add_post=True)
 
+    # ---- the same block with horizontal fusion ---------------------------------------------------------
+    def _na_many(self, calls):
+        """calls: dicts for ops.norm_act (x may be a (tensor, sums) pair); adds train flag, dropout and site ids."""
+        out = []
+        for kw in calls:
+            kw = dict(kw)
+            self._site += 1
+            drop = kw.pop("drop", False)
+            kw.update(train=self.training, drop_p=self.dropout if drop else 0.0, salt=self._site)
+            out.append(kw)
+        return ops.norm_act_many(out)
+
+    def _block_staged(self, m, x):
+        """DSTD_GC.forward (CISTGCN.py:373-390) with the gate paths (:378-384), the four Map2Adj towers (:183-189) and
+        the two domain layers (:259-269) advanced in lock-step: every stage is one contraction launch or one row-kernel
+        launch for all branches instead of one launch per branch and op."""
+        tr = self.training
+        doms = (m.dsgn, m.tsgn)
+        if not all(d.interpretable for d in doms):
+            return self._block(m, x)
+        xn = self._na(x, bn=m.global_norm)
+        stats = ops.dstd_stats(xn)
+        B, _, T, V = xn.shape
+        has_res = not isinstance(m.dsgn.residual, nn.Identity)
+        has_bres = not isinstance(m.residual, nn.Identity)
+        maps = [d.map_to_adj for d in doms]
+        # 1. every first-level map of xn
+        items = [_rows_item(xn, m.conv_s[0], tr), _rows_item(xn, m.conv_t[0], tr)]
+        for a in maps:
+            items += [_pw_item(xn, a.time_compress[0], tr), _pw_item(xn, a.joint_compress[0], tr)]
+        if has_res:
+            items += [_pw_item(xn, d.residual[0], tr) for d in doms]
+        if has_bres:
+            items.append(_pw_item(xn, m.residual[0], tr))
+        o = _run_items(items)
+        gs, gt, tc = o[0], o[1], o[2:6]
+        # 2. their BatchNorm / PReLU tails
+        calls = [dict(x=gs, bn=m.conv_s[1], drop=True, prelu=m.conv_s[3]), dict(x=gt, bn=m.conv_t[1], drop=True, prelu=m.conv_t[3])]
+        for i, a in enumerate(maps):
+            calls += [dict(x=tc[2 * i], bn=a.time_compress[1], prelu=a.time_compress[2]),
+                      dict(x=tc[2 * i + 1], bn=a.joint_compress[1], prelu=a.joint_compress[2])]
+        k = 6
+        if has_res:
+            calls += [dict(x=o[k + i], bn=d.residual[1]) for i, d in enumerate(doms)]
+            k += 2
+        if has_bres:
+            calls.append(dict(x=o[k], bn=m.residual[1]))
+        r = self._na_many(calls)
+        gs, gt, t1 = r[0], r[1], r[2:6]
+        res = r[6:8] if has_res else [xn, xn]
+        bres = r[-1] if has_bres else xn
+        # 3. collapsing convolutions
+        items = [_cols_item(gs, m.conv_s[4], tr), _cols_item(gt, m.conv_t[4], tr)]
+        for i, a in enumerate(maps):
+            items += [_rows_item(t1[2 * i], a.time_compress[3], tr), _cols_item(t1[2 * i + 1], a.joint_compress[3], tr)]
+        o = _run_items(items)
+        # 4. BatchNorm tails
+        calls = [dict(x=o[0], bn=m.conv_s[5], drop=True, prelu=m.conv_s[7]), dict(x=o[1], bn=m.conv_t[5], drop=True, prelu=m.conv_t[7])]
+        for i, a in enumerate(maps):
+            calls += [dict(x=o[2 + 2 * i], bn=a.time_compress[4], drop=True), dict(x=o[3 + 2 * i], bn=a.joint_compress[4], drop=True)]
+        r = self._na_many(calls)
+        hs = ops.cat_channels([r[0].view(B, -1), stats])
+        ht = ops.cat_channels([r[1].view(B, -1), stats])
+        # 5. gate Linear + last tower maps
+        items = [_lin_item(hs, m.map_s[0], tr), _lin_item(ht, m.map_t[0], tr)]
+        for i, a in enumerate(maps):
+            items += [_pw_item(r[2 + 2 * i], a.time_compress[6], False), _pw_item(r[3 + 2 * i], a.joint_compress[6], False)]
+        o = _run_items(items)
+        g = self._na_many([dict(x=o[0], bn=m.map_s[1], drop=True, prelu=m.map_s[3]), dict(x=o[1], bn=m.map_t[1], drop=True, prelu=m.map_t[3])])
+        # 6. rank-1 products  o[b,v,t,tau] = s[b,v,t] q[b,tau,v]  |  o[b,t,v,w] = s[b,v,t] q[b,t,w]
+        outer = []
+        for i, d in enumerate(doms):
+            q, s = o[2 + 2 * i][0].view(B, T, V), o[3 + 2 * i][0].view(B, V, T)
+            outer.append((("bvt,bxv->bvtx" if d.domain == "space" else "bvt,btw->btvw"), s, q, None, None, None))
+        oo = ops.contract_many(outer)
+        # 7. gate output Linear + expansor first map
+        items = [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
+        items += [_pw_item(oo[i][0], a.expansor[0], tr) for i, a in enumerate(maps)]
+        o = _run_items(items)
+        m.w1, m.w2 = o[0][0], o[1][0]
+        e = self._na_many([dict(x=o[2 + i], bn=a.expansor[1], drop=True, prelu=a.expansor[3]) for i, a in enumerate(maps)])
+        adj = _run_items([_pw_item(e[i], a.expansor[4], False) for i, a in enumerate(maps)])
+        # 8. graph product + channel mix, then BN + residual + PReLU
+        ys = []
+        for i, d in enumerate(doms):
+            d.Adj = adj[i][0]
+            conv = d.tcn[0]
+            if self.fused_domain:
+                wmat = conv.weight.view(conv.out_channels, conv.in_channels)
+                ys.append(ops.stgcn_domain(xn, d.Adj, wmat, conv.bias, 0 if d.domain == "space" else 1, tr))
+            else:
+                spec = "bctv,bvtq->bcqv" if d.domain == "space" else "bctv,btvw->bctw"
+                ys.append(self._lin(_pointwise, ops.contract(spec, xn, d.Adj), conv))
+        x12 = self._na_many([dict(x=ys[i], bn=d.tcn[1], drop=True, add=res[i], prelu=d.prelu) for i, d in enumerate(doms)])
+        ab = self._na_many([dict(x=x12[0], pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1]),
+                            dict(x=x12[1], pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])])
+        c = m.compressor
+        h = self._na(self._lin(_pointwise, ops.cat_channels(ab), c[0]), bn=c[1], prelu=c[2])
+        gate = ops.se_gate(ops.mean_bc(h), c[3].w1, c[3].w2)
+        return self._na(h, pre=gate, add=bres, add_post=True)
+
     # ---- FPN.forward, CISTGCN.py:74-79 -------------------------------------------------------------
     def _fpn(self, m, x):
         blocks = (m.block1, m.block2, m.block3)
         ys = ops.dilated_convs(x, [b[0] for b in blocks])
-        outs = [self._na(y, bn=b[1], prelu=b[3]) for y, b in zip(ys, blocks)]     # FPN dropout p = 0 (:533)
+        outs = self._na_many([dict(x=y, bn=b[1], prelu=b[3]) for y, b in zip(ys, blocks)])   # FPN dropout p = 0 (:533)
         outs.append(ops.mean_bc(x))                                                # action context, broadcast below
         return _pointwise(ops.cat_channels(outs, bcast=(False, False, False, True)), m.compress)[0]
 
@@ -342,14 +471,15 @@ class CISTGCN(nn.Module):
         B, To, V, _ = x7.shape
         x = x7.view(B, 1, To, V * 3)
         c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
-        y1, y2, ym = self._parallel([
-            lambda: ops.max_bc(self._na(self._lin(_pointwise, x, c1[0]), bn=c1[1], prelu=c1[2])),
-            lambda: ops.max_bc(self._na(self._lin(_collapse_rows, x, c2[0]), bn=c2[1], prelu=c2[2])),
-            lambda: ops.mean_bc(self._na(self._lin(_pointwise, x, c3[0]), bn=c3[1], prelu=c3[2]))], [x])
-        heads = [self._na(_linear(y, h[0])[0], drop=True, prelu=h[2]) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))]
+        tr = self.training
+        o = _run_items([_pw_item(x, c1[0], tr), _rows_item(x, c2[0], tr), _pw_item(x, c3[0], tr)])
+        r = self._na_many([dict(x=o[i], bn=c[1], prelu=c[2]) for i, c in enumerate((c1, c2, c3))])
+        y1, y2, ym = ops.max_bc(r[0]), ops.max_bc(r[1]), ops.mean_bc(r[2])
+        o = _run_items([_lin_item(y, h[0], False) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))])
+        heads = self._na_many([dict(x=o[i][0], drop=True, prelu=h[2]) for i, h in enumerate((m.map1, m.map2, m.map3))])
         y = ops.cat_channels(heads)
-        m.joints = self._na(self._lin(_linear, y, m.fmap_s[0]), bn=m.fmap_s[1], drop=True)
-        m.displacements = self._na(self._lin(_linear, y, m.fmap_t[0]), bn=m.fmap_t[1], drop=True)
+        o = _run_items([_lin_item(y, m.fmap_s[0], tr), _lin_item(y, m.fmap_t[0], tr)])
+        m.joints, m.displacements = self._na_many([dict(x=o[0], bn=m.fmap_s[1], drop=True), dict(x=o[1], bn=m.fmap_t[1], drop=True)])
         m.seq_joints = ops.contract("bt,bv->btv", m.displacements, m.joints)
         n = m.norm_map
         h = self._na(self._lin(_pointwise, m.seq_joints, n[0]), bn=n[1], drop=True, prelu=n[3])
@@ -370,8 +500,9 @@ class CISTGCN(nn.Module):
         ops.begin_step(x.device, bump_seed=self.training and self.dropout > 0.0)
         self._site, self._next_stream = 0, 0
         h = ops.feature_lift(x)                                         # (B,10,T,V)
+        block = self._block_staged if self.staged else self._block
         for blk in self.st_gcnns:
-            h = self._block(blk, h)
+            h = block(blk, h)
         h = h.permute(0, 2, 1, 3)                                       # NCTV -> NTCV (view)
         z = self._na(self._fpn(self.txcnns[0], h), prelu=self.prelus[0])
         for i in range(1, self.n_txcnn_layers):
@@ -383,7 +514,7 @@ class CISTGCN(nn.Module):
         def output_blocks():
             x8 = x7.permute(0, 3, 2, 1)                                 # (B,3,V,T_out) view
             for blk in self.st_gcnns_o:
-                x8 = self._block(blk, x8)
+                x8 = block(blk, x8)
             return x8
         act, x8 = self._parallel([lambda: self._context(self.context_layer, x7), output_blocks], [x7])
         return ops.add3(x[:, -1:], x8.permute(0, 3, 2, 1), act),

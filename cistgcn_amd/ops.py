@@ -181,10 +181,13 @@ def _label_strides(t, labels):
     return {l: s for l, s in zip(labels, t.stride())}
 
 
-def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None):
-    """Y = contraction of a and x per einsum-style `spec`; returns a fresh contiguous tensor.
-    `sa`/`sx` (label -> element stride) and `oa`/`ox` override the operands' own strides, which is
-    how dilated / halo-shifted windows are addressed without materialising them."""
+class _Prep:
+    """One contraction ready to launch: descriptor, output tensor, optional channel-sum slice."""
+    __slots__ = ("desc", "y", "stats", "zero")
+
+
+def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None,
+                      out=None):
     ins, ly = spec.split("->")
     la, lx = ins.split(",")
     _chk(a, "a"), _chk(x, "x")
@@ -196,15 +199,56 @@ def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, s
                     raise ValueError("contract: size mismatch for index '%s' in %s" % (l, spec))
     sa = _label_strides(a, la) if sa is None else sa
     sx = _label_strides(x, lx) if sx is None else sx
-    y = torch.empty([sizes[l] for l in ly], dtype=torch.float32, device=x.device)
+    shape = [sizes[l] for l in ly]
+    y = out.view(shape) if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
     sy = _label_strides(y, ly)
     p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label or stats_label, x.device, True)
-    stats = None
+    r = _Prep()
+    r.y, r.zero, r.stats = y, p.splitk > 1, None
     if stats_label is not None and p.splitk == 1:
-        stats = _arena(x.device).take(2 * sizes[stats_label])     # f64 channel sums of y for the BatchNorm that follows
-    _lib.call("cg_contract", _ptr(a), _ptr(x), _ptr(y), _ptr(bias), _ptr(stats), _ptr(p.tables), p.G, p.M, p.N, p.K,
-              p.splitk, p.a_kfast, p.x_kfast, y.numel(), _stream(x))
-    return (y, stats) if stats_label is not None else y
+        r.stats = _arena(x.device).take(2 * sizes[stats_label])     # f64 channel sums of y for the BatchNorm that follows
+    d = _lib.ContractDesc()
+    d.A, d.X, d.Y, d.tab = a.data_ptr(), x.data_ptr(), y.data_ptr(), p.tables.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.stats = r.stats.data_ptr() if r.stats is not None else None
+    d.G, d.M, d.N, d.K, d.splitk, d.a_kfast, d.x_kfast = p.G, p.M, p.N, p.K, p.splitk, p.a_kfast, p.x_kfast
+    r.desc = d
+    return r
+
+
+_MAX_CONTRACT_BATCH = 16
+
+
+def _contract_launch(builders, device):
+    """builders: callables out -> _Prep (out = pre-zeroed flat buffer for a split-K result, else None).
+    Runs all contractions in as few launches as possible; split-K outputs share ONE zeroed buffer."""
+    # first pass decides which problems need a zeroed output (plan lookup is cached, so this is cheap)
+    probe = [b(None) for b in builders]
+    need = [i for i, r in enumerate(probe) if r.zero]
+    if need:
+        sizes = [probe[i].y.numel() for i in need]
+        zbuf = torch.empty(sum((n + 3) & ~3 for n in sizes), dtype=torch.float32, device=device)
+        _lib.call("cg_zero", _ptr(zbuf), zbuf.numel() * 4, _stream(zbuf))
+        off = 0
+        for i, n in zip(need, sizes):
+            stale = probe[i]
+            probe[i] = builders[i](zbuf[off:off + n])
+            probe[i].stats = stale.stats
+            off += (n + 3) & ~3
+    for c0 in range(0, len(probe), _MAX_CONTRACT_BATCH):
+        chunk = probe[c0:c0 + _MAX_CONTRACT_BATCH]
+        arr = (_lib.ContractDesc * len(chunk))(*[r.desc for r in chunk])
+        _lib.call("cg_contract_many", arr, len(chunk), _stream(chunk[0].y))
+    return probe
+
+
+def _contract_raw(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None):
+    """Y = contraction of a and x per einsum-style `spec`; returns a fresh contiguous tensor.
+    `sa`/`sx` (label -> element stride) and `oa`/`ox` override the operands' own strides, which is
+    how dilated / halo-shifted windows are addressed without materialising them."""
+    r = _contract_launch([lambda out: _contract_prepare(spec, a, x, bias, bias_label, sizes, sa, sx, oa, ox, stats_label, out)],
+                         x.device)[0]
+    return (r.y, r.stats) if stats_label is not None else r.y
 
 
 _ones = {}
@@ -220,6 +264,69 @@ def _sum_keep(t, labels, keep):
         return t
     sizes = {l: n for l, n in zip(labels, t.shape)}
     return _contract_raw("%s,%s->%s" % (labels, rest, keep), t, one, sizes=sizes, sx={l: 0 for l in rest})
+
+
+def _sum_keep_builder(t, labels, keep):
+    one = _ones.get(t.device)
+    if one is None:
+        one = _ones[t.device] = torch.ones(1, dtype=torch.float32, device=t.device)
+    rest = "".join(l for l in labels if l not in keep)
+    sizes = {l: n for l, n in zip(labels, t.shape)}
+    return lambda out: _contract_prepare("%s,%s->%s" % (labels, rest, keep), t, one, sizes=sizes, sx={l: 0 for l in rest}, out=out)
+
+
+class _ContractMany(torch.autograd.Function):
+    """Several independent contractions in one launch (forward) and all their gradients in one launch (backward)."""
+
+    @staticmethod
+    def forward(ctx, metas, *ts):
+        n = len(metas)
+        trip = [ts[3 * i:3 * i + 3] for i in range(n)]
+        builders = [(lambda out, m=m, t=t: _contract_prepare(m[0], t[0], t[1], t[2], m[1], stats_label=m[2], out=out))
+                    for m, t in zip(metas, trip)]
+        preps = _contract_launch(builders, trip[0][1].device)
+        ctx.metas = metas
+        ctx.save_for_backward(*[t for tr in trip for t in tr[:2]])
+        outs = []
+        for r in preps:
+            if r.stats is not None:
+                ctx.mark_non_differentiable(r.stats)
+            outs += [r.y, r.stats]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved = ctx.saved_tensors
+        builders, slots = [], []
+        for i, (spec, bias_label, _) in enumerate(ctx.metas):
+            a, x, dy = saved[2 * i], saved[2 * i + 1], grads[2 * i]
+            ins, ly = spec.split("->")
+            la, lx = ins.split(",")
+            if ctx.needs_input_grad[1 + 3 * i]:
+                builders.append(lambda out, s="%s,%s->%s" % (ly, lx, la), dy=dy, x=x: _contract_prepare(s, dy, x, out=out))
+                slots.append(3 * i)
+            if ctx.needs_input_grad[2 + 3 * i]:
+                builders.append(lambda out, s="%s,%s->%s" % (la, ly, lx), a=a, dy=dy: _contract_prepare(s, a, dy, out=out))
+                slots.append(3 * i + 1)
+            if ctx.needs_input_grad[3 + 3 * i]:
+                builders.append(_sum_keep_builder(dy, ly, bias_label))
+                slots.append(3 * i + 2)
+        res = [None] * (3 * len(ctx.metas))
+        if builders:
+            for slot, r in zip(slots, _contract_launch(builders, grads[0].device)):
+                res[slot] = r.y
+        return (None,) + tuple(res)
+
+
+def contract_many(items):
+    """items: (spec, a, x, bias, bias_label, stats_label) tuples -> list of (y, channel sums or None).
+    All contractions run in one launch; so do all their gradients."""
+    metas = tuple((it[0], it[4], it[5]) for it in items)
+    flat = []
+    for it in items:
+        flat += [it[1], it[2], it[3]]
+    out = _ContractMany.apply(metas, *flat)
+    return [(out[2 * i], out[2 * i + 1]) for i in range(len(items))]
 
 
 class _Contract(torch.autograd.Function):
@@ -263,119 +370,176 @@ def contract_stats(spec, a, x, bias=None, bias_label=None, stats_label="o"):
 # ----------------------------------------------------------------------------------------------
 # fused BatchNorm / Dropout / residual / PReLU row kernel
 # ----------------------------------------------------------------------------------------------
-class _NormActFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, pre, add, gamma, beta, alpha, cfg):
-        _chk(x, "x")
-        dev = x.device
-        v = _view4(x)
-        B, C, P = v.n[0], v.n[1], v.n[2] * v.n[3]
-        y = torch.empty(x.shape, dtype=torch.float32, device=dev)
-        a = NormAct()
-        a.x, a.xv, a.y, a.yv = x.data_ptr(), v, y.data_ptr(), _view4(y)
-        if pre is not None:
-            if tuple(pre.shape) != (B, C) or not pre.is_contiguous():
-                raise ValueError("norm_act: gate must be a contiguous (B,C) tensor")
-            a.pre = pre.data_ptr()
-        if add is not None:
-            if add.shape != x.shape:
-                raise ValueError("norm_act: addend shape %s != %s" % (tuple(add.shape), tuple(x.shape)))
-            a.add, a.av = add.data_ptr(), _view4(add)
-        a.add_post = 1 if cfg.get("add_post") else 0
-        bn = cfg.get("bn")
-        save = None
-        if bn is not None:
-            train = cfg["train"]
-            a.bn_mode = 1 if train else 2
-            a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
-            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
-            a.momentum, a.eps = bn.momentum, bn.eps
-            save = torch.empty(2, C, dtype=torch.float32, device=dev)
-            a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
-            if train:
-                if B * P <= 1:
-                    raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
-                stats = cfg.get("stats")
-                if stats is None:
-                    stats = _arena(dev).take(2 * C)
-                    _lib.call("cg_chan_stats", _ptr(x), ctypes.byref(v), _ptr(pre), _ptr(stats), _stream(x))
-                a.stats = stats.data_ptr()
-        p = float(cfg.get("drop_p", 0.0)) if cfg.get("train") else 0.0
-        if p > 0.0:
-            a.drop_p, a.seed, a.salt = p, seed_state(dev).data_ptr(), cfg["salt"]
-        if alpha is not None:
-            a.alpha, a.alpha_n = alpha.data_ptr(), alpha.numel()
-        _lib.call("cg_norm_act_fwd", ctypes.byref(a), _stream(x))
-        ctx.cfg, ctx.p, ctx.mode = cfg, p, a.bn_mode
-        ctx.save_for_backward(x, pre, add, gamma, beta, alpha, save)
-        return y
+_ROW_BATCH = 6
+
+
+def _na_fill_fwd(a, x, pre, add, gamma, beta, alpha, cfg, pending_stats):
+    """Fill the forward part of a CgNormAct; returns (y, save).  Problems whose batch statistics are not yet
+    available are appended to `pending_stats` (reduced together by cg_chan_stats_many)."""
+    _chk(x, "x")
+    dev = x.device
+    v = _view4(x)
+    B, C, P = v.n[0], v.n[1], v.n[2] * v.n[3]
+    y = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    a.x, a.xv, a.y, a.yv = x.data_ptr(), v, y.data_ptr(), _view4(y)
+    if pre is not None:
+        if tuple(pre.shape) != (B, C) or not pre.is_contiguous():
+            raise ValueError("norm_act: gate must be a contiguous (B,C) tensor")
+        a.pre = pre.data_ptr()
+    if add is not None:
+        if add.shape != x.shape:
+            raise ValueError("norm_act: addend shape %s != %s" % (tuple(add.shape), tuple(x.shape)))
+        a.add, a.av = add.data_ptr(), _view4(add)
+    a.add_post = 1 if cfg.get("add_post") else 0
+    bn = cfg.get("bn")
+    save = None
+    if bn is not None:
+        train = cfg["train"]
+        a.bn_mode = 1 if train else 2
+        a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+        a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        a.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+        a.momentum, a.eps = bn.momentum, bn.eps
+        save = torch.empty(2, C, dtype=torch.float32, device=dev)
+        a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
+        if train:
+            if B * P <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            stats = cfg.get("stats")
+            if stats is None:
+                stats = _arena(dev).take(2 * C)
+                it = _lib.StatsArgs()
+                it.x, it.xv, it.pre, it.stats = x.data_ptr(), v, (pre.data_ptr() if pre is not None else None), stats.data_ptr()
+                pending_stats.append(it)
+            a.stats = stats.data_ptr()
+    p = float(cfg.get("drop_p", 0.0)) if cfg.get("train") else 0.0
+    if p > 0.0:
+        a.drop_p, a.seed, a.salt = p, seed_state(dev).data_ptr(), cfg["salt"]
+    if alpha is not None:
+        a.alpha, a.alpha_n = alpha.data_ptr(), alpha.numel()
+    return y, save, p
+
+
+class _NormActMany(torch.autograd.Function):
+    """Up to any number of independent fused BatchNorm/Dropout/residual/PReLU row problems; forward is one
+    statistics launch (only for inputs without precomputed sums) + one launch per 6 problems, backward one
+    reduction launch + one apply launch per 6 problems."""
 
     @staticmethod
-    def backward(ctx, dy):
-        x, pre, add, gamma, beta, alpha, save = ctx.saved_tensors
-        cfg, dev = ctx.cfg, x.device
-        v = _view4(x)
-        B, C = v.n[0], v.n[1]
-        a = NormAct()
-        a.x, a.xv = x.data_ptr(), v
-        if pre is not None:
-            a.pre = pre.data_ptr()
-        add_post = 1 if cfg.get("add_post") else 0
-        a.add_post = add_post
-        if add is not None:
-            a.add, a.av = add.data_ptr(), _view4(add)
-        a.bn_mode = ctx.mode
-        bn = cfg.get("bn")
-        if bn is not None:
-            a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
-            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            a.momentum, a.eps = bn.momentum, bn.eps
-            a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
-        if ctx.p > 0.0:
-            a.drop_p, a.seed, a.salt = ctx.p, seed_state(dev).data_ptr(), cfg["salt"]
-        nalpha = 0
-        if alpha is not None:
-            nalpha = alpha.numel()
-            a.alpha, a.alpha_n = alpha.data_ptr(), nalpha
-        a.dy, a.dyv = dy.data_ptr(), _view4(dy)
-        need = ctx.needs_input_grad
-        dx = dpre = dadd = dgamma = dbeta = dalpha = None
-        if need[0]:
-            dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
-            a.dx, a.dxv = dx.data_ptr(), _view4(dx)
-        if pre is not None and need[1]:
-            dpre = torch.empty(B, C, dtype=torch.float32, device=dev)
-            a.dpre = dpre.data_ptr()
-        if add is not None and need[2]:
-            if add_post:
-                dadd = dy
-            else:
-                dadd = torch.empty(add.shape, dtype=torch.float32, device=dev)
-                a.dadd, a.dav = dadd.data_ptr(), _view4(dadd)
-        need_reduce = 1 if (bn is not None or alpha is not None) else 0
-        if need_reduce:
-            a.red = _arena(dev).take(2 * C + nalpha).data_ptr()
+    def forward(ctx, cfgs, *ts):
+        n = len(cfgs)
+        six = [ts[6 * i:6 * i + 6] for i in range(n)]
+        arr = (NormAct * n)()
+        pending, ys, saves, ps = [], [], [], []
+        for i in range(n):
+            y, save, p = _na_fill_fwd(arr[i], *six[i], cfgs[i], pending)
+            ys.append(y); saves.append(save); ps.append(p)
+        stream = _stream(six[0][0])
+        for c0 in range(0, len(pending), _ROW_BATCH):
+            chunk = pending[c0:c0 + _ROW_BATCH]
+            _lib.call("cg_chan_stats_many", (_lib.StatsArgs * len(chunk))(*chunk), len(chunk), stream)
+        for c0 in range(0, n, _ROW_BATCH):
+            m = min(_ROW_BATCH, n - c0)
+            _lib.call("cg_norm_act_fwd_many", ctypes.cast(ctypes.byref(arr[c0]), ctypes.POINTER(NormAct)), m, stream)
+        ctx.cfgs, ctx.ps, ctx.modes = cfgs, ps, [arr[i].bn_mode for i in range(n)]
+        flat = []
+        for i in range(n):
+            flat += list(six[i]) + [saves[i]]
+        ctx.save_for_backward(*flat)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = len(ctx.cfgs)
+        saved = ctx.saved_tensors
+        arr = (NormAct * n)()
+        flags = (ctypes.c_int * n)()
+        grads = []
+        for i in range(n):
+            x, pre, add, gamma, beta, alpha, save = saved[7 * i:7 * i + 7]
+            cfg, dy, a = ctx.cfgs[i], dys[i], arr[i]
+            dev = x.device
+            v = _view4(x)
+            B, C = v.n[0], v.n[1]
+            a.x, a.xv = x.data_ptr(), v
+            if pre is not None:
+                a.pre = pre.data_ptr()
+            add_post = 1 if cfg.get("add_post") else 0
+            a.add_post = add_post
+            if add is not None:
+                a.add, a.av = add.data_ptr(), _view4(add)
+            a.bn_mode = ctx.modes[i]
+            bn = cfg.get("bn")
             if bn is not None:
-                g = torch.empty(2, C, dtype=torch.float32, device=dev)
-                dgamma, dbeta = g[0], g[1]
-                a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+                a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+                a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                a.momentum, a.eps = bn.momentum, bn.eps
+                a.save_mean, a.save_rstd = save[0].data_ptr(), save[1].data_ptr()
+            if ctx.ps[i] > 0.0:
+                a.drop_p, a.seed, a.salt = ctx.ps[i], seed_state(dev).data_ptr(), cfg["salt"]
+            nalpha = 0
             if alpha is not None:
-                dalpha = torch.empty(alpha.shape, dtype=torch.float32, device=dev)
-                a.dalpha = dalpha.data_ptr()
-        _lib.call("cg_norm_act_bwd", ctypes.byref(a), need_reduce, _stream(x))
-        return dx, dpre, dadd, dgamma, dbeta, dalpha, None
+                nalpha = alpha.numel()
+                a.alpha, a.alpha_n = alpha.data_ptr(), nalpha
+            a.dy, a.dyv = dy.data_ptr(), _view4(dy)
+            need = ctx.needs_input_grad[1 + 6 * i:7 + 6 * i]
+            dx = dpre = dadd = dgamma = dbeta = dalpha = None
+            if need[0]:
+                dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+                a.dx, a.dxv = dx.data_ptr(), _view4(dx)
+            if pre is not None and need[1]:
+                dpre = torch.empty(B, C, dtype=torch.float32, device=dev)
+                a.dpre = dpre.data_ptr()
+            if add is not None and need[2]:
+                if add_post:
+                    dadd = dy
+                else:
+                    dadd = torch.empty(add.shape, dtype=torch.float32, device=dev)
+                    a.dadd, a.dav = dadd.data_ptr(), _view4(dadd)
+            flags[i] = 1 if (bn is not None or alpha is not None) else 0
+            if flags[i]:
+                a.red = _arena(dev).take(2 * C + nalpha).data_ptr()
+                if bn is not None:
+                    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+                    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+                    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+                if alpha is not None:
+                    dalpha = torch.empty(alpha.shape, dtype=torch.float32, device=dev)
+                    a.dalpha = dalpha.data_ptr()
+            grads += [dx, dpre, dadd, dgamma, dbeta, dalpha]
+        stream = _stream(saved[0])
+        for c0 in range(0, n, _ROW_BATCH):
+            m = min(_ROW_BATCH, n - c0)
+            _lib.call("cg_norm_act_bwd_many", ctypes.cast(ctypes.byref(arr[c0]), ctypes.POINTER(NormAct)),
+                      ctypes.cast(ctypes.byref(flags, 4 * c0), ctypes.POINTER(ctypes.c_int)), m, stream)
+        return (None,) + tuple(grads)
+
+
+def _na_args(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None):
+    if isinstance(x, tuple):          # (tensor, channel sums) as returned by the contraction helpers
+        x, st = x
+        stats = st if st is not None else stats
+    cfg = {"bn": bn, "train": bool(train), "add_post": add_post, "drop_p": drop_p, "salt": salt, "stats": stats}
+    return cfg, (x, pre, add, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                 prelu.weight if prelu is not None else None)
+
+
+def norm_act_many(calls):
+    """calls: list of keyword dicts as accepted by `norm_act`; all problems run in shared launches."""
+    cfgs, flat = [], []
+    for kw in calls:
+        cfg, six = _na_args(**kw)
+        cfgs.append(cfg)
+        flat += list(six)
+    return list(_NormActMany.apply(tuple(cfgs), *flat))
 
 
 def norm_act(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None):
     """y = PReLU(Dropout(BN(x * pre)) [+ add]) [+ add];  every stage optional.
     `bn` is the parameter holder (an nn.BatchNorm*), `prelu` an nn.PReLU; `stats` are precomputed
-    f64 channel sums of x (the fused ST-GCN kernel emits them)."""
-    cfg = {"bn": bn, "train": bool(train), "add_post": add_post, "drop_p": drop_p, "salt": salt, "stats": stats}
-    gamma = bn.weight if bn is not None else None
-    beta = bn.bias if bn is not None else None
-    alpha = prelu.weight if prelu is not None else None
-    return _NormActFn.apply(x, pre, add, gamma, beta, alpha, cfg)
+    f64 channel sums of x (the contraction / fused ST-GCN kernels emit them)."""
+    return norm_act_many([dict(x=x, bn=bn, train=train, pre=pre, add=add, add_post=add_post, drop_p=drop_p, salt=salt,
+                               prelu=prelu, stats=stats)])[0]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -474,12 +638,17 @@ class _Cat(torch.autograd.Function):
         shape = list(ref.shape)
         shape[1] = sum(chans)
         y = torch.empty(shape, dtype=torch.float32, device=ref.device)
-        c0 = 0
+        c0, items = 0, []
         for t, bc, c in zip(ts, bcast, chans):
             dst = y.narrow(1, c0, c)
             src = t.view(t.shape[0], c, *([1] * (ref.dim() - 2))).expand_as(dst) if bc else t
-            _add_into(dst, src)
+            it = _lib.CopyItem()
+            it.y, it.yv, it.a, it.av = dst.data_ptr(), _view4(dst), src.data_ptr(), _view4(src)
+            items.append(it)
             c0 += c
+        for i0 in range(0, len(items), 4):      # all slices of the concatenation in one launch (four per launch)
+            chunk = items[i0:i0 + 4]
+            _lib.call("cg_copy_many", (_lib.CopyItem * len(chunk))(*chunk), len(chunk), _stream(y))
         ctx.bcast, ctx.chans = bcast, chans
         return y
 
@@ -559,14 +728,14 @@ class _DilatedConvs(torch.autograd.Function):
         pad = _DilatedConvs.PAD
         xp = _halo(x, pad)
         sB, sC, sH, sW = xp.stride()
-        outs = []
+        builders = []
         for i, d in enumerate(dils):
             w, b = wb[2 * i], wb[2 * i + 1]
             sizes = {"b": B, "c": C, "o": w.shape[0], "i": 3, "j": 3, "h": H, "w": W}
-            y = _contract_raw("ocij,bcijhw->bohw", w, xp, b, "o", sizes=sizes,
-                              sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW},
-                              ox=(pad - d) * (sH + sW))
-            outs.append(y)
+            builders.append(lambda out, w=w, b=b, d=d, sizes=sizes: _contract_prepare(
+                "ocij,bcijhw->bohw", w, xp, b, "o", sizes=sizes,
+                sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW}, ox=(pad - d) * (sH + sW), out=out))
+        outs = [r.y for r in _contract_launch(builders, x.device)]      # the three dilations in one launch
         ctx.dils, ctx.shape = dils, x.shape
         ctx.save_for_backward(xp, *wb[0::2])
         return tuple(outs)
@@ -577,26 +746,36 @@ class _DilatedConvs(torch.autograd.Function):
         B, C, H, W = ctx.shape
         pad = _DilatedConvs.PAD
         sB, sC, sH, sW = xp.stride()
-        grads, dxs = [], []
+        builders, slots = [], []
         for i, d in enumerate(ctx.dils):
             w, dy = ws[i], dys[i]
-            O = w.shape[0]
-            sizes = {"b": B, "c": C, "o": O, "i": 3, "j": 3, "h": H, "w": W}
-            dw = db = None
+            sizes = {"b": B, "c": C, "o": w.shape[0], "i": 3, "j": 3, "h": H, "w": W}
             if ctx.needs_input_grad[2 + 2 * i]:
-                dw = _contract_raw("bohw,bcijhw->ocij", dy, xp, sizes=sizes,
-                                   sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW},
-                                   ox=(pad - d) * (sH + sW))
+                builders.append(lambda out, dy=dy, d=d, sizes=sizes: _contract_prepare(
+                    "bohw,bcijhw->ocij", dy, xp, sizes=sizes,
+                    sx={"b": sB, "c": sC, "i": d * sH, "j": d * sW, "h": sH, "w": sW}, ox=(pad - d) * (sH + sW), out=out))
+                slots.append(("w", i))
             if ctx.needs_input_grad[3 + 2 * i]:
-                db = _sum_keep(dy, "bohw", "o")
+                builders.append(_sum_keep_builder(dy, "bohw", "o"))
+                slots.append(("b", i))
             if ctx.needs_input_grad[0]:
                 dyp = _halo(dy, pad)
                 tB, tO, tH, tW = dyp.stride()
                 # dx[b,c,h,w] = sum_{o,i,j} w[o,c,i,j] * dy[b,o,h-d(i-1),w-d(j-1)]
-                dxs.append(_contract_raw("ocij,boijhw->bchw", w, dyp, sizes=sizes,
-                                         sx={"b": tB, "o": tO, "i": -d * tH, "j": -d * tW, "h": tH, "w": tW},
-                                         ox=(pad + d) * (tH + tW)))
-            grads += [dw, db]
+                builders.append(lambda out, w=w, dyp=dyp, d=d, sizes=sizes, t=(tB, tO, tH, tW): _contract_prepare(
+                    "ocij,boijhw->bchw", w, dyp, sizes=sizes,
+                    sx={"b": t[0], "o": t[1], "i": -d * t[2], "j": -d * t[3], "h": t[2], "w": t[3]},
+                    ox=(pad + d) * (t[2] + t[3]), out=out))
+                slots.append(("x", i))
+        grads, dxs = [None] * (2 * len(ctx.dils)), []
+        if builders:
+            for (kind, i), r in zip(slots, _contract_launch(builders, xp.device)):    # all nine gradients in one launch
+                if kind == "w":
+                    grads[2 * i] = r.y
+                elif kind == "b":
+                    grads[2 * i + 1] = r.y
+                else:
+                    dxs.append(r.y)
         dx = None
         if dxs:
             dx = torch.empty(ctx.shape, dtype=torch.float32, device=xp.device)

@@ -48,10 +48,22 @@ int cg_contract(const float* A, const float* X, float* Y, const float* bias, dou
                 int G, int M, int N, int K, int splitk, int a_kfast, int x_kfast,
                 long long y_dense_numel, void* stream);
 
+/* Horizontal fusion: up to 16 independent contractions in ONE launch (same-depth maps of the parallel branches
+ * of a DSTD_GC block - gate s/t, the four Map2Adj towers, residual maps - and, in backward, every dA / dX / bias
+ * sum of such a stage).  Split-K outputs (splitk > 1) must be zero on entry. */
+typedef struct CgContractDesc {
+  const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
+  int G, M, N, K, splitk, kchunk /* set by the library */, a_kfast, x_kfast;
+  long long block0;              /* set by the library */
+} CgContractDesc;
+int cg_contract_many(const CgContractDesc* descs, int n, void* stream);
+
 /* ---- per-channel statistics and the fused BatchNorm / Dropout / PReLU row kernel ---------------
  * stats[c] = { sum, sum of squares } over batch and positions of x*pre (f64, must be zero on entry).
  * Replaces the reduction half of nn.BatchNorm{1,2}d in train mode. */
 int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream);
+typedef struct CgStatsArgs { const float* x; CgView4 xv; const float* pre; double* stats; } CgStatsArgs;
+int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream);   /* up to 6 tensors per launch */
 /* out[c] = sum over batch and positions (bias gradients of the convolutions). */
 int cg_chan_sum(const float* x, const CgView4* xv, float* out, void* stream);
 
@@ -84,6 +96,9 @@ typedef struct CgNormAct {
 } CgNormAct;
 int cg_norm_act_fwd(const CgNormAct* a, void* stream);
 int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream);
+/* the same for up to 6 independent row problems per launch (branches of one block at the same depth) */
+int cg_norm_act_fwd_many(const CgNormAct* arr, int n, void* stream);
+int cg_norm_act_bwd_many(const CgNormAct* arr, const int* need_reduce, int n, void* stream);
 
 /* per-(b,c) mean (kind 0), max with first arg-max (kind 1) or sum (kind 2) over the positions; adjoints of 0/1.
  * Replaces AdaptiveAvgPool (SE.py:8,27; CISTGCN.py:69,76), .max(-1)[0] chains and .mean((2,3))
@@ -96,6 +111,8 @@ int cg_reduce_bc_bwd(const float* dout, const int32_t* arg, int kind, float* dx,
  * x[:, -1:] + x8^T + act (:595-597). */
 int cg_add3(float* y, const CgView4* yv, const float* a, const CgView4* av, const float* b, const CgView4* bv,
             const float* c, const CgView4* cv, void* stream);
+typedef struct CgCopyItem { float* y; CgView4 yv; const float* a; CgView4 av; } CgCopyItem;
+int cg_copy_many(const CgCopyItem* items, int n, void* stream);   /* up to 4 strided copies (cat slices) per launch */
 int cg_zero(void* p, long long bytes, void* stream);
 
 /* ---- stage kernels --------------------------------------------------------------------------------

@@ -34,9 +34,11 @@ def test_model_matches_reference_golden(name, mode):
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
-def test_model_generic_contraction_path(mode):
-    # graph product + channel mix through the generic contraction instead of the fused kernel
-    checks.check_model_golden("cuda", "h36m_c8_t10_v22", modes=(mode,), fused=False)
+@pytest.mark.parametrize("fused,staged", [(False, True), (True, False), (False, False)], ids=["generic-domain", "one-launch-per-op", "both"])
+def test_model_alternative_launch_plans(mode, fused, staged):
+    # fused=False: graph product + channel mix through the generic contraction instead of the fused kernel;
+    # staged=False: one launch per op instead of one launch per stage of a block's parallel branches
+    checks.check_model_golden("cuda", "h36m_c8_t10_v22", modes=(mode,), fused=fused, staged=staged)
 
 
 @pytest.mark.parametrize("cfg", [(64, 10, 22, 8), (32, 50, 25, 4), (16, 10, 18, 6), (64, 50, 22, 4)], ids=str)
