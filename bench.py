@@ -82,28 +82,39 @@ def roofline_domain_kernel(B, C, T, V, device, reps=30):
     return tot_b, tot_t, per
 
 
-def cpu_baseline(C, B, T, V, dropout, budget_s=15.0):
-    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on
-    this box's host cores on the same workload: forward + MPJPE + backward."""
+def cpu_baseline(C, B, T, V, dropout, budget_s=16.0):
+    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on this
+    box's host cores on the same workload: forward + MPJPE + backward.  PyTorch's intra-op threading does not
+    scale on ~1.5 k tiny ops per step, so several thread counts are tried and the BEST one is reported."""
     from oracle import cistgcn_ref as O
     torch.manual_seed(0)
     net = O.CISTGCN(*make_cfg(C, T, V, dropout)).train()
     x, tgt = synth(B, T, V, 0)
+
     def step():
         net.zero_grad(set_to_none=True)
         pred, = net(x)
         O.mpjpe(pred, tgt).backward()
-    for _ in range(2):
+
+    ncpu = os.cpu_count() or 1
+    tried, best = [], None
+    counts = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    for nt in counts:
+        torch.set_num_threads(nt)
         step()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 50:
-            break
-    return {"value": B * n / el, "unit": "sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d fwd+bwd steps of %s-shaped batch (B=%d) in %.1f s, torch %s CPU" % (n, "workload", B, el, torch.__version__)}
+        n, t0 = 0, time.perf_counter()
+        while True:
+            step()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s / len(counts) or n >= 30:
+                break
+        rate = B * n / el
+        tried.append("%d thr: %.1f seq/s (%d steps, %.1f s)" % (nt, rate, n, el))
+        if best is None or rate > best[0]:
+            best = (rate, nt)
+    return {"value": best[0], "unit": "sequences/sec", "cores": best[1], "kind": "port",
+            "sample": "fwd+bwd steps of the bench workload (B=%d) on the host, torch %s CPU, best of: %s" % (B, torch.__version__, "; ".join(tried))}
 
 
 def main():
