@@ -82,10 +82,8 @@ def roofline_domain_kernel(B, C, T, V, device, reps=30):
     return tot_b, tot_t, per
 
 
-def cpu_baseline(C, B, T, V, dropout, budget_s=16.0):
-    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on this
-    box's host cores on the same workload: forward + MPJPE + backward.  PyTorch's intra-op threading does not
-    scale on ~1.5 k tiny ops per step, so several thread counts are tried and the BEST one is reported."""
+def cpu_baseline_worker(C, B, T, V, dropout, budget_s):
+    """Runs in a child process with OMP_NUM_THREADS fixed: times the CPU oracle, prints one JSON line."""
     from oracle import cistgcn_ref as O
     torch.manual_seed(0)
     net = O.CISTGCN(*make_cfg(C, T, V, dropout)).train()
@@ -96,28 +94,50 @@ def cpu_baseline(C, B, T, V, dropout, budget_s=16.0):
         pred, = net(x)
         O.mpjpe(pred, tgt).backward()
 
-    ncpu = os.cpu_count() or 1
-    tried, best = [], None
-    counts = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
-    for nt in counts:
-        torch.set_num_threads(nt)
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
         step()
-        n, t0 = 0, time.perf_counter()
-        while True:
-            step()
-            n += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s / len(counts) or n >= 30:
-                break
-        rate = B * n / el
-        tried.append("%d thr: %.1f seq/s (%d steps, %.1f s)" % (nt, rate, n, el))
-        if best is None or rate > best[0]:
-            best = (rate, nt)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 30:
+            break
+    print(json.dumps({"rate": B * n / el, "steps": n, "seconds": el, "threads": torch.get_num_threads()}))
+
+
+def cpu_baseline(C, B, T, V, dropout, budget_s=16.0):
+    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on this
+    box's host cores on the same workload: forward + MPJPE + backward.  PyTorch's intra-op threading does not
+    scale on ~1.5 k tiny ops per step, so several thread counts are tried (one child process each, OMP_NUM_THREADS
+    fixed) and the BEST one is reported."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    tried, best = [], None
+    for nt in counts:
+        env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt), HIP_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(C), str(B), str(T), str(V), str(dropout),
+               str(budget_s / len(counts))]
+        print("bench.py: cpu baseline with %d threads ..." % nt, file=sys.stderr, flush=True)
+        try:
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+            r = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as e:        # a failed trial must not take the GPU result down with it
+            tried.append("%d thr: failed (%s)" % (nt, type(e).__name__))
+            continue
+        tried.append("%d thr: %.1f seq/s (%d steps, %.1f s)" % (nt, r["rate"], r["steps"], r["seconds"]))
+        if best is None or r["rate"] > best[0]:
+            best = (r["rate"], nt)
+    if best is None:
+        return {"value": None, "unit": "sequences/sec", "cores": 0, "kind": "port", "sample": "; ".join(tried)}
     return {"value": best[0], "unit": "sequences/sec", "cores": best[1], "kind": "port",
             "sample": "fwd+bwd steps of the bench workload (B=%d) on the host, torch %s CPU, best of: %s" % (B, torch.__version__, "; ".join(tried))}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+        C, B, T, V = [int(v) for v in sys.argv[2:6]]
+        return cpu_baseline_worker(C, B, T, V, float(sys.argv[6]), float(sys.argv[7]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)

@@ -25,6 +25,7 @@
 struct CgContractDesc {
   const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
   int G, M, N, K, splitk, kchunk, a_kfast, x_kfast;
+  int accumulate, pad;       // accumulate = 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
   long long block0;          // first block id of this problem inside the launch
 };
 #define CG_MAX_BATCH 16
@@ -38,6 +39,7 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   const float* __restrict__ bias = d.bias; double* __restrict__ stats = d.stats;
   const int G = d.G, M = d.M, N = d.N, K = d.K, splitk = d.splitk, kchunk = d.kchunk;
   const int a_kfast = d.a_kfast, x_kfast = d.x_kfast;
+  const bool atomic_out = splitk > 1 || d.accumulate != 0;
   const int32_t* gA = d.tab;
   const int32_t* gX = gA + G;
   const int32_t* gY = gX + G;
@@ -152,7 +154,7 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
       const int n = n0 + tx + 16 * j;
       if (n >= N) continue;
       const float v = acc[i][j] + bv;
-      if (splitk > 1) atomicAdd(&Y[rowY + nY[n]], v);
+      if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
       else Y[rowY + nY[n]] = v;
       s += (double)v; q += (double)v * (double)v;
     }
@@ -198,7 +200,7 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
     CgContractDesc d = descs[i];
     if (!d.A || !d.X || !d.Y || !d.tab) return CG_EARG;
     if (d.G <= 0 || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.splitk <= 0) return CG_ESHAPE;
-    if (d.stats && d.splitk > 1) return CG_EARG;
+    if (d.stats && (d.splitk > 1 || d.accumulate)) return CG_EARG;
     d.block0 = total;
     total += cg_contract_blocks(d);
     batch.d[i] = d;
@@ -223,6 +225,6 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
-  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.block0 = 0;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.pad = 0; d.block0 = 0;
   return cg_contract_many(&d, 1, stream_);
 }

@@ -147,6 +147,7 @@ struct CgNormAct {
   float* dpre;                  // (B,C) or null
   double* red;                  // [C][2] sum g, sum g*xhat  (+ alpha_n slots behind it for d alpha)
   float* dgamma; float* dbeta; float* dalpha;
+  double* ystats;               // forward, optional: [C][2] f64 sums of y (zero on entry) for the BatchNorm that consumes y
 };
 
 // u = (v - mean) * scale + shift, scale = gamma * rstd, shift = beta: the mean is subtracted FIRST (as
@@ -198,6 +199,8 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   const CgChanAffine af = cg_chan_affine(a, c, false);
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
+  __shared__ double red[32];
+  double ys = 0.0, yq = 0.0;
   CG_CHUNK_LOOP(nb, P, e) {
     CG_CHUNK_ROW(e, P, b0)
     CG_POS(a.xv, p)
@@ -209,6 +212,12 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
     if (a.alpha) u = u > 0.f ? u : alpha * u;
     if (a.add && a.add_post) u += ad;
     a.y[cg_row_base(a.yv, b, c) + CG_OFF(a.yv)] = u;
+    ys += (double)u; yq += (double)u * (double)u;
+  }
+  if (a.ystats) {      // uniform per problem: every thread of the workgroup takes this branch
+    ys = cg_block_sum(ys, red);
+    yq = cg_block_sum(yq, red + 16);
+    if (threadIdx.x == 0) { atomicAdd(&a.ystats[2 * c], ys); atomicAdd(&a.ystats[2 * c + 1], yq); }
   }
 }
 

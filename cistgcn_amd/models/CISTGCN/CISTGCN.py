@@ -456,7 +456,8 @@ class CISTGCN(nn.Module):
         c = m.compressor
         h = self._na(self._lin(_pointwise, ops.cat_channels(ab), c[0]), bn=c[1], prelu=c[2])
         gate = ops.se_gate(ops.mean_bc(h), c[3].w1, c[3].w2)
-        return self._na(h, pre=gate, add=bres, add_post=True)
+        # the next block starts with a BatchNorm of this output: let the kernel emit its channel sums (train mode)
+        return self._na(h, pre=gate, add=bres, add_post=True, emit_stats=tr)
 
     # ---- FPN.forward, CISTGCN.py:74-79 -------------------------------------------------------------
     def _fpn(self, m, x):
@@ -503,6 +504,7 @@ class CISTGCN(nn.Module):
         block = self._block_staged if self.staged else self._block
         for blk in self.st_gcnns:
             h = block(blk, h)
+        h = h[0] if isinstance(h, tuple) else h                          # (tensor, channel sums) from a staged block
         h = h.permute(0, 2, 1, 3)                                       # NCTV -> NTCV (view)
         z = self._na(self._fpn(self.txcnns[0], h), prelu=self.prelus[0])
         for i in range(1, self.n_txcnn_layers):
@@ -515,6 +517,6 @@ class CISTGCN(nn.Module):
             x8 = x7.permute(0, 3, 2, 1)                                 # (B,3,V,T_out) view
             for blk in self.st_gcnns_o:
                 x8 = block(blk, x8)
-            return x8
+            return x8[0] if isinstance(x8, tuple) else x8
         act, x8 = self._parallel([lambda: self._context(self.context_layer, x7), output_blocks], [x7])
         return ops.add3(x[:, -1:], x8.permute(0, 3, 2, 1), act),

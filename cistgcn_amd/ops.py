@@ -219,22 +219,34 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
 _MAX_CONTRACT_BATCH = 16
 
 
-def _contract_launch(builders, device):
-    """builders: callables out -> _Prep (out = pre-zeroed flat buffer for a split-K result, else None).
-    Runs all contractions in as few launches as possible; split-K outputs share ONE zeroed buffer."""
-    # first pass decides which problems need a zeroed output (plan lookup is cached, so this is cheap)
-    probe = [b(None) for b in builders]
-    need = [i for i, r in enumerate(probe) if r.zero]
-    if need:
-        sizes = [probe[i].y.numel() for i in need]
-        zbuf = torch.empty(sum((n + 3) & ~3 for n in sizes), dtype=torch.float32, device=device)
-        _lib.call("cg_zero", _ptr(zbuf), zbuf.numel() * 4, _stream(zbuf))
-        off = 0
-        for i, n in zip(need, sizes):
-            stale = probe[i]
-            probe[i] = builders[i](zbuf[off:off + n])
-            probe[i].stats = stale.stats
-            off += (n + 3) & ~3
+def _contract_launch(builders, device, groups=None):
+    """builders: callables out -> _Prep (out = pre-zeroed flat buffer the result must be written into, or None).
+    Runs all contractions in as few launches as possible.  Split-K outputs are carved from ONE zeroed buffer;
+    `groups[i]` (optional) names an accumulation group: all members add (fp32 atomics) into one shared zeroed output."""
+    probe = [b(None) for b in builders]            # plan lookup is cached, so probing is cheap
+    groups = groups or [None] * len(builders)
+    slots, order = {}, []                          # slot key -> numel
+    for i, r in enumerate(probe):
+        key = ("g", groups[i]) if groups[i] is not None else (("s", i) if r.zero else None)
+        if key is not None and key not in slots:
+            slots[key] = r.y.numel()
+            order.append(key)
+    if order:
+        offs, total = {}, 0
+        for key in order:
+            offs[key] = total
+            total += (slots[key] + 3) & ~3
+        zbuf = torch.empty(total, dtype=torch.float32, device=device)
+        _lib.call("cg_zero", _ptr(zbuf), total * 4, _stream(zbuf))
+        for i, r in enumerate(probe):
+            key = ("g", groups[i]) if groups[i] is not None else (("s", i) if r.zero else None)
+            if key is None:
+                continue
+            stats = r.stats
+            probe[i] = builders[i](zbuf[offs[key]:offs[key] + slots[key]])
+            probe[i].stats = stats
+            if groups[i] is not None:
+                probe[i].desc.accumulate = 1
     for c0 in range(0, len(probe), _MAX_CONTRACT_BATCH):
         chunk = probe[c0:c0 + _MAX_CONTRACT_BATCH]
         arr = (_lib.ContractDesc * len(chunk))(*[r.desc for r in chunk])
@@ -297,23 +309,34 @@ class _ContractMany(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         saved = ctx.saved_tensors
-        builders, slots = [], []
+        builders, slots, groups = [], [], []
+        shared = {}      # inputs that feed several problems of the stage: their gradients accumulate in one buffer
+        for i in range(len(ctx.metas)):
+            x = saved[2 * i + 1]
+            if ctx.needs_input_grad[2 + 3 * i]:
+                shared.setdefault((x.data_ptr(), tuple(x.shape), tuple(x.stride())), []).append(i)
         for i, (spec, bias_label, _) in enumerate(ctx.metas):
             a, x, dy = saved[2 * i], saved[2 * i + 1], grads[2 * i]
             ins, ly = spec.split("->")
             la, lx = ins.split(",")
             if ctx.needs_input_grad[1 + 3 * i]:
                 builders.append(lambda out, s="%s,%s->%s" % (ly, lx, la), dy=dy, x=x: _contract_prepare(s, dy, x, out=out))
-                slots.append(3 * i)
+                slots.append(3 * i); groups.append(None)
             if ctx.needs_input_grad[2 + 3 * i]:
+                key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
                 builders.append(lambda out, s="%s,%s->%s" % (la, ly, lx), a=a, dy=dy: _contract_prepare(s, a, dy, out=out))
-                slots.append(3 * i + 1)
+                slots.append(3 * i + 1); groups.append(key if len(shared[key]) > 1 else None)
             if ctx.needs_input_grad[3 + 3 * i]:
                 builders.append(_sum_keep_builder(dy, ly, bias_label))
-                slots.append(3 * i + 2)
+                slots.append(3 * i + 2); groups.append(None)
         res = [None] * (3 * len(ctx.metas))
         if builders:
-            for slot, r in zip(slots, _contract_launch(builders, grads[0].device)):
+            seen = set()
+            for slot, grp, r in zip(slots, groups, _contract_launch(builders, grads[0].device, groups)):
+                if grp is not None:
+                    if grp in seen:
+                        continue          # the shared buffer already holds the sum; hand it to autograd once
+                    seen.add(grp)
                 res[slot] = r.y
         return (None,) + tuple(res)
 
@@ -417,7 +440,11 @@ def _na_fill_fwd(a, x, pre, add, gamma, beta, alpha, cfg, pending_stats):
         a.drop_p, a.seed, a.salt = p, seed_state(dev).data_ptr(), cfg["salt"]
     if alpha is not None:
         a.alpha, a.alpha_n = alpha.data_ptr(), alpha.numel()
-    return y, save, p
+    emitted = None
+    if cfg.get("emit_stats"):
+        emitted = _arena(dev).take(2 * C)
+        a.ystats = emitted.data_ptr()
+    return y, save, p, emitted
 
 
 class _NormActMany(torch.autograd.Function):
@@ -430,10 +457,10 @@ class _NormActMany(torch.autograd.Function):
         n = len(cfgs)
         six = [ts[6 * i:6 * i + 6] for i in range(n)]
         arr = (NormAct * n)()
-        pending, ys, saves, ps = [], [], [], []
+        pending, ys, saves, ps, emitted = [], [], [], [], []
         for i in range(n):
-            y, save, p = _na_fill_fwd(arr[i], *six[i], cfgs[i], pending)
-            ys.append(y); saves.append(save); ps.append(p)
+            y, save, p, em = _na_fill_fwd(arr[i], *six[i], cfgs[i], pending)
+            ys.append(y); saves.append(save); ps.append(p); emitted.append(em)
         stream = _stream(six[0][0])
         for c0 in range(0, len(pending), _ROW_BATCH):
             chunk = pending[c0:c0 + _ROW_BATCH]
@@ -446,7 +473,10 @@ class _NormActMany(torch.autograd.Function):
         for i in range(n):
             flat += list(six[i]) + [saves[i]]
         ctx.save_for_backward(*flat)
-        return tuple(ys)
+        for em in emitted:
+            if em is not None:
+                ctx.mark_non_differentiable(em)
+        return tuple(ys) + tuple(emitted)
 
     @staticmethod
     def backward(ctx, *dys):
@@ -515,11 +545,13 @@ class _NormActMany(torch.autograd.Function):
         return (None,) + tuple(grads)
 
 
-def _na_args(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None):
+def _na_args(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None,
+             emit_stats=False):
     if isinstance(x, tuple):          # (tensor, channel sums) as returned by the contraction helpers
         x, st = x
         stats = st if st is not None else stats
-    cfg = {"bn": bn, "train": bool(train), "add_post": add_post, "drop_p": drop_p, "salt": salt, "stats": stats}
+    cfg = {"bn": bn, "train": bool(train), "add_post": add_post, "drop_p": drop_p, "salt": salt, "stats": stats,
+           "emit_stats": bool(emit_stats)}
     return cfg, (x, pre, add, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
                  prelu.weight if prelu is not None else None)
 
@@ -531,15 +563,19 @@ def norm_act_many(calls):
         cfg, six = _na_args(**kw)
         cfgs.append(cfg)
         flat += list(six)
-    return list(_NormActMany.apply(tuple(cfgs), *flat))
+    out = _NormActMany.apply(tuple(cfgs), *flat)
+    n = len(cfgs)
+    return [(out[i], out[n + i]) if cfgs[i]["emit_stats"] else out[i] for i in range(n)]
 
 
-def norm_act(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None):
+def norm_act(x, bn=None, train=False, pre=None, add=None, add_post=False, drop_p=0.0, salt=0, prelu=None, stats=None,
+             emit_stats=False):
     """y = PReLU(Dropout(BN(x * pre)) [+ add]) [+ add];  every stage optional.
     `bn` is the parameter holder (an nn.BatchNorm*), `prelu` an nn.PReLU; `stats` are precomputed
-    f64 channel sums of x (the contraction / fused ST-GCN kernels emit them)."""
+    f64 channel sums of x (the contraction / fused ST-GCN kernels emit them); `emit_stats` returns
+    (y, f64 channel sums of y) for a BatchNorm that consumes y next."""
     return norm_act_many([dict(x=x, bn=bn, train=train, pre=pre, add=add, add_post=add_post, drop_p=drop_p, salt=salt,
-                               prelu=prelu, stats=stats)])[0]
+                               prelu=prelu, stats=stats, emit_stats=emit_stats)])[0]
 
 
 # ----------------------------------------------------------------------------------------------

@@ -50,10 +50,12 @@ int cg_contract(const float* A, const float* X, float* Y, const float* bias, dou
 
 /* Horizontal fusion: up to 16 independent contractions in ONE launch (same-depth maps of the parallel branches
  * of a DSTD_GC block - gate s/t, the four Map2Adj towers, residual maps - and, in backward, every dA / dX / bias
- * sum of such a stage).  Split-K outputs (splitk > 1) must be zero on entry. */
+ * sum of such a stage).  Split-K and accumulate outputs must be zero on entry (input gradients of maps that
+ * share one input are accumulated into ONE buffer instead of being summed by extra kernels). */
 typedef struct CgContractDesc {
   const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
   int G, M, N, K, splitk, kchunk /* set by the library */, a_kfast, x_kfast;
+  int accumulate, pad;           /* accumulate = 1: fp32 atomic adds into a zeroed Y shared by several problems */
   long long block0;              /* set by the library */
 } CgContractDesc;
 int cg_contract_many(const CgContractDesc* descs, int n, void* stream);
@@ -93,6 +95,7 @@ typedef struct CgNormAct {
   float* dpre;
   double* red;                   /* [2C + alpha_n] f64 scratch, zero on entry */
   float* dgamma; float* dbeta; float* dalpha;
+  double* ystats;                /* forward, optional: [C][2] f64 sums of y (zero on entry) for the BatchNorm consuming y */
 } CgNormAct;
 int cg_norm_act_fwd(const CgNormAct* a, void* stream);
 int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream);

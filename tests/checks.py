@@ -170,6 +170,65 @@ def check_norm_act(device):
         pass
 
 
+def check_batched_ops(device):
+    """Horizontal fusion: several contractions / row problems per launch give the same numbers as one by one,
+    shared-input gradients are accumulated in the kernel, channel sums come out of the epilogues."""
+    g = _gen(11)
+    x = _rand(g, 3, 10, 5, 7)
+    ws = [_rand(g, 8, 10), _rand(g, 4, 10, 5), _rand(g, 6, 10), _rand(g, 9, 12)]
+    bias, z = _rand(g, 6), _rand(g, 3, 12)
+    specs = ["oc,bchw->bohw", "och,bchw->bow", "oc,bchw->bohw", "oi,bi->bo"]
+
+    def run(dev, batched):
+        xs, zs, bs = _leaf(x, dev), _leaf(z, dev), _leaf(bias, dev)
+        wl = [_leaf(w, dev) for w in ws]
+        if batched:
+            ops.begin_step(dev)
+            outs = ops.contract_many([(specs[0], wl[0], xs, None, None, "o"), (specs[1], wl[1], xs, None, None, None),
+                                      (specs[2], wl[2], xs, bs, "o", None), (specs[3], wl[3], zs, None, None, "o")])
+            ys, sts = [o[0] for o in outs], [o[1] for o in outs]
+        else:
+            ys = [torch.einsum(specs[0], wl[0], xs), torch.einsum(specs[1], wl[1], xs),
+                  torch.einsum(specs[2], wl[2], xs) + bs.view(1, -1, 1, 1), torch.einsum(specs[3], wl[3], zs)]
+            sts = None
+        gy = [_rand(_gen(50 + i), *y.shape).to(dev) for i, y in enumerate(ys)]
+        torch.autograd.backward(ys, gy)
+        return ys, sts, [xs.grad, zs.grad, bs.grad] + [w.grad for w in wl]
+
+    ys, sts, gr = run(device, True)
+    yr, _, grr = run("cpu", False)
+    for i, (a, b) in enumerate(zip(ys, yr)):
+        assert_close(a, b, "contract_many y%d" % i, rel=2e-5)
+    for i, (a, b) in enumerate(zip(gr, grr)):
+        assert_close(a, b, "contract_many grad%d" % i, rel=2e-5, floor=float(b.abs().max()))
+    y0 = yr[0].detach().double()
+    assert_close(sts[0].cpu(), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "epilogue sums", rel=1e-6)
+    assert sts[1] is None and sts[2] is None
+    # row problems of different shapes in one launch, one of them emitting the sums of its output
+    shapes = [(4, 6, 5, 7), (4, 3, 1, 9), (6, 5)]
+    xs = [_rand(g, *sh, scale=2.0) + 0.5 for sh in shapes]
+    bns_ref = [nn.BatchNorm2d(6), nn.BatchNorm2d(3), nn.BatchNorm1d(5)]
+    bns_dev = [type(b)(b.num_features).to(device) for b in bns_ref]
+    prs_ref = [nn.PReLU(), None, nn.PReLU(5)]
+    prs_dev = [None if p is None else type(p)(p.num_parameters).to(device) for p in prs_ref]
+    xd = [_leaf(t, device) for t in xs]
+    xr = [_leaf(t, "cpu") for t in xs]
+    ops.begin_step(device)
+    outs = ops.norm_act_many([dict(x=xd[i], bn=bns_dev[i], train=True, prelu=prs_dev[i], emit_stats=(i == 0)) for i in range(3)])
+    yd = [outs[0][0], outs[1], outs[2]]
+    yr = [(prs_ref[i](bns_ref[i](xr[i])) if prs_ref[i] is not None else bns_ref[i](xr[i])) for i in range(3)]
+    gy = [_rand(_gen(70 + i), *sh) for i, sh in enumerate(shapes)]
+    torch.autograd.backward(yd, [t.to(device) for t in gy])
+    torch.autograd.backward(yr, gy)
+    for i in range(3):
+        assert_close(yd[i], yr[i], "norm_act_many y%d" % i, rel=2e-5)
+        assert_close(xd[i].grad, xr[i].grad, "norm_act_many dx%d" % i, rel=2e-5, floor=float(xr[i].grad.abs().max()))
+        assert_close(bns_dev[i].weight.grad, bns_ref[i].weight.grad, "norm_act_many dgamma%d" % i, rel=2e-5, floor=1e-3)
+        assert_close(bns_dev[i].running_var, bns_ref[i].running_var, "norm_act_many running_var%d" % i, rel=2e-5)
+    y0 = yr[0].detach().double()
+    assert_close(outs[0][1].cpu(), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "emitted sums", rel=1e-6)
+
+
 def check_dropout(device):
     """Dropout cannot match the CPU RNG stream; check rate, scale and fwd/bwd mask agreement."""
     p = 0.3
