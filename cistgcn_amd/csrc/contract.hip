@@ -5,8 +5,9 @@
 // gradients is an instance of this form once each logical index (g, m, n, k) is allowed to be a
 // composite of tensor axes.  The host flattens the composites into int32 element-offset tables,
 // so the kernel is layout-agnostic: NCTV / NTCV / (N,3,V,T) views, zero-padded halos and dilation
-// all reduce to table contents.  fp32 FMA on the VALU; 64x64 (or 16x64) output tile per 256-thread
-// workgroup, K staged through LDS in steps of 16, optional split-K with fp32 atomics.
+// all reduce to table contents.  64x64 output tile per 256-thread workgroup on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact f32), or 16x64 on the VALU for thin outputs; K staged through LDS in
+// steps of 16, optional split-K with fp32 atomics.
 //
 // This is the scaffold kernel: the hot ST-GCN stage has its own fused kernel (stgcn_domain.hip).
 #include "cg_common.h"
@@ -31,6 +32,11 @@ struct CgContractDesc {
 #define CG_MAX_BATCH 16
 struct CgContractBatch { int n; int pad; CgContractDesc d[CG_MAX_BATCH]; };
 
+// fp32-input MFMA (v_mfma_f32_16x16x4_f32): exact f32 fma chain in k order, one A and one B value per lane
+// (A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]); D: col = lane & 15, row = 4 * (lane >> 4) + reg.
+typedef float cg_f32x4 __attribute__((vector_size(16)));
+#define CG_LDT 80   // LDS row stride of the 64-wide tiles: 80 mod 32 = 16 keeps the four k-rows of a fragment read on distinct banks
+
 template <int BM, int TM>
 __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long long bid, float* As_, float* Xs_,
                                                  int32_t* sKA, int32_t* sKX, double* sStat_) {
@@ -50,8 +56,10 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   const int32_t* nY = nX + N;
   const int32_t* kA = nY + N;
   const int32_t* kX = kA + K;
-  float (*As)[BM + 1] = reinterpret_cast<float (*)[BM + 1]>(As_);
-  float (*Xs)[BN + 1] = reinterpret_cast<float (*)[BN + 1]>(Xs_);
+  constexpr int LDA = BM == 64 ? CG_LDT : BM + 1;
+  constexpr int LDB = BM == 64 ? CG_LDT : BN + 1;
+  float (*As)[LDA] = reinterpret_cast<float (*)[LDA]>(As_);
+  float (*Xs)[LDB] = reinterpret_cast<float (*)[LDB]>(Xs_);
   double (*sStat)[2] = reinterpret_cast<double (*)[2]>(sStat_);
 
   const int tiles_n = (N + BN - 1) / BN;
@@ -94,12 +102,6 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   }
   __syncthreads();   // k tables visible
 
-  float acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
-
   float ra[A_PER], rx[X_PER];
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -117,48 +119,107 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
       rx[r] = v;
     }
   };
-
-  fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += CG_BK) {
+  auto stage = [&]() {
 #pragma unroll
     for (int r = 0; r < A_PER; ++r) As[a_kk[r]][a_mm[r]] = ra[r];
 #pragma unroll
     for (int r = 0; r < X_PER; ++r) Xs[x_kk[r]][x_nn[r]] = rx[r];
-    __syncthreads();
-    if (k0 + CG_BK < kend) fetch(k0 + CG_BK);      // in flight while the FMAs below run
-#pragma unroll
-    for (int kk = 0; kk < CG_BK; ++kk) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Xs[kk][tx + 16 * j];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-
+  };
   const long long baseY = gY[g];
+
+  if constexpr (BM == 64) {
+    // ---- matrix-core path: each wave owns a 32x32 quadrant of the 64x64 tile = 2x2 MFMA tiles of 16x16 ----
+    const int lane = tid & 63, wv = tid >> 6;
+    const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    cg_f32x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + ty + 16 * i;
-    if (m >= M) continue;
-    const float bv = (bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
-    const long long rowY = baseY + mY[m];
-    double s = 0.0, q = 0.0;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + tx + 16 * j;
-      if (n >= N) continue;
-      const float v = acc[i][j] + bv;
-      if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
-      else Y[rowY + nY[n]] = v;
-      s += (double)v; q += (double)v * (double)v;
+      for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += CG_BK) {
+      stage();
+      __syncthreads();
+      if (k0 + CG_BK < kend) fetch(k0 + CG_BK);      // in flight while the MFMAs below run
+#pragma unroll
+      for (int ks = 0; ks < CG_BK / 4; ++ks) {
+        const int k = 4 * ks + l4;
+        const float a0 = As[k][wm + l15], a1 = As[k][wm + 16 + l15];
+        const float b0 = Xs[k][wn + l15], b1 = Xs[k][wn + 16 + l15];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      __syncthreads();
     }
-    if (stats != nullptr) { atomicAdd(&sStat[ty + 16 * i][0], s); atomicAdd(&sStat[ty + 16 * i][1], q); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mt = wm + 16 * i + 4 * l4 + r;          // row inside the tile
+        const int m = m0 + mt;
+        if (m >= M) continue;
+        const float bv = (bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
+        const long long rowY = baseY + mY[m];
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn + 16 * j + l15;
+          if (n >= N) continue;
+          const float v = acc[i][j][r] + bv;
+          if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
+          else Y[rowY + nY[n]] = v;
+          s += (double)v; q += (double)v * (double)v;
+        }
+        if (stats != nullptr) { atomicAdd(&sStat[mt][0], s); atomicAdd(&sStat[mt][1], q); }
+      }
+    }
+  } else {
+    // ---- VALU path for thin outputs (M <= 16): one row x four columns per thread ----
+    float acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += CG_BK) {
+      stage();
+      __syncthreads();
+      if (k0 + CG_BK < kend) fetch(k0 + CG_BK);      // in flight while the FMAs below run
+#pragma unroll
+      for (int kk = 0; kk < CG_BK; ++kk) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Xs[kk][tx + 16 * j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + ty + 16 * i;
+      if (m >= M) continue;
+      const float bv = (bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
+      const long long rowY = baseY + mY[m];
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + tx + 16 * j;
+        if (n >= N) continue;
+        const float v = acc[i][j] + bv;
+        if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
+        else Y[rowY + nY[n]] = v;
+        s += (double)v; q += (double)v * (double)v;
+      }
+      if (stats != nullptr) { atomicAdd(&sStat[ty + 16 * i][0], s); atomicAdd(&sStat[ty + 16 * i][1], q); }
+    }
   }
   if (stats != nullptr) {           // channel of row m = mB[m] (the bias / statistics index)
     __syncthreads();
@@ -167,8 +228,8 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 }
 
 __global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch batch) {
-  __shared__ float As[CG_BK * 65];
-  __shared__ float Xs[CG_BK * 65];
+  __shared__ float As[CG_BK * CG_LDT];
+  __shared__ float Xs[CG_BK * CG_LDT];
   __shared__ int32_t sKA[CG_KT];
   __shared__ int32_t sKX[CG_KT];
   __shared__ double sStat[64 * 2];

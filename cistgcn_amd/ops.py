@@ -170,7 +170,7 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
     p.dense = y_dense
     if y_dense and p.K >= 256 and blocks < 512:
         # few output tiles and a long reduction (weight / bias gradients): spread K over workgroups
-        p.splitk = int(max(1, min((p.K + 127) // 128, (1024 + blocks - 1) // blocks)))
+        p.splitk = int(max(1, min((p.K + 63) // 64, (1024 + blocks - 1) // blocks)))
     _plans[key] = p
     return p
 
@@ -292,6 +292,7 @@ class _ContractMany(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, metas, *ts):
+        ctx.set_materialize_grads(False)      # the channel-sum outputs never receive a gradient: do not zero-fill one
         n = len(metas)
         trip = [ts[3 * i:3 * i + 3] for i in range(n)]
         builders = [(lambda out, m=m, t=t: _contract_prepare(m[0], t[0], t[1], t[2], m[1], stats_label=m[2], out=out))
@@ -313,10 +314,13 @@ class _ContractMany(torch.autograd.Function):
         shared = {}      # inputs that feed several problems of the stage: their gradients accumulate in one buffer
         for i in range(len(ctx.metas)):
             x = saved[2 * i + 1]
-            if ctx.needs_input_grad[2 + 3 * i]:
+            if ctx.needs_input_grad[2 + 3 * i] and grads[2 * i] is not None:
                 shared.setdefault((x.data_ptr(), tuple(x.shape), tuple(x.stride())), []).append(i)
+        dev = saved[0].device
         for i, (spec, bias_label, _) in enumerate(ctx.metas):
             a, x, dy = saved[2 * i], saved[2 * i + 1], grads[2 * i]
+            if dy is None:                    # this output was not used downstream
+                continue
             ins, ly = spec.split("->")
             la, lx = ins.split(",")
             if ctx.needs_input_grad[1 + 3 * i]:
@@ -332,7 +336,7 @@ class _ContractMany(torch.autograd.Function):
         res = [None] * (3 * len(ctx.metas))
         if builders:
             seen = set()
-            for slot, grp, r in zip(slots, groups, _contract_launch(builders, grads[0].device, groups)):
+            for slot, grp, r in zip(slots, groups, _contract_launch(builders, dev, groups)):
                 if grp is not None:
                     if grp in seen:
                         continue          # the shared buffer already holds the sum; hand it to autograd once
@@ -454,6 +458,7 @@ class _NormActMany(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfgs, *ts):
+        ctx.set_materialize_grads(False)      # emitted channel sums never receive a gradient
         n = len(cfgs)
         six = [ts[6 * i:6 * i + 6] for i in range(n)]
         arr = (NormAct * n)()
@@ -485,6 +490,9 @@ class _NormActMany(torch.autograd.Function):
         arr = (NormAct * n)()
         flags = (ctypes.c_int * n)()
         grads = []
+        live = [i for i in range(n) if dys[i] is not None]
+        if len(live) != n:
+            raise RuntimeError("norm_act_many: an output was not used in the loss; call the problems separately")
         for i in range(n):
             x, pre, add, gamma, beta, alpha, save = saved[7 * i:7 * i + 7]
             cfg, dy, a = ctx.cfgs[i], dys[i], arr[i]
@@ -940,6 +948,7 @@ def mpjpe(pred, target):
 class _StgcnDomain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, adj, w, bias, domain, want_stats):
+        ctx.set_materialize_grads(False)
         if not (x.is_contiguous() and adj.is_contiguous() and w.is_contiguous()):
             raise ValueError("stgcn_domain expects contiguous x (B,C,T,V), Adj and W")
         B, Cin, T, V = x.shape

@@ -62,6 +62,29 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return r;
 }
 
+// v_mfma_f32_16x16x4_f32 on one "wave": every lane contributes A[i = lane & 15][k = lane >> 4] and
+// B[k = lane >> 4][j = lane & 15]; lane receives D[row = 4 * (lane >> 4) + reg][col = lane & 15].
+typedef float hipemu_f32x4 __attribute__((vector_size(16)));
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+  const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64;
+  float* slot = reinterpret_cast<float*>(hipemu::wave_slot(wave, lane));
+  slot[0] = a; slot[1] = b;
+  hipemu::wave_barrier(wave);
+  const int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * (lane >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) {
+      const float av = reinterpret_cast<float*>(hipemu::wave_slot(wave, row + 16 * k))[0];
+      const float bv = reinterpret_cast<float*>(hipemu::wave_slot(wave, col + 16 * k))[1];
+      acc = fmaf(av, bv, acc);
+    }
+    c[r] = acc;
+  }
+  hipemu::wave_barrier(wave);
+  return c;
+}
+
 template <typename T>
 static inline T hipemu_atomic_add_fp(T* p, T v) {
   using U = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;

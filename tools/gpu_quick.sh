@@ -6,5 +6,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/py
 grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2
 grep -E "^E  " gpurun_out/pytest_gpu.log | cut -c1-250 | head -10
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log
-timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>&1 | grep -E "metric|NaN|Error" | cut -c1-900
-timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload cistgcn64_b256_t50_v22 2>&1 | grep -E "metric|NaN|Error" | cut -c1-500
+timeout -k 10 400 python bench.py --steps 50 --warmup 10 > gpurun_out/bench_default.log 2>&1; echo "bench rc=$?"; grep -E "metric|NaN|Error" gpurun_out/bench_default.log | cut -c1-1500
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload cistgcn64_b256_t50_v22 2>&1 | grep -E "metric|NaN|Error" | cut -c1-300
+bash tools/gpu_profile.sh cistgcn8_b16_t50_v22 > gpurun_out/profile.log 2>&1; echo "profile rc=$?"
+bash tools/gpu_profile.sh cistgcn64_b256_t50_v22 > gpurun_out/profile64.log 2>&1; echo "profile64 rc=$?"
