@@ -7,12 +7,12 @@
 // so the kernel is layout-agnostic: NCTV / NTCV / (N,3,V,T) views, zero-padded halos and dilation
 // all reduce to table contents.  64x64 output tile per 256-thread workgroup on the fp32 matrix cores
 // (v_mfma_f32_16x16x4_f32, exact f32), or 16x64 on the VALU for thin outputs; K staged through LDS in
-// steps of 16, optional split-K with fp32 atomics.
+// steps of 32, optional split-K with fp32 atomics.
 //
 // This is the scaffold kernel: the hot ST-GCN stage has its own fused kernel (stgcn_domain.hip).
 #include "cg_common.h"
 
-#define CG_BK 16
+#define CG_BK 32
 #define CG_KT 2048   // k-offset table entries staged in LDS per workgroup (two tables)
 
 // Per K-step the kernel needs one dependent global load per operand element (offset tables are in
@@ -26,7 +26,8 @@
 struct CgContractDesc {
   const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
   int G, M, N, K, splitk, kchunk, a_kfast, x_kfast;
-  int accumulate, pad;       // accumulate = 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
+  int accumulate;            // 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
+  int x_vec;                 // 1: X is contiguous and 16-byte aligned along n in groups of four -> float4 loads
   long long block0;          // first block id of this problem inside the launch
 };
 #define CG_MAX_BATCH 16
@@ -93,10 +94,16 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
     const int m = m0 + a_mm[r];
     a_off[r] = m < M ? baseA + mA[m] : -1;
   }
+  const bool x_vec = d.x_vec != 0 && !x_kfast;     // element r = 4*q + j of this thread is column 4*(e4 % 16) + j of k-row e4 / 16
 #pragma unroll
   for (int r = 0; r < X_PER; ++r) {
-    const int e = tid + 256 * r;
-    if (x_kfast) { x_kk[r] = e % CG_BK; x_nn[r] = e / CG_BK; } else { x_nn[r] = e % BN; x_kk[r] = e / BN; }
+    if (x_vec) {
+      const int e4 = tid + 256 * (r >> 2);
+      x_kk[r] = e4 / (BN / 4); x_nn[r] = (e4 % (BN / 4)) * 4 + (r & 3);
+    } else {
+      const int e = tid + 256 * r;
+      if (x_kfast) { x_kk[r] = e % CG_BK; x_nn[r] = e / CG_BK; } else { x_nn[r] = e % BN; x_kk[r] = e / BN; }
+    }
     const int n = n0 + x_nn[r];
     x_off[r] = n < N ? baseX + nX[n] : -1;
   }
@@ -111,12 +118,22 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
       if (a_off[r] >= 0 && k < kend) v = A[a_off[r] + (lds_tab ? sKA[k - kbeg] : kA[k])];
       ra[r] = v;
     }
+    if (x_vec) {
 #pragma unroll
-    for (int r = 0; r < X_PER; ++r) {
-      const int k = k0 + x_kk[r];
-      float v = 0.f;
-      if (x_off[r] >= 0 && k < kend) v = X[x_off[r] + (lds_tab ? sKX[k - kbeg] : kX[k])];
-      rx[r] = v;
+      for (int q = 0; q < X_PER / 4; ++q) {
+        const int k = k0 + x_kk[4 * q];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x_off[4 * q] >= 0 && k < kend) v = *reinterpret_cast<const float4*>(X + x_off[4 * q] + (lds_tab ? sKX[k - kbeg] : kX[k]));
+        rx[4 * q] = v.x; rx[4 * q + 1] = v.y; rx[4 * q + 2] = v.z; rx[4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < X_PER; ++r) {
+        const int k = k0 + x_kk[r];
+        float v = 0.f;
+        if (x_off[r] >= 0 && k < kend) v = X[x_off[r] + (lds_tab ? sKX[k - kbeg] : kX[k])];
+        rx[r] = v;
+      }
     }
   };
   auto stage = [&]() {
@@ -262,6 +279,7 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
     if (!d.A || !d.X || !d.Y || !d.tab) return CG_EARG;
     if (d.G <= 0 || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.splitk <= 0) return CG_ESHAPE;
     if (d.stats && (d.splitk > 1 || d.accumulate)) return CG_EARG;
+    if (d.x_vec && ((d.N & 3) || ((uintptr_t)d.X & 15))) return CG_EARG;
     d.block0 = total;
     total += cg_contract_blocks(d);
     batch.d[i] = d;
@@ -286,6 +304,6 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
-  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.pad = 0; d.block0 = 0;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.block0 = 0;
   return cg_contract_many(&d, 1, stream_);
 }

@@ -119,7 +119,7 @@ def begin_step(device, bump_seed=False):
 # generic contraction
 # ----------------------------------------------------------------------------------------------
 class _Plan:
-    __slots__ = ("tables", "G", "M", "N", "K", "splitk", "a_kfast", "x_kfast", "dense")
+    __slots__ = ("tables", "G", "M", "N", "K", "splitk", "a_kfast", "x_kfast", "dense", "x_vec")
 
 
 _plans = {}
@@ -165,6 +165,13 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
     kx, nx = _min_stride(k, sizes, sx), _min_stride(n, sizes, sx)
     p.a_kfast = 1 if (ma is None or (ka is not None and ka < ma)) else 0
     p.x_kfast = 1 if (nx is None or (kx is not None and kx < nx)) else 0
+    # X readable as float4 along n: n-offsets contiguous in aligned groups of four and every other offset a multiple of 4
+    nx_tab = tabs[6]
+    p.x_vec = 0
+    if not p.x_kfast and p.N % 4 == 0 and p.N >= 4:
+        quads = nx_tab.reshape(-1, 4)
+        if (np.diff(quads, axis=1) == 1).all() and (quads[:, 0] % 4 == 0).all() and (tabs[1] % 4 == 0).all() and (tabs[9] % 4 == 0).all():
+            p.x_vec = 1
     blocks = p.G * ((p.M + (15 if p.M <= 16 else 63)) // (16 if p.M <= 16 else 64)) * ((p.N + 63) // 64)
     p.splitk = 1
     p.dense = y_dense
@@ -212,6 +219,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     d.bias = bias.data_ptr() if bias is not None else None
     d.stats = r.stats.data_ptr() if r.stats is not None else None
     d.G, d.M, d.N, d.K, d.splitk, d.a_kfast, d.x_kfast = p.G, p.M, p.N, p.K, p.splitk, p.a_kfast, p.x_kfast
+    d.x_vec = 1 if (p.x_vec and x.data_ptr() % 16 == 0) else 0
     r.desc = d
     return r
 
@@ -329,7 +337,9 @@ class _ContractMany(torch.autograd.Function):
             if ctx.needs_input_grad[2 + 3 * i]:
                 key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
                 builders.append(lambda out, s="%s,%s->%s" % (la, ly, lx), a=a, dy=dy: _contract_prepare(s, a, dy, out=out))
-                slots.append(3 * i + 1); groups.append(key if len(shared[key]) > 1 else None)
+                # large tensors: float atomics are slower than separate outputs + adds (MI355X ~1.3 TB/s of atomic bytes)
+                small = x.numel() * len(shared[key]) <= (1 << 22)
+                slots.append(3 * i + 1); groups.append(key if (len(shared[key]) > 1 and small) else None)
             if ctx.needs_input_grad[3 + 3 * i]:
                 builders.append(_sum_keep_builder(dy, ly, bias_label))
                 slots.append(3 * i + 2); groups.append(None)

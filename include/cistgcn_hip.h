@@ -55,7 +55,8 @@ int cg_contract(const float* A, const float* X, float* Y, const float* bias, dou
 typedef struct CgContractDesc {
   const float* A; const float* X; float* Y; const float* bias; double* stats; const int32_t* tab;
   int G, M, N, K, splitk, kchunk /* set by the library */, a_kfast, x_kfast;
-  int accumulate, pad;           /* accumulate = 1: fp32 atomic adds into a zeroed Y shared by several problems */
+  int accumulate;                /* 1: fp32 atomic adds into a zeroed Y shared by several problems */
+  int x_vec;                     /* 1: X contiguous + 16-byte aligned along n in groups of four (float4 loads) */
   long long block0;              /* set by the library */
 } CgContractDesc;
 int cg_contract_many(const CgContractDesc* descs, int n, void* stream);

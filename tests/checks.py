@@ -85,6 +85,14 @@ def check_contract(device):
          [wb, xb], device, rel=1e-4, what="contract tiled/split-K")
 
 
+    # float4 operand loads (positions contiguous in aligned groups of four), both tile shapes
+    xv = _rand(g, 5, 12, 4, 8)
+    for O_ in (8, 40):
+        wv = _rand(g, O_, 12, scale=0.3)
+        _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_), lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_),
+             [wv, xv], device, what="contract vectorised loads O=%d" % O_)
+
+
 def check_norm_act(device):
     g = _gen(2)
     B, C, T, V = 4, 6, 5, 7
