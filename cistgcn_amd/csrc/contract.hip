@@ -7,12 +7,13 @@
 // so the kernel is layout-agnostic: NCTV / NTCV / (N,3,V,T) views, zero-padded halos and dilation
 // all reduce to table contents.  64x64 output tile per 256-thread workgroup on the fp32 matrix cores
 // (v_mfma_f32_16x16x4_f32, exact f32), or 16x64 on the VALU for thin outputs; K staged through LDS in
-// steps of 32, optional split-K with fp32 atomics.
+// steps of 16, optional split-K with fp32 atomics.
 //
 // This is the scaffold kernel: the hot ST-GCN stage has its own fused kernel (stgcn_domain.hip).
 #include "cg_common.h"
 
-#define CG_BK 32
+#define CG_BK 16      // K step of the 64x64 matrix-core tile
+#define CG_BK_THIN 16 // K step of the thin (M <= 16) tile (64 was measured slower: fewer resident workgroups)
 #define CG_KT 2048   // k-offset table entries staged in LDS per workgroup (two tables)
 
 // Per K-step the kernel needs one dependent global load per operand element (offset tables are in
@@ -38,7 +39,7 @@ struct CgContractBatch { int n; int pad; CgContractDesc d[CG_MAX_BATCH]; };
 typedef float cg_f32x4 __attribute__((vector_size(16)));
 #define CG_LDT 80   // LDS row stride of the 64-wide tiles: 80 mod 32 = 16 keeps the four k-rows of a fragment read on distinct banks
 
-template <int BM, int TM>
+template <int BM, int TM, int BK>
 __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long long bid, float* As_, float* Xs_,
                                                  int32_t* sKA, int32_t* sKX, double* sStat_) {
   constexpr int BN = 64, TN = 4;
@@ -82,15 +83,15 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   }
   if (stats != nullptr && tid < 2 * BM) sStat[tid >> 1][tid & 1] = 0.0;
 
-  constexpr int A_PER = (BM * CG_BK) / 256;   // 4 (BM=64) or 1 (BM=16)
-  constexpr int X_PER = (BN * CG_BK) / 256;   // 4
+  constexpr int A_PER = (BM * BK) / 256;   // 4 (BM=64) or 1 (BM=16)
+  constexpr int X_PER = (BN * BK) / 256;   // 4
   int a_mm[A_PER], a_kk[A_PER], x_nn[X_PER], x_kk[X_PER];
   long long a_off[A_PER], x_off[X_PER];
   const long long baseA = gA[g], baseX = gX[g];
 #pragma unroll
   for (int r = 0; r < A_PER; ++r) {
     const int e = tid + 256 * r;
-    if (a_kfast) { a_kk[r] = e % CG_BK; a_mm[r] = e / CG_BK; } else { a_mm[r] = e % BM; a_kk[r] = e / BM; }
+    if (a_kfast) { a_kk[r] = e % BK; a_mm[r] = e / BK; } else { a_mm[r] = e % BM; a_kk[r] = e / BM; }
     const int m = m0 + a_mm[r];
     a_off[r] = m < M ? baseA + mA[m] : -1;
   }
@@ -102,7 +103,7 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
       x_kk[r] = e4 / (BN / 4); x_nn[r] = (e4 % (BN / 4)) * 4 + (r & 3);
     } else {
       const int e = tid + 256 * r;
-      if (x_kfast) { x_kk[r] = e % CG_BK; x_nn[r] = e / CG_BK; } else { x_nn[r] = e % BN; x_kk[r] = e / BN; }
+      if (x_kfast) { x_kk[r] = e % BK; x_nn[r] = e / BK; } else { x_nn[r] = e % BN; x_kk[r] = e / BN; }
     }
     const int n = n0 + x_nn[r];
     x_off[r] = n < N ? baseX + nX[n] : -1;
@@ -155,12 +156,13 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
     fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += CG_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
       stage();
       __syncthreads();
-      if (k0 + CG_BK < kend) fetch(k0 + CG_BK);      // in flight while the MFMAs below run
-#pragma unroll
-      for (int ks = 0; ks < CG_BK / 4; ++ks) {
+      if (k0 + BK < kend) fetch(k0 + BK);      // in flight while the MFMAs below run
+      const int nks = (min(BK, kend - k0) + 3) / 4;     // short reductions (outer products, K = 3..10) stop early
+#pragma unroll 4
+      for (int ks = 0; ks < nks; ++ks) {
         const int k = 4 * ks + l4;
         const float a0 = As[k][wm + l15], a1 = As[k][wm + 16 + l15];
         const float b0 = Xs[k][wn + l15], b1 = Xs[k][wn + 16 + l15];
@@ -201,12 +203,13 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = 0.f;
     fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += CG_BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
       stage();
       __syncthreads();
-      if (k0 + CG_BK < kend) fetch(k0 + CG_BK);      // in flight while the FMAs below run
-#pragma unroll
-      for (int kk = 0; kk < CG_BK; ++kk) {
+      if (k0 + BK < kend) fetch(k0 + BK);      // in flight while the FMAs below run
+      const int klim = min(BK, kend - k0);              // short reductions stop early
+#pragma unroll 4
+      for (int kk = 0; kk < klim; ++kk) {
         float a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i] = As[kk][ty + 16 * i];
@@ -245,8 +248,8 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 }
 
 __global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch batch) {
-  __shared__ float As[CG_BK * CG_LDT];
-  __shared__ float Xs[CG_BK * CG_LDT];
+  __shared__ float As[CG_BK * CG_LDT];                 // 16 x 80 (wide tile) or 64 x 17 (thin tile)
+  __shared__ float Xs[CG_BK_THIN * 65];                // 16 x 80 (wide tile) or 64 x 65 (thin tile)
   __shared__ int32_t sKA[CG_KT];
   __shared__ int32_t sKX[CG_KT];
   __shared__ double sStat[64 * 2];
@@ -256,13 +259,14 @@ __global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch b
     if (bid >= batch.d[i].block0) pi = i;
   const CgContractDesc& d = batch.d[pi];
   bid -= d.block0;
-  if (d.M <= 16) cg_contract_body<16, 1>(d, bid, As, Xs, sKA, sKX, sStat);
-  else cg_contract_body<64, 4>(d, bid, As, Xs, sKA, sKX, sStat);
+  if (d.M <= 16) cg_contract_body<16, 1, CG_BK_THIN>(d, bid, As, Xs, sKA, sKX, sStat);
+  else cg_contract_body<64, 4, CG_BK>(d, bid, As, Xs, sKA, sKX, sStat);
 }
 
 static long long cg_contract_blocks(CgContractDesc& d) {
   int kchunk = (d.K + d.splitk - 1) / d.splitk;
-  d.kchunk = ((kchunk + CG_BK - 1) / CG_BK) * CG_BK;
+  const int bk = d.M <= 16 ? CG_BK_THIN : CG_BK;
+  d.kchunk = ((kchunk + bk - 1) / bk) * bk;
   const int BM = d.M <= 16 ? 16 : 64;
   return (long long)((d.N + 63) / 64) * ((d.M + BM - 1) / BM) * d.splitk * d.G;
 }
