@@ -248,8 +248,9 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 }
 
 __global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch batch) {
-  __shared__ float As[CG_BK * CG_LDT];                 // 16 x 80 (wide tile) or 64 x 17 (thin tile)
-  __shared__ float Xs[CG_BK_THIN * 65];                // 16 x 80 (wide tile) or 64 x 65 (thin tile)
+  constexpr int kTile = CG_BK * CG_LDT > CG_BK_THIN * 65 ? CG_BK * CG_LDT : CG_BK_THIN * 65;
+  __shared__ float As[kTile];                          // wide tile: BK x 80; thin tile: BK_THIN x 17
+  __shared__ float Xs[kTile];                          // wide tile: BK x 80; thin tile: BK_THIN x 65
   __shared__ int32_t sKA[CG_KT];
   __shared__ int32_t sKX[CG_KT];
   __shared__ double sStat[64 * 2];

@@ -65,6 +65,42 @@ class FlatGrads:
         self._copy(1)
 
 
+class FlatAdam:
+    """Adam on ONE flat fp32 buffer.  Semantics of the reference's optimizer,
+    `torch.optim.Adam(params, lr, weight_decay)` (environment/utils.py:53-57): L2 decay added to the gradient,
+    bias-corrected moments, eps after the square root; optional `clip_grad_value_` (environment/train.py:97-98).
+    The parameters are re-homed into slices of one buffer (views, no copies afterwards), gradients arrive through
+    `FlatGrads`, so the 698 per-tensor update launches of the stock optimizer become one kernel."""
+
+    def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, flat=None):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        device = self.params[0].device
+        self.grads = flat if flat is not None else FlatGrads(self.params, device)
+        self.flat_param = torch.empty(self.grads.numel, dtype=torch.float32, device=device)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + n].view(p.shape)       # same values, new home
+                off += n
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.lr, self.betas, self.eps, self.weight_decay, self.clip_value = lr, betas, eps, weight_decay, clip_value
+        self.step_count = 0
+
+    def step(self, grad_scale=1.0, gathered=False):
+        """One update.  `grad_scale` folds the 1/world of a data-parallel sum; `gathered` = the flat gradient
+        buffer is already filled (e.g. by GraphedStep / after the all-reduce)."""
+        if not gathered:
+            self.grads.gather()
+        self.step_count += 1
+        f = self.flat_param
+        _lib.call("cg_adam_flat", ops._ptr(f), ops._ptr(self.grads.flat), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
+                  f.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.clip_value,
+                  self.step_count, ops._stream(f))
+
+
 def allreduce_mean_(flat, group=None):
     """In-place mean over the data-parallel group: RCCL all-reduce(sum) over xGMI (backend "nccl" on
     ROCm) or gloo in the CPU tests, then the 1/world scale folded into the same buffer."""

@@ -93,6 +93,16 @@ def check_contract(device):
              [wv, xv], device, what="contract vectorised loads O=%d" % O_)
 
 
+    # wide (matrix-core) tile with bias and the BatchNorm-sum epilogue, ragged N and short K
+    for K_ in (4, 12, 20):
+        xw, ww, bw = _rand(g, 3, K_, 5, 7), _rand(g, 40, K_, scale=0.3), _rand(g, 40)
+        ops.begin_step(device)
+        yw, st = ops.contract_stats("oc,bchw->bohw", ww.to(device), xw.to(device), bw.to(device), "o")
+        rw = (torch.einsum("oc,bchw->bohw", ww, xw) + bw.view(1, -1, 1, 1)).double()
+        assert_close(yw, rw, "contract wide K=%d" % K_, rel=2e-5)
+        assert_close(st.cpu(), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
+
+
 def check_norm_act(device):
     g = _gen(2)
     B, C, T, V = 4, 6, 5, 7
@@ -460,3 +470,37 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
     for k in so:
         if "running" in k or "num_batches" in k:
             assert_close(sd[k].float(), so[k].float(), k)
+
+
+def check_flat_adam(device):
+    """cg_adam_flat + FlatGrads against torch.optim.Adam with the reference's settings (weight decay, no amsgrad)."""
+    from cistgcn_amd.runtime import FlatAdam
+    torch.manual_seed(3)
+    ref = nn.Sequential(nn.Linear(13, 7), nn.BatchNorm1d(7), nn.Linear(7, 300), nn.PReLU())
+    dev = nn.Sequential(nn.Linear(13, 7), nn.BatchNorm1d(7), nn.Linear(7, 300), nn.PReLU())
+    dev.load_state_dict(ref.state_dict())
+    dev.to(device)
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-4)
+    opt_dev = FlatAdam(dev, lr=1e-2, weight_decay=1e-4)
+    g = _gen(21)
+    for step in range(4):
+        for pr, pd in zip(ref.parameters(), dev.parameters()):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad = gr.clone()
+            pd.grad = gr.clone().to(device)
+        opt_ref.step()
+        opt_dev.step()
+        for (k, pr), pd in zip(ref.named_parameters(), dev.parameters()):
+            assert_close(pd, pr, "adam step %d %s" % (step, k), rel=1e-5)
+    # clip_grad_value_ + gradient pre-scale (data-parallel mean)
+    ref2, dev2 = nn.Linear(5, 4), nn.Linear(5, 4)
+    dev2.load_state_dict(ref2.state_dict()); dev2.to(device)
+    o_ref, o_dev = torch.optim.Adam(ref2.parameters(), lr=1e-2), FlatAdam(dev2, lr=1e-2, clip_value=0.5)
+    for pr, pd in zip(ref2.parameters(), dev2.parameters()):
+        gr = 3 * torch.randn(pr.shape, generator=g)
+        pr.grad = gr.clone() / 2
+        pd.grad = gr.clone().to(device)
+    torch.nn.utils.clip_grad_value_(ref2.parameters(), 0.5)
+    o_ref.step(); o_dev.step(grad_scale=0.5)
+    for pr, pd in zip(ref2.parameters(), dev2.parameters()):
+        assert_close(pd, pr, "adam clip/scale", rel=1e-5)

@@ -83,3 +83,24 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_reference_checkpoint_layout_loads(tmp_path):
+    """Checkpoint I/O compatibility: a `*.pth.tar` written the way the reference does
+    (train.py:184-194 via environment/utils.py:60-66: {epoch, lr, err, metric_used_to_save, state_dict, optimizer})
+    loads by key into the MI355X model exactly as model_loader.py:24-26 does it."""
+    from cistgcn_amd.models import CISTGCN_0
+    from oracle import cistgcn_ref as O
+    torch.manual_seed(1)
+    src = O.CISTGCN(*make_cfg(8, 10, 22))
+    opt = torch.optim.Adam(src.parameters(), lr=1e-2, weight_decay=1e-4)
+    path = os.path.join(tmp_path, "CISTGCN_0_best.pth.tar")
+    torch.save({"epoch": 3, "lr": 1e-2, "err": 42.0, "metric_used_to_save": "mpjpe", "state_dict": src.state_dict(),
+                "optimizer": opt.state_dict()}, path)
+    ckpt = torch.load(path, map_location="cpu")
+    net = CISTGCN_0(*make_cfg(8, 10, 22))
+    missing = net.load_state_dict(ckpt["state_dict"])
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert ckpt["epoch"] == 3 and ckpt["err"] == 42.0
+    sd = net.state_dict()
+    assert all(torch.equal(sd[k], v) for k, v in src.state_dict().items())

@@ -1,23 +1,17 @@
 #!/bin/bash
-# One GPU-box session: bench + rocprof kernel stats for both workloads (+ PMC traffic).  Logs under gpurun_out/.
+# Full GPU-box session: parity tests, smoke, bench (with CPU baseline), rocprof kernel stats for both workloads, PMC traffic.
 set -u
 mkdir -p gpurun_out
-run() {  # name, timeout, command...
-  local name=$1 t=$2; shift 2
-  echo "=== $name" | tee -a gpurun_out/session.log
-  timeout -k 10 "$t" "$@" > "gpurun_out/$name.log" 2>&1
-  local rc=$?
-  echo "$name rc=$rc" | tee -a gpurun_out/session.log
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/session.log; exit 1; fi
-  return 0
-}
-: > gpurun_out/session.log
-run build 300 python -c "import __graft_entry__ as g; g.build()"
-run bench_default 600 python bench.py --steps 50 --warmup 10
-tail -c 400 gpurun_out/bench_default.log
-run profile 900 bash tools/gpu_profile.sh cistgcn8_b16_t50_v22
-run profile64 900 bash tools/gpu_profile.sh cistgcn64_b256_t50_v22
-run pmc 600 bash tools/gpu_pmc.sh cistgcn8_b16_t50_v22
-tail -5 gpurun_out/pmc.log
-run pmc64 600 bash tools/gpu_pmc.sh cistgcn64_b256_t50_v22
-tail -5 gpurun_out/pmc64.log
+step() { echo "=== $1 $(date +%H:%M:%S)"; }
+step build; python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
+step pytest; timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -2
+grep -E "^E  " gpurun_out/pytest_gpu.log | cut -c1-250 | head -10
+step smoke; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/smoke.log
+step bench; timeout -k 10 400 python bench.py --steps 50 --warmup 10 > gpurun_out/bench_default.log 2>&1; echo "bench rc=$?"; grep -E "metric|NaN|Error" gpurun_out/bench_default.log | cut -c1-400
+step bench64; timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --workload cistgcn64_b256_t50_v22 > gpurun_out/bench_c64.log 2>&1; grep -E "metric|NaN|Error" gpurun_out/bench_c64.log | cut -c1-300
+step profile; bash tools/gpu_profile.sh cistgcn8_b16_t50_v22 > gpurun_out/profile.log 2>&1; echo "profile rc=$?"
+step profile64; bash tools/gpu_profile.sh cistgcn64_b256_t50_v22 > gpurun_out/profile64.log 2>&1; echo "profile64 rc=$?"
+step pmc; bash tools/gpu_pmc.sh cistgcn8_b16_t50_v22 > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log
+step pmc64; bash tools/gpu_pmc.sh cistgcn64_b256_t50_v22 > gpurun_out/pmc64.log 2>&1; tail -3 gpurun_out/pmc64.log
+step done
