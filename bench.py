@@ -226,8 +226,12 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_roofline:
             nbytes, secs, per = roofline_domain_kernel(B, C, T, V, device)
+            traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_pmc.sh), recorded under profiles/
+            tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "cg_stgcn_domain_fwd_kernel<0>", "avg_us": secs / len(per) * 1e6,
                                "algorithmic_bytes_per_launch_avg": nbytes / len(per), "per_shape": per}
         if not args.no_cpu_baseline:
