@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libcistgcn_hip.so")
 
 _handle = None
+STAT_REPLICAS = 16     # CG_STAT_REPLICAS of include/cistgcn_hip.h
 # Host pointers are refused unless a test harness has injected an emulated build of the very same
 # kernel sources (tests/hipemu).  The product never sets this.
 _host_pointers_ok = False
@@ -48,7 +49,7 @@ class NormAct(ctypes.Structure):
 class ContractDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("bias", c_void_p), ("stats", c_void_p), ("tab", c_void_p),
                 ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("splitk", c_int), ("kchunk", c_int),
-                ("a_kfast", c_int), ("x_kfast", c_int), ("accumulate", c_int), ("x_vec", c_int), ("block0", c_longlong)]
+                ("a_kfast", c_int), ("x_kfast", c_int), ("accumulate", c_int), ("x_vec", c_int), ("stat_ch", c_int), ("pad", c_int), ("block0", c_longlong)]
 
 
 class StatsArgs(ctypes.Structure):

@@ -11,6 +11,11 @@
 #define CG_EARG (-1)
 #define CG_ESHAPE (-2)
 
+// BatchNorm channel sums are accumulated with f64 atomics by every workgroup of the producing kernel; with
+// thousands of workgroups per channel one address serialises (~tens of microseconds).  Producers therefore add
+// into replica (block id mod CG_STAT_REPLICAS) of a [CG_STAT_REPLICAS][C][2] buffer, the consumer sums the replicas.
+#define CG_STAT_REPLICAS 16
+
 // 4-D strided view: dims n[0..3] (n[0] = batch rows, n[1] = channel), element strides s[0..3].
 // Layout-agnostic: NCTV, NTCV and (N,3,V,T) views of one buffer differ only in s[].
 struct CgView4 {

@@ -29,6 +29,7 @@ struct CgContractDesc {
   int G, M, N, K, splitk, kchunk, a_kfast, x_kfast;
   int accumulate;            // 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
   int x_vec;                 // 1: X is contiguous and 16-byte aligned along n in groups of four -> float4 loads
+  int stat_ch, pad;          // number of channels of `stats` (replica stride = 2 * stat_ch doubles)
   long long block0;          // first block id of this problem inside the launch
 };
 #define CG_MAX_BATCH 16
@@ -243,7 +244,8 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   }
   if (stats != nullptr) {           // channel of row m = mB[m] (the bias / statistics index)
     __syncthreads();
-    if (tid < 2 * BM && m0 + (tid >> 1) < M) atomicAdd(&stats[2 * mB[m0 + (tid >> 1)] + (tid & 1)], sStat[tid >> 1][tid & 1]);
+    double* rep = stats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * d.stat_ch;
+    if (tid < 2 * BM && m0 + (tid >> 1) < M) atomicAdd(&rep[2 * mB[m0 + (tid >> 1)] + (tid & 1)], sStat[tid >> 1][tid & 1]);
   }
 }
 
@@ -285,6 +287,7 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
     if (d.G <= 0 || d.M <= 0 || d.N <= 0 || d.K <= 0 || d.splitk <= 0) return CG_ESHAPE;
     if (d.stats && (d.splitk > 1 || d.accumulate)) return CG_EARG;
     if (d.x_vec && ((d.N & 3) || ((uintptr_t)d.X & 15))) return CG_EARG;
+    if (d.stats && d.stat_ch <= 0) return CG_EARG;
     d.block0 = total;
     total += cg_contract_blocks(d);
     batch.d[i] = d;
@@ -309,6 +312,6 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
-  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.block0 = 0;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.stat_ch = M; d.pad = 0; d.block0 = 0;
   return cg_contract_many(&d, 1, stream_);
 }

@@ -64,8 +64,9 @@ __global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
   s = cg_block_sum(s, red);
   q = cg_block_sum(q, red + 16);
   if (threadIdx.x == 0) {
-    atomicAdd(&it.stats[2 * c], s);
-    atomicAdd(&it.stats[2 * c + 1], q);
+    double* rep = it.stats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * xv.n[1];
+    atomicAdd(&rep[2 * c], s);
+    atomicAdd(&rep[2 * c + 1], q);
   }
 }
 
@@ -164,8 +165,13 @@ __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c
     r.mean = a.save_mean[c]; r.rstd = a.save_rstd[c];
   } else if (a.bn_mode == 1) {
     const double cnt = (double)a.xv.n[0] * (double)(a.xv.n[2] * a.xv.n[3]);
-    const double mean = a.stats[2 * c] / cnt;
-    double var = a.stats[2 * c + 1] / cnt - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < CG_STAT_REPLICAS; ++r) {      // replicated accumulators (cg_common.h)
+      s1 += a.stats[((long long)r * a.xv.n[1] + c) * 2];
+      s2 += a.stats[((long long)r * a.xv.n[1] + c) * 2 + 1];
+    }
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     r.mean = (float)mean;
     r.rstd = (float)(1.0 / sqrt(var + (double)a.eps));
@@ -217,7 +223,10 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   if (a.ystats) {      // uniform per problem: every thread of the workgroup takes this branch
     ys = cg_block_sum(ys, red);
     yq = cg_block_sum(yq, red + 16);
-    if (threadIdx.x == 0) { atomicAdd(&a.ystats[2 * c], ys); atomicAdd(&a.ystats[2 * c + 1], yq); }
+    if (threadIdx.x == 0) {
+      double* rep = a.ystats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * C;
+      atomicAdd(&rep[2 * c], ys); atomicAdd(&rep[2 * c + 1], yq);
+    }
   }
 }
 

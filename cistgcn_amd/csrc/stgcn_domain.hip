@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* _
   }
   if (ystats) {
     __syncthreads();
-    for (int e = tid; e < 2 * g.Cout; e += nt) atomicAdd(&ystats[e], sStat[e]);
+    double* rep = ystats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * g.Cout;
+    for (int e = tid; e < 2 * g.Cout; e += nt) atomicAdd(&rep[e], sStat[e]);
   }
 }
 

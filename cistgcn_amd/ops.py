@@ -52,7 +52,7 @@ class _Arena:
     """Per-device f64 scratch that is all-zero at the start of every step: BatchNorm sums and
     backward reductions take slices from it; one memset per step replaces one per layer."""
 
-    def __init__(self, device, n=1 << 19):
+    def __init__(self, device, n=1 << 21):
         self.buf = torch.zeros(n, dtype=torch.float64, device=device)
         self.cur = 0
         self.high = 0
@@ -213,13 +213,14 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     r = _Prep()
     r.y, r.zero, r.stats = y, p.splitk > 1, None
     if stats_label is not None and p.splitk == 1:
-        r.stats = _arena(x.device).take(2 * sizes[stats_label])     # f64 channel sums of y for the BatchNorm that follows
+        r.stats = _arena(x.device).take(2 * sizes[stats_label] * _lib.STAT_REPLICAS)   # replicated f64 channel sums of y
     d = _lib.ContractDesc()
     d.A, d.X, d.Y, d.tab = a.data_ptr(), x.data_ptr(), y.data_ptr(), p.tables.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.stats = r.stats.data_ptr() if r.stats is not None else None
     d.G, d.M, d.N, d.K, d.splitk, d.a_kfast, d.x_kfast = p.G, p.M, p.N, p.K, p.splitk, p.a_kfast, p.x_kfast
     d.x_vec = 1 if (p.x_vec and x.data_ptr() % 16 == 0) else 0
+    d.stat_ch = sizes[stats_label] if stats_label is not None else 0
     r.desc = d
     return r
 
@@ -444,7 +445,7 @@ def _na_fill_fwd(a, x, pre, add, gamma, beta, alpha, cfg, pending_stats):
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
             stats = cfg.get("stats")
             if stats is None:
-                stats = _arena(dev).take(2 * C)
+                stats = _arena(dev).take(2 * C * _lib.STAT_REPLICAS)
                 it = _lib.StatsArgs()
                 it.x, it.xv, it.pre, it.stats = x.data_ptr(), v, (pre.data_ptr() if pre is not None else None), stats.data_ptr()
                 pending_stats.append(it)
@@ -456,7 +457,7 @@ def _na_fill_fwd(a, x, pre, add, gamma, beta, alpha, cfg, pending_stats):
         a.alpha, a.alpha_n = alpha.data_ptr(), alpha.numel()
     emitted = None
     if cfg.get("emit_stats"):
-        emitted = _arena(dev).take(2 * C)
+        emitted = _arena(dev).take(2 * C * _lib.STAT_REPLICAS)
         a.ystats = emitted.data_ptr()
     return y, save, p, emitted
 
@@ -967,7 +968,7 @@ class _StgcnDomain(torch.autograd.Function):
         if tuple(adj.shape) != exp or w.numel() != Cout * Cin:
             raise ValueError("stgcn_domain: adjacency %s / weight %s do not match x %s" % (tuple(adj.shape), tuple(w.shape), tuple(x.shape)))
         y = torch.empty(B, Cout, T, V, dtype=torch.float32, device=x.device)
-        stats = _arena(x.device).take(2 * Cout) if want_stats else None
+        stats = _arena(x.device).take(2 * Cout * _lib.STAT_REPLICAS) if want_stats else None
         _lib.call("cg_stgcn_domain_fwd", _ptr(x), _ptr(adj), _ptr(w), _ptr(bias), _ptr(y), _ptr(stats),
                   B, Cin, Cout, T, V, domain, _stream(x))
         ctx.domain = domain

@@ -26,6 +26,11 @@
 extern "C" {
 #endif
 
+/* BatchNorm channel sums ("stats" / "ystats" below) are [CG_STAT_REPLICAS][C][2] f64 buffers, zero on entry:
+ * every workgroup adds {sum, sum of squares} into replica (block id mod CG_STAT_REPLICAS) so that f64 atomics do
+ * not serialise on one address; cg_norm_act_fwd sums the replicas. */
+#define CG_STAT_REPLICAS 16
+
 /* 4-D strided view: n[0] batch, n[1] channel, n[2] x n[3] positions; s[] in elements.
  * NCTV, NTCV (CISTGCN.py:582) and (N,3,V,T) (:592) views of one buffer differ only in s[]. */
 typedef struct CgView4 {
@@ -57,6 +62,7 @@ typedef struct CgContractDesc {
   int G, M, N, K, splitk, kchunk /* set by the library */, a_kfast, x_kfast;
   int accumulate;                /* 1: fp32 atomic adds into a zeroed Y shared by several problems */
   int x_vec;                     /* 1: X contiguous + 16-byte aligned along n in groups of four (float4 loads) */
+  int stat_ch, pad;              /* channels of `stats`: it holds CG_STAT_REPLICAS x stat_ch x 2 doubles */
   long long block0;              /* set by the library */
 } CgContractDesc;
 int cg_contract_many(const CgContractDesc* descs, int n, void* stream);

@@ -15,6 +15,12 @@ from helpers import assert_close, assert_grads_close, load_case, make_cfg, state
 from oracle import cistgcn_ref as O
 
 
+def _chan_sums(st):
+    """fold the replicated [R][C][2] channel-sum buffer (CG_STAT_REPLICAS) into [C*2]"""
+    from cistgcn_amd import _lib
+    return st.detach().cpu().view(_lib.STAT_REPLICAS, -1).sum(0)
+
+
 def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
@@ -100,7 +106,7 @@ def check_contract(device):
         yw, st = ops.contract_stats("oc,bchw->bohw", ww.to(device), xw.to(device), bw.to(device), "o")
         rw = (torch.einsum("oc,bchw->bohw", ww, xw) + bw.view(1, -1, 1, 1)).double()
         assert_close(yw, rw, "contract wide K=%d" % K_, rel=2e-5)
-        assert_close(st.cpu(), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
+        assert_close(_chan_sums(st), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
 
 
 def check_norm_act(device):
@@ -220,7 +226,7 @@ def check_batched_ops(device):
     for i, (a, b) in enumerate(zip(gr, grr)):
         assert_close(a, b, "contract_many grad%d" % i, rel=2e-5, floor=float(b.abs().max()))
     y0 = yr[0].detach().double()
-    assert_close(sts[0].cpu(), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "epilogue sums", rel=1e-6)
+    assert_close(_chan_sums(sts[0]), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "epilogue sums", rel=1e-6)
     assert sts[1] is None and sts[2] is None
     # row problems of different shapes in one launch, one of them emitting the sums of its output
     shapes = [(4, 6, 5, 7), (4, 3, 1, 9), (6, 5)]
@@ -244,7 +250,7 @@ def check_batched_ops(device):
         assert_close(bns_dev[i].weight.grad, bns_ref[i].weight.grad, "norm_act_many dgamma%d" % i, rel=2e-5, floor=1e-3)
         assert_close(bns_dev[i].running_var, bns_ref[i].running_var, "norm_act_many running_var%d" % i, rel=2e-5)
     y0 = yr[0].detach().double()
-    assert_close(outs[0][1].cpu(), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "emitted sums", rel=1e-6)
+    assert_close(_chan_sums(outs[0][1]), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "emitted sums", rel=1e-6)
 
 
 def check_dropout(device):
@@ -344,7 +350,7 @@ def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 
             y, st = ops.stgcn_domain(x.to(device), adj.to(device), w.to(device), bias.to(device), domain, want_stats=True)
             yc = y.detach().cpu().double()
             ref = torch.stack((yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3))), 1).reshape(-1)
-            assert_close(st.cpu(), ref, what + " channel sums", rel=1e-6)
+            assert_close(_chan_sums(st), ref, what + " channel sums", rel=1e-6)
 
 
 # ---------------------------------------------------------------------------------------------
