@@ -25,6 +25,7 @@ struct CgDomainGeom {
   int GT, ntiles;      // groups per tile, tiles per sample
   int NG, J, Jp, PP;   // groups per sample, contraction length, padded, positions per tile
   int Cinp, Coutp;
+  int per;             // tiles handled by one workgroup (weights / gradient accumulators persist across them)
   int xt, XS;          // xt = 1: x slice stored channel-fastest [GT][J][XS] (XS = Cinp + 4) so that the graph
                        // product reads four input channels per ds_read_b128 (4x4 register tile, Cin >= 16)
 };
@@ -42,9 +43,10 @@ __device__ __forceinline__ int cg_dom_x_floats(const CgDomainGeom& g) {
 // (4-byte columns of a 64-byte line in the space domain), then hit in ONE L2 instead of eight.
 // Placement only affects speed, never results.  The grid is padded to a multiple of 8.
 __device__ __forceinline__ int cg_dom_logical_block(const CgDomainGeom& g) {
-  const int per = gridDim.x / 8;
-  const int lid = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  return lid < g.B * g.ntiles ? lid : -1;
+  const int chunk = gridDim.x / 8;
+  const int lid = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  const int nwg = (g.B * g.ntiles + g.per - 1) / g.per;
+  return lid < nwg ? lid : -1;
 }
 
 template <int DOMAIN>
@@ -137,62 +139,70 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* _
   float* sWt = sG + g.Cinp * g.PP;
   double* sStat = reinterpret_cast<double*>(sWt + g.Cin * g.Coutp);
 
-  const int lid = cg_dom_logical_block(g);
-  if (lid < 0) return;
-  const int b = lid / g.ntiles, tile = lid % g.ntiles;
-  const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+  const int wg = cg_dom_logical_block(g);
+  if (wg < 0) return;
   const long long TV = (long long)g.T * g.V;
-  const float* xb = x + (long long)b * g.Cin * TV;
-  const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int total = g.B * g.ntiles;
 
-  cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
+  // the mixing weights and the statistics accumulators are staged once per workgroup and reused for all its tiles
   for (int e = tid; e < g.Cin * g.Coutp; e += nt) {
     const int co = e % g.Coutp, ci = e / g.Coutp;
     sWt[e] = co < g.Cout ? W[co * g.Cin + ci] : 0.f;
   }
   if (ystats) for (int e = tid; e < 2 * g.Coutp; e += nt) sStat[e] = 0.0;
-  __syncthreads();
-  cg_dom_graph_product(g, sA, sX, sG);
-  __syncthreads();
 
-  // channel mix: 4 output channels x 4 positions per work item
-  const int pq = g.PP / 4, cq = g.Coutp / 4;
-  float* yb = y + (long long)b * g.Cout * TV;
-  for (int idx = tid; idx < cq * pq; idx += nt) {
-    const int pc = idx % pq, cc = idx / pq;
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
-    for (int ci = 0; ci < g.Cin; ++ci) {
-      const float4 w = *reinterpret_cast<const float4*>(sWt + ci * g.Coutp + 4 * cc);
-      const float4 v = *reinterpret_cast<const float4*>(sG + ci * g.PP + 4 * pc);
-      const float wv[4] = {w.x, w.y, w.z, w.w};
-      const float gv[4] = {v.x, v.y, v.z, v.w};
+  for (int it = 0; it < g.per; ++it) {
+    const int lid = wg * g.per + it;
+    if (lid >= total) break;                     // uniform across the workgroup
+    const int b = lid / g.ntiles, tile = lid % g.ntiles;
+    const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+    const float* xb = x + (long long)b * g.Cin * TV;
+    const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
+    __syncthreads();                             // previous tile fully consumed before its LDS images are overwritten
+    cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
+    __syncthreads();
+    cg_dom_graph_product(g, sA, sX, sG);
+    __syncthreads();
+
+    // channel mix: 4 output channels x 4 positions per work item
+    const int pq = g.PP / 4, cq = g.Coutp / 4;
+    float* yb = y + (long long)b * g.Cout * TV;
+    for (int idx = tid; idx < cq * pq; idx += nt) {
+      const int pc = idx % pq, cc = idx / pq;
+      float acc[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
-    }
-    const int pos0 = 4 * pc, grp = pos0 / g.Jp, o0 = pos0 % g.Jp;   // 4 positions never straddle a group (Jp % 4 == 0)
-    if (grp >= ng) continue;
+        for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+      for (int ci = 0; ci < g.Cin; ++ci) {
+        const float4 w = *reinterpret_cast<const float4*>(sWt + ci * g.Coutp + 4 * cc);
+        const float4 v = *reinterpret_cast<const float4*>(sG + ci * g.PP + 4 * pc);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        const float gv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int co = 4 * cc + a;
-      if (co >= g.Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
-      double s = 0.0, sq = 0.0;
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = o0 + q;
-        if (o >= g.J) continue;
-        const float v = acc[a][q] + bv;
-        yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
-        s += (double)v; sq += (double)v * (double)v;
+          for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
       }
-      if (ystats) { atomicAdd(&sStat[2 * co], s); atomicAdd(&sStat[2 * co + 1], sq); }
+      const int pos0 = 4 * pc, grp = pos0 / g.Jp, o0 = pos0 % g.Jp;   // 4 positions never straddle a group (Jp % 4 == 0)
+      if (grp >= ng) continue;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int co = 4 * cc + a;
+        if (co >= g.Cout) continue;
+        const float bv = bias ? bias[co] : 0.f;
+        double s = 0.0, sq = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int o = o0 + q;
+          if (o >= g.J) continue;
+          const float v = acc[a][q] + bv;
+          yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
+          s += (double)v; sq += (double)v * (double)v;
+        }
+        if (ystats) { atomicAdd(&sStat[2 * co], s); atomicAdd(&sStat[2 * co + 1], sq); }
+      }
     }
   }
   if (ystats) {
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* _
 
 // Backward of the fused stage.  Recomputes G from x and Adj, then
 //   dG = W^T dy ; dx = dG A^T ; dAdj = x^T dG ; dW += dy G^T ; db += sum dy.
+// dW / db partial sums stay in registers across the tiles of a workgroup and are added to HBM once at its end.
 template <int DOMAIN>
 __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
                                                                   const float* __restrict__ W, const float* __restrict__ dy,
@@ -221,128 +232,151 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_bwd_kernel(const float* _
   float* sDY = sDG + g.Cinp * g.PP;
   float* sW = sDY + g.Coutp * g.PP;        // [Coutp][Cinp]
 
-  const int lid = cg_dom_logical_block(g);
-  if (lid < 0) return;
-  const int b = lid / g.ntiles, tile = lid % g.ntiles;
-  const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+  const int wg = cg_dom_logical_block(g);
+  if (wg < 0) return;
   const long long TV = (long long)g.T * g.V;
-  const float* xb = x + (long long)b * g.Cin * TV;
-  const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
-  const float* dyb = dy + (long long)b * g.Cout * TV;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int J = g.J, Jp = g.Jp, GT = g.GT, PP = g.PP;
+  const int total = g.B * g.ntiles;
+  const int pq = PP / 4, iq = g.Cinp / 4, cq = g.Coutp / 4, oq = Jp / 4;
 
-  cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
   for (int e = tid; e < g.Coutp * g.Cinp; e += nt) {
     const int ci = e % g.Cinp, co = e / g.Cinp;
     sW[e] = (co < g.Cout && ci < g.Cin) ? W[co * g.Cin + ci] : 0.f;
   }
-  for (int e = tid; e < g.Coutp * PP; e += nt) {
-    const int pos = e % PP, co = e / PP, grp = pos / Jp, o = pos % Jp;
-    float v = 0.f;
-    if (co < g.Cout && grp < ng && o < J) v = dyb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)];
-    sDY[e] = v;
-  }
-  __syncthreads();
-  cg_dom_graph_product(g, sA, sX, sG);
-  // dG[ci][pos] = sum_co W[co][ci] dy[co][pos]
-  const int pq = PP / 4, iq = g.Cinp / 4, cq = g.Coutp / 4;
-  for (int idx = tid; idx < iq * pq; idx += nt) {
-    const int pc = idx % pq, ic = idx / pq;
-    float acc[4][4];
+  // register accumulators: dW tile (4 co x 4 ci) of work item idx = tid (+ nt ...), one db partial per thread
+  constexpr int kMaxWItems = 4;            // ceil(cq*iq / 256) <= 4 for Cout, Cin <= 128
+  float wacc[kMaxWItems][4][4];
+#pragma unroll
+  for (int u = 0; u < kMaxWItems; ++u)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
-    for (int co = 0; co < g.Cout; ++co) {
-      const float4 w = *reinterpret_cast<const float4*>(sW + co * g.Cinp + 4 * ic);
-      const float4 v = *reinterpret_cast<const float4*>(sDY + co * PP + 4 * pc);
-      const float wv[4] = {w.x, w.y, w.z, w.w};
-      const float gv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-      *reinterpret_cast<float4*>(sDG + (4 * ic + a) * PP + 4 * pc) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
-  }
-  __syncthreads();
+      for (int q = 0; q < 4; ++q) wacc[u][a][q] = 0.f;
+  float bacc = 0.f;
 
-  // dx[ci][grp][j] = sum_o dG[ci][grp][o] * A[grp][j][o]
-  float* dxb = dx + (long long)b * g.Cin * TV;
-  const int oq = Jp / 4;
-  for (int idx = tid; idx < g.Cin * ng * J; idx += nt) {
-    int ci, grp, j;
-    if (DOMAIN == 1) { j = idx % J; const int r = idx / J; grp = r % ng; ci = r / ng; }
-    else { grp = idx % ng; const int r = idx / ng; j = r % J; ci = r / J; }
-    const float* dg = sDG + ci * PP + grp * Jp;
-    const float* ar = sA + (grp * J + j) * Jp;
-    float s = 0.f;
-    for (int oc = 0; oc < oq; ++oc) {
-      const float4 d = *reinterpret_cast<const float4*>(dg + 4 * oc);
-      const float4 a = *reinterpret_cast<const float4*>(ar + 4 * oc);
-      s = fmaf(d.x, a.x, s); s = fmaf(d.y, a.y, s); s = fmaf(d.z, a.z, s); s = fmaf(d.w, a.w, s);
+  for (int it = 0; it < g.per; ++it) {
+    const int lid = wg * g.per + it;
+    if (lid >= total) break;                     // uniform across the workgroup
+    const int b = lid / g.ntiles, tile = lid % g.ntiles;
+    const int g0 = tile * g.GT, ng = min(g.GT, g.NG - g0);
+    const float* xb = x + (long long)b * g.Cin * TV;
+    const float* ab = adj + ((long long)b * g.NG + g0) * g.J * g.J;
+    const float* dyb = dy + (long long)b * g.Cout * TV;
+    __syncthreads();                             // previous tile fully consumed
+    cg_dom_stage_inputs<DOMAIN>(g, xb, ab, g0, ng, sA, sX);
+    for (int e = tid; e < g.Coutp * PP; e += nt) {
+      const int pos = e % PP, co = e / PP, grp = pos / Jp, o = pos % Jp;
+      float v = 0.f;
+      if (co < g.Cout && grp < ng && o < J) v = dyb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)];
+      sDY[e] = v;
     }
-    dxb[ci * TV + cg_dom_off<DOMAIN>(g, g0 + grp, j)] = s;
-  }
-  // dAdj[grp][j][o] = sum_ci x[ci][grp][j] * dG[ci][grp][o]
-  float* dab = dadj + ((long long)b * g.NG + g0) * J * J;
-  for (int idx = tid; idx < ng * J * oq; idx += nt) {
-    const int oc = idx % oq, r = idx / oq, j = r % J, grp = r / J;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int ci = 0; ci < g.Cin; ++ci) {
-      const float xv = sX[cg_dom_x_index(g, ci, grp, j)];
-      const float4 d = *reinterpret_cast<const float4*>(sDG + ci * PP + grp * Jp + 4 * oc);
-      acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y);
-      acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
-    }
-    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
-    float* row = dab + ((long long)grp * J + j) * J;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (4 * oc + q < J) row[4 * oc + q] = av[q];
-  }
-  // dW[co][ci] += sum_pos dy[co][pos] * G[ci][pos]   (4x4 register tile, float4 along positions)
-  for (int idx = tid; idx < cq * iq; idx += nt) {
-    const int ic = idx % iq, cc = idx / iq;
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
-    for (int pc = 0; pc < pq; ++pc) {
-      float dv[4][4], gv[4][4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const float4 d = *reinterpret_cast<const float4*>(sDY + (4 * cc + a) * PP + 4 * pc);
-        dv[a][0] = d.x; dv[a][1] = d.y; dv[a][2] = d.z; dv[a][3] = d.w;
-        const float4 v = *reinterpret_cast<const float4*>(sG + (4 * ic + a) * PP + 4 * pc);
-        gv[a][0] = v.x; gv[a][1] = v.y; gv[a][2] = v.z; gv[a][3] = v.w;
-      }
+    __syncthreads();
+    cg_dom_graph_product(g, sA, sX, sG);
+    // dG[ci][pos] = sum_co W[co][ci] dy[co][pos]
+    for (int idx = tid; idx < iq * pq; idx += nt) {
+      const int pc = idx % pq, ic = idx / pq;
+      float acc[4][4];
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) acc[a][q] = 0.f;
+      for (int co = 0; co < g.Cout; ++co) {
+        const float4 w = *reinterpret_cast<const float4*>(sW + co * g.Cinp + 4 * ic);
+        const float4 v = *reinterpret_cast<const float4*>(sDY + co * PP + 4 * pc);
+        const float wv[4] = {w.x, w.y, w.z, w.w};
+        const float gv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[a][q] = fmaf(dv[a][e], gv[q][e], acc[a][q]);
-    }
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = 4 * cc + a, ci = 4 * ic + q;
-        if (co < g.Cout && ci < g.Cin) atomicAdd(&dW[co * g.Cin + ci], acc[a][q]);
+          for (int q = 0; q < 4; ++q) acc[a][q] = fmaf(wv[a], gv[q], acc[a][q]);
       }
-  }
-  if (dbias) {
-    for (int co = tid; co < g.Cout; co += nt) {
-      float s = 0.f;
-      for (int p = 0; p < PP; ++p) s += sDY[co * PP + p];
-      atomicAdd(&dbias[co], s);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        *reinterpret_cast<float4*>(sDG + (4 * ic + a) * PP + 4 * pc) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+    }
+    __syncthreads();
+
+    // dx[ci][grp][j] = sum_o dG[ci][grp][o] * A[grp][j][o]
+    float* dxb = dx + (long long)b * g.Cin * TV;
+    for (int idx = tid; idx < g.Cin * ng * J; idx += nt) {
+      int ci, grp, j;
+      if (DOMAIN == 1) { j = idx % J; const int r = idx / J; grp = r % ng; ci = r / ng; }
+      else { grp = idx % ng; const int r = idx / ng; j = r % J; ci = r / J; }
+      const float* dg = sDG + ci * PP + grp * Jp;
+      const float* ar = sA + (grp * J + j) * Jp;
+      float sacc = 0.f;
+      for (int oc = 0; oc < oq; ++oc) {
+        const float4 d = *reinterpret_cast<const float4*>(dg + 4 * oc);
+        const float4 a = *reinterpret_cast<const float4*>(ar + 4 * oc);
+        sacc = fmaf(d.x, a.x, sacc); sacc = fmaf(d.y, a.y, sacc); sacc = fmaf(d.z, a.z, sacc); sacc = fmaf(d.w, a.w, sacc);
+      }
+      dxb[ci * TV + cg_dom_off<DOMAIN>(g, g0 + grp, j)] = sacc;
+    }
+    // dAdj[grp][j][o] = sum_ci x[ci][grp][j] * dG[ci][grp][o]
+    float* dab = dadj + ((long long)b * g.NG + g0) * J * J;
+    for (int idx = tid; idx < ng * J * oq; idx += nt) {
+      const int oc = idx % oq, r = idx / oq, j = r % J, grp = r / J;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ci = 0; ci < g.Cin; ++ci) {
+        const float xv = sX[cg_dom_x_index(g, ci, grp, j)];
+        const float4 d = *reinterpret_cast<const float4*>(sDG + ci * PP + grp * Jp + 4 * oc);
+        acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y);
+        acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+      }
+      const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+      float* row = dab + ((long long)grp * J + j) * J;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * oc + q < J) row[4 * oc + q] = av[q];
+    }
+    // dW[co][ci] += sum_pos dy[co][pos] * G[ci][pos]   (4x4 register tile per work item, float4 along positions)
+#pragma unroll
+    for (int u = 0; u < kMaxWItems; ++u) {
+      const int idx = tid + u * 256;
+      if (idx < cq * iq) {
+        const int ic = idx % iq, cc = idx / iq;
+        for (int pc = 0; pc < pq; ++pc) {
+          float dv[4][4], gv[4][4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const float4 d = *reinterpret_cast<const float4*>(sDY + (4 * cc + a) * PP + 4 * pc);
+            dv[a][0] = d.x; dv[a][1] = d.y; dv[a][2] = d.z; dv[a][3] = d.w;
+            const float4 v = *reinterpret_cast<const float4*>(sG + (4 * ic + a) * PP + 4 * pc);
+            gv[a][0] = v.x; gv[a][1] = v.y; gv[a][2] = v.z; gv[a][3] = v.w;
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) wacc[u][a][q] = fmaf(dv[a][e], gv[q][e], wacc[u][a][q]);
+        }
+      }
+    }
+    if (dbias && tid < g.Cout) {
+      float sacc = 0.f;
+      for (int p = 0; p < PP; ++p) sacc += sDY[tid * PP + p];
+      bacc += sacc;
     }
   }
+
+  // one atomic per weight-gradient entry and workgroup
+#pragma unroll
+  for (int u = 0; u < kMaxWItems; ++u) {
+    const int idx = tid + u * 256;
+    if (idx < cq * iq) {
+      const int ic = idx % iq, cc = idx / iq;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = 4 * cc + a, ci = 4 * ic + q;
+          if (co < g.Cout && ci < g.Cin) atomicAdd(&dW[co * g.Cin + ci], wacc[u][a][q]);
+        }
+    }
+  }
+  if (dbias && tid < g.Cout) atomicAdd(&dbias[tid], bacc);
 }
 
 __global__ void cg_dom_fold_replicas_kernel(const float* __restrict__ ws, int replicas, int n_w, int n_b,
@@ -397,6 +431,13 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   g.GT = best; g.PP = best * g.Jp;
   g.ntiles = (g.NG + best - 1) / best;
   if ((long long)B * g.ntiles > 2147483647LL) return CG_ESHAPE;
+  if (Cin > 128 || Cout > 128 || Cout > 256) return CG_ESHAPE;       // register / thread budget of the backward accumulators
+  // tiles per workgroup: amortise the weight staging (and, in backward, the dW/db atomics) while keeping ~2048 workgroups
+  const long long total = (long long)B * g.ntiles;
+  long long per = total / 2048;
+  if (per < 1) per = 1;
+  if (per > 16) per = 16;
+  g.per = (int)per;
   return CG_OK;
 }
 
@@ -407,7 +448,8 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
   const size_t lds = cg_dom_lds_bytes(g, false);
-  dim3 grid((unsigned)(((B * g.ntiles + 7) / 8) * 8)), block(256);
+  const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;
+  dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
   if (lds > 48 * 1024) {
     const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_kernel<0> : (const void*)cg_stgcn_domain_fwd_kernel<1>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -434,7 +476,8 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   hipError_t e = hipMemsetAsync(ws, 0, (size_t)CG_DOM_REPLICAS * (n_w + n_b) * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   const size_t lds = cg_dom_lds_bytes(g, true);
-  dim3 grid((unsigned)(((B * g.ntiles + 7) / 8) * 8)), block(256);
+  const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;
+  dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
   if (lds > 48 * 1024) {
     const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_bwd_kernel<0> : (const void*)cg_stgcn_domain_bwd_kernel<1>;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

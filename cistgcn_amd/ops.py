@@ -177,7 +177,9 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
     p.dense = y_dense
     if y_dense and p.K >= 256 and blocks < 512:
         # few output tiles and a long reduction (weight / bias gradients): spread K over workgroups
-        p.splitk = int(max(1, min((p.K + 63) // 64, (1024 + blocks - 1) // blocks)))
+        # every split adds its tile with fp32 atomics: splitk blocks serialise on each output address (~0.1 us each on
+        # MI355X) while each block walks K/splitk in ~1 us steps of 16 -> balance at splitk ~ sqrt(K/2)
+        p.splitk = int(max(1, min((p.K + 63) // 64, (1024 + blocks - 1) // blocks, int((p.K / 2.0) ** 0.5))))
     _plans[key] = p
     return p
 

@@ -334,7 +334,7 @@ def check_stage_kernels(device):
     assert_close(pd.grad, pr.grad, "mpjpe grad", rel=1e-5, floor=float(pr.grad.abs().max()))
 
 
-def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22), (2, 64, 64, 10, 22), (2, 32, 10, 50, 25))):
+def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22), (2, 64, 64, 10, 22), (2, 32, 10, 50, 25), (100, 3, 3, 45, 4), (128, 20, 24, 40, 6))):
     g = _gen(7)
     for (B, Cin, Cout, T, V) in shapes:
         for domain in (0, 1):

@@ -21,4 +21,4 @@ def test_operator(check):
 
 
 def test_stgcn_domain_small():
-    checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9), (2, 18, 16, 5, 7)))
+    checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9), (2, 18, 16, 5, 7), (100, 3, 3, 45, 4)))
