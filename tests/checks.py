@@ -52,7 +52,8 @@ def _run(fn_dev, fn_ref, inputs, device, rel=2e-5, what=""):
 
 
 # ---------------------------------------------------------------------------------------------
-def check_contract(device):
+def check_contract(device, quick=False):
+    """quick=True (CPU shim): smaller tiled case; the MI355X run uses the full sizes"""
     g = _gen(1)
     B, C, O, T, V = 3, 10, 8, 5, 7
     x = _rand(g, B, C, T, V)
@@ -85,22 +86,22 @@ def check_contract(device):
     _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_.permute(0, 2, 1, 3)),
          lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_.permute(0, 2, 1, 3)), [w, x], device, what="contract permuted")
     # many output rows/cols (several tiles, both tile shapes) and a long K (split-K path in the weight grad)
-    xb = _rand(g, 40, 70, 9, 11)
-    wb = _rand(g, 130, 70, scale=0.1)
+    xb = _rand(g, 6, 36, 5, 6) if quick else _rand(g, 40, 70, 9, 11)
+    wb = _rand(g, 70 if quick else 130, xb.shape[1], scale=0.1)
     _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_), lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_),
          [wb, xb], device, rel=1e-4, what="contract tiled/split-K")
 
 
     # float4 operand loads (positions contiguous in aligned groups of four), both tile shapes
     xv = _rand(g, 5, 12, 4, 8)
-    for O_ in (8, 40):
+    for O_ in ((40,) if quick else (8, 40)):
         wv = _rand(g, O_, 12, scale=0.3)
         _run(lambda w_, x_: ops.contract("oc,bchw->bohw", w_, x_), lambda w_, x_: torch.einsum("oc,bchw->bohw", w_, x_),
              [wv, xv], device, what="contract vectorised loads O=%d" % O_)
 
 
     # wide (matrix-core) tile with bias and the BatchNorm-sum epilogue, ragged N and short K
-    for K_ in (4, 12, 20):
+    for K_ in ((12,) if quick else (4, 12, 20)):
         xw, ww, bw = _rand(g, 3, K_, 5, 7), _rand(g, 40, K_, scale=0.3), _rand(g, 40)
         ops.begin_step(device)
         yw, st = ops.contract_stats("oc,bchw->bohw", ww.to(device), xw.to(device), bw.to(device), "o")
@@ -109,7 +110,7 @@ def check_contract(device):
         assert_close(_chan_sums(st), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
 
 
-def check_norm_act(device):
+def check_norm_act(device, quick=False):
     g = _gen(2)
     B, C, T, V = 4, 6, 5, 7
     x = _rand(g, B, C, T, V, scale=3.0) + 1.5
@@ -126,7 +127,7 @@ def check_norm_act(device):
     for train in (True, False):
         for use_pre in (False, True):
             for add_mode in (None, "pre", "post"):
-                for alpha_n in (0, 1, C):
+                for alpha_n in ((1, C) if (quick and add_mode == "pre") else ((1,) if quick else (0, 1, C))):
                     bn_ref = make_bn()
                     bn_dev = nn.BatchNorm2d(C)
                     bn_dev.load_state_dict(bn_ref.state_dict())

@@ -40,7 +40,8 @@ def _worker(rank, world, port, q):
     allreduce_mean_(buf)
     flat.scatter()
     w = shard_weights(16 if rank == 0 else 48)      # unequal per-GPU batches (BASELINE config 5)
-    q.put((rank, [p.grad.clone() for p in net.parameters()], mine, w))
+    # by value (numpy): tensors sent through a Queue travel as shared-memory handles that die with this process
+    q.put((rank, [p.grad.numpy().copy() for p in net.parameters()], [m.numpy().copy() for m in mine], w))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,8 +61,9 @@ def test_two_rank_gradient_mean():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    import numpy as np
     mean = [(a + b) / 2 for a, b in zip(res[0][1], res[1][1])]
     for r in range(world):
         for got, ref in zip(res[r][0], mean):
-            assert torch.allclose(got, ref, rtol=0, atol=1e-6)
+            assert np.allclose(got, ref, rtol=0, atol=1e-6)
     assert abs(res[0][2] - 0.5) < 1e-6 and abs(res[1][2] - 1.5) < 1e-6

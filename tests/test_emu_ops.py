@@ -17,8 +17,11 @@ def _emulated_kernels():
                                    checks.check_reduce_and_gate, checks.check_copies, checks.check_dilated_convs,
                                    checks.check_stage_kernels, checks.check_flat_adam], ids=lambda f: f.__name__)
 def test_operator(check):
-    check("cpu")
+    if check in (checks.check_contract, checks.check_norm_act):
+        check("cpu", quick=True)
+    else:
+        check("cpu")
 
 
 def test_stgcn_domain_small():
-    checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9), (2, 18, 16, 5, 7), (100, 3, 3, 45, 4)))
+    checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9), (2, 18, 16, 5, 7)))
