@@ -17,6 +17,7 @@
 //   sG [Cinp][PP]    graph product, PP = GT*Jp positions
 //   sWt[Cin][Coutp]  W transposed (fwd) / sW [Cout][Cinp] (bwd)
 #include "cg_common.h"
+#include <stdlib.h>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
@@ -202,6 +203,135 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_kernel(const float* _
           s += (double)v; sq += (double)v * (double)v;
         }
         if (ystats) { atomicAdd(&sStat[2 * co], s); atomicAdd(&sStat[2 * co + 1], sq); }
+      }
+    }
+  }
+  if (ystats) {
+    __syncthreads();
+    double* rep = ystats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * g.Cout;
+    for (int e = tid; e < 2 * g.Cout; e += nt) atomicAdd(&rep[e], sStat[e]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Matrix-core forward for wide layers (Cin, Cout >= 16): both products of a tile run on v_mfma_f32_16x16x4_f32
+// (exact f32 fma chains).  Per tile and group:   G (Cin x J) = X (Cin x J) . A (J x J)   then, over the whole tile,
+// Y (Cout x positions) = W (Cout x Cin) . G.   LDS images are padded so that every 16x16x4 fragment read is in
+// bounds and reads zeros outside the data:  sA [GT][Jk][Jg], sX [GT][Jk][XS] (channel fastest), sG [Cink][GT*Jg],
+// sWt [Cink][Coutm]   with Jk = J up to 4, Jg = J up to 16, Cink = Cin up to 4 (>= 16), Coutm = Cout up to 16.
+// ---------------------------------------------------------------------------------------------------------
+typedef float cg_dom_f32x4 __attribute__((vector_size(16)));
+
+struct CgDomMfma {
+  int Jk, Jg, PPg, Cink, Cinm, Coutm, XS;
+};
+
+__host__ __device__ static inline CgDomMfma cg_dom_mfma_geom(const CgDomainGeom& g) {
+  CgDomMfma m;
+  m.Jk = (g.J + 3) & ~3;
+  m.Jg = (g.J + 15) & ~15;
+  m.PPg = g.GT * m.Jg;
+  m.Cink = (g.Cin + 3) & ~3;
+  m.Cinm = (g.Cin + 15) & ~15;
+  m.Coutm = (g.Cout + 15) & ~15;
+  m.XS = m.Cinm + 4;
+  return m;
+}
+
+static size_t cg_dom_mfma_lds_bytes(const CgDomainGeom& g) {
+  const CgDomMfma m = cg_dom_mfma_geom(g);
+  const size_t f = (size_t)g.GT * m.Jk * m.Jg + (size_t)g.GT * m.Jk * m.XS + (size_t)m.Cinm * m.PPg + (size_t)m.Cink * m.Coutm;
+  return f * sizeof(float) + (size_t)2 * m.Coutm * sizeof(double) + 16;
+}
+
+template <int DOMAIN>
+__global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ adj,
+                                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                                       float* __restrict__ y, double* __restrict__ ystats, CgDomainGeom g) {
+  const CgDomMfma m = cg_dom_mfma_geom(g);
+  float* sA = reinterpret_cast<float*>(cg_dyn_lds);
+  float* sX = sA + g.GT * m.Jk * m.Jg;
+  float* sG = sX + g.GT * m.Jk * m.XS;
+  float* sWt = sG + m.Cinm * m.PPg;
+  double* sStat = reinterpret_cast<double*>(sWt + m.Cink * m.Coutm);
+
+  const int wg = cg_dom_logical_block(g);
+  if (wg < 0) return;
+  const long long TV = (long long)g.T * g.V;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int total = g.B * g.ntiles;
+  const int J = g.J, GT = g.GT;
+
+  for (int e = tid; e < m.Cink * m.Coutm; e += nt) {
+    const int co = e % m.Coutm, ci = e / m.Coutm;
+    sWt[e] = (co < g.Cout && ci < g.Cin) ? W[co * g.Cin + ci] : 0.f;
+  }
+  if (ystats) for (int e = tid; e < 2 * m.Coutm; e += nt) sStat[e] = 0.0;
+
+  for (int it = 0; it < g.per; ++it) {
+    const int lid = wg * g.per + it;
+    if (lid >= total) break;                     // uniform across the workgroup
+    const int b = lid / g.ntiles, tile = lid % g.ntiles;
+    const int g0 = tile * GT, ng = min(GT, g.NG - g0);
+    const float* xb = x + (long long)b * g.Cin * TV;
+    const float* ab = adj + ((long long)b * g.NG + g0) * J * J;
+    __syncthreads();                             // previous tile fully consumed
+    for (int e = tid; e < GT * m.Jk * m.Jg; e += nt) sA[e] = 0.f;
+    for (int e = tid; e < GT * m.Jk * m.XS; e += nt) sX[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < ng * J * J; e += nt) {            // adjacency slabs: contiguous (ng, J, J)
+      const int o = e % J, r = e / J, j = r % J, grp = r / J;
+      sA[(grp * m.Jk + j) * m.Jg + o] = ab[e];
+    }
+    if (DOMAIN == 1) {
+      const int run = ng * J;
+      for (int e = tid; e < g.Cin * run; e += nt) {
+        const int ci = e / run, r = e - ci * run, grp = r / J, j = r % J;
+        sX[(grp * m.Jk + j) * m.XS + ci] = xb[(long long)ci * TV + (long long)g0 * g.V + r];
+      }
+    } else {
+      for (int e = tid; e < g.Cin * J * ng; e += nt) {
+        const int grp = e % ng, r = e / ng, j = r % J, ci = r / J;
+        sX[(grp * m.Jk + j) * m.XS + ci] = xb[(long long)ci * TV + (long long)j * g.V + g0 + grp];
+      }
+    }
+    __syncthreads();
+
+    // graph product on the matrix cores: tiles (group, 16 channels, 16 outputs) dealt round-robin to the 4 waves
+    const int mt = m.Cinm / 16, ntl = m.Jg / 16;
+    for (int t = wv; t < GT * mt * ntl; t += 4) {
+      const int n0 = (t % ntl) * 16, r = t / ntl, m0 = (r % mt) * 16, grp = r / mt;
+      cg_dom_f32x4 acc = cg_dom_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* xa = sX + (grp * m.Jk + l4) * m.XS + m0 + l15;
+      const float* aa = sA + (grp * m.Jk + l4) * m.Jg + n0 + l15;
+      for (int k0 = 0; k0 < m.Jk; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[k0 * m.XS], aa[k0 * m.Jg], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sG[(m0 + 4 * l4 + q) * m.PPg + grp * m.Jg + n0 + l15] = acc[q];
+    }
+    __syncthreads();
+
+    // channel mix on the matrix cores: tiles (16 output channels, 16 positions)
+    float* yb = y + (long long)b * g.Cout * TV;
+    const int ct = m.Coutm / 16, pt = m.PPg / 16;
+    for (int t = wv; t < ct * pt; t += 4) {
+      const int n0 = (t % pt) * 16, m0 = (t / pt) * 16;
+      cg_dom_f32x4 acc = cg_dom_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wa = sWt + l4 * m.Coutm + m0 + l15;
+      const float* ga = sG + l4 * m.PPg + n0 + l15;
+      for (int k0 = 0; k0 < m.Cink; k0 += 4)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k0 * m.Coutm], ga[k0 * m.PPg], acc, 0, 0, 0);
+      const int pos = n0 + l15, grp = pos / m.Jg, o = pos % m.Jg;
+      const bool pos_ok = grp < ng && o < J;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = m0 + 4 * l4 + q;
+        if (co < g.Cout && pos_ok) {
+          const float v = acc[q] + (bias ? bias[co] : 0.f);
+          yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
+          if (ystats) { atomicAdd(&sStat[2 * co], (double)v); atomicAdd(&sStat[2 * co + 1], (double)v * (double)v); }
+        }
       }
     }
   }
@@ -413,7 +543,11 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   g.xt = Cin >= 16 ? 1 : 0;
   g.XS = g.Cinp + 4;
   // groups per tile: the largest tile that keeps the LDS image <= 64 KiB (two workgroups per CU) and
-  // the grid >= 1024 workgroups; a single group is accepted up to the full 160 KiB.
+  // the grid >= 1024 workgroups; a single group is accepted up to the full 160 KiB.  Small problems
+  // (fewer than 1024 single-group tiles) instead aim at one wave of ~256 workgroups: one round on the 256 CUs.
+  const long long tiles1 = (long long)B * g.NG;
+  const int want_wgs = tiles1 < 1024 ? 256 : 1024;
+  const char* env_gt = getenv("CG_DOM_GT");          // tuning aid (tools/bench_domain.py); unset in production
   int best = 0;
   for (int gt = 1; gt <= g.NG; ++gt) {
     g.GT = gt; g.PP = gt * g.Jp;
@@ -423,8 +557,9 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
       best = 1;
       continue;
     }
+    if (env_gt) { if (gt > atoi(env_gt) || bytes > 150 * 1024) break; best = gt; continue; }
     if (bytes > 64 * 1024) break;
-    if ((long long)B * ((g.NG + gt - 1) / gt) < 1024) break;
+    if ((long long)B * ((g.NG + gt - 1) / gt) < want_wgs) break;
     best = gt;
   }
   if (best == 0) return CG_ESHAPE;
@@ -437,6 +572,8 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   long long per = total / 2048;
   if (per < 1) per = 1;
   if (per > 16) per = 16;
+  const char* env_per = getenv("CG_DOM_PER");        // tuning aid
+  if (env_per) per = atoi(env_per) > 0 ? atoi(env_per) : per;
   g.per = (int)per;
   return CG_OK;
 }
@@ -447,6 +584,26 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
+  const bool mfma = Cin >= 16 && Cout >= 16 && getenv("CG_DOM_NO_MFMA") == nullptr;
+  if (mfma) {
+    // matrix-core path: its own LDS images; fit the tile to 64 KiB where possible
+    while (g.GT > 1 && cg_dom_mfma_lds_bytes(g) > 64 * 1024) { --g.GT; g.PP = g.GT * g.Jp; }
+    g.ntiles = (g.NG + g.GT - 1) / g.GT;
+    if (cg_dom_mfma_lds_bytes(g) > 160 * 1024 - 256) return CG_ESHAPE;
+    const long long total = (long long)B * g.ntiles;
+    if (getenv("CG_DOM_PER") == nullptr) { long long per = total / 2048; g.per = (int)(per < 1 ? 1 : (per > 16 ? 16 : per)); }
+    const size_t lds = cg_dom_mfma_lds_bytes(g);
+    const long long nwg = (total + g.per - 1) / g.per;
+    dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
+    if (lds > 48 * 1024) {
+      const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_mfma_kernel<0> : (const void*)cg_stgcn_domain_fwd_mfma_kernel<1>;
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_fwd_mfma_kernel<0>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
+    else hipLaunchKernelGGL(cg_stgcn_domain_fwd_mfma_kernel<1>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
+    return cg_launch_status();
+  }
   const size_t lds = cg_dom_lds_bytes(g, false);
   const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;
   dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
