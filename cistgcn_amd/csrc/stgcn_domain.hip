@@ -572,6 +572,9 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   long long per = total / 2048;
   if (per < 1) per = 1;
   if (per > 16) per = 16;
+  // space-domain forward: more tiles in flight per XCD than its 4 MiB L2 can hold let partially written y lines
+  // escape to HBM (PMC: 91 MB written per launch instead of 53 MB) -> one tile per workgroup there
+  if (domain == 0 && !bwd) per = 1;
   const char* env_per = getenv("CG_DOM_PER");        // tuning aid
   if (env_per) per = atoi(env_per) > 0 ? atoi(env_per) : per;
   g.per = (int)per;
@@ -584,7 +587,9 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
-  const bool mfma = Cin >= 16 && Cout >= 16 && getenv("CG_DOM_NO_MFMA") == nullptr;
+  // matrix cores pay off in the time domain (164 vs 243 us at C=64, B=256); in the space domain the kernel is bound by
+  // its 4-byte-column accesses, the MFMA variant is no faster there and measured 1.7x the HBM write traffic (PMC)
+  const bool mfma = Cin >= 16 && Cout >= 16 && domain == 1 && getenv("CG_DOM_NO_MFMA") == nullptr;
   if (mfma) {
     // matrix-core path: its own LDS images; fit the tile to 64 KiB where possible
     while (g.GT > 1 && cg_dom_mfma_lds_bytes(g) > 64 * 1024) { --g.GT; g.PP = g.GT * g.Jp; }

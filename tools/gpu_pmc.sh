@@ -18,7 +18,7 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
     tot, n = 0.0, 0
     for f in files:
         for r in csv.DictReader(open(f)):
-            if "cg_stgcn_domain_fwd_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cnt:
+            if "cg_stgcn_domain_fwd" in r.get("Kernel_Name", "") and r.get("Counter_Name") == cnt:
                 tot += float(r["Counter_Value"]); n += 1
     res[cnt] = {"sum": tot, "dispatches": n}
     print(cnt, "files", len(files), "dispatches", n, "sum", tot)
