@@ -180,20 +180,24 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
       for (int r = 0; r < 4; ++r) {
         const int mt = wm + 16 * i + 4 * l4 + r;          // row inside the tile
         const int m = m0 + mt;
-        if (m >= M) continue;
-        const float bv = (bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
-        const long long rowY = baseY + mY[m];
+        const bool row_ok = m < M;
+        const float bv = (row_ok && bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
+        const long long rowY = row_ok ? baseY + mY[m] : 0;
         double s = 0.0, q = 0.0;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + wn + 16 * j + l15;
-          if (n >= N) continue;
+          if (!row_ok || n >= N) continue;
           const float v = acc[i][j][r] + bv;
           if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
           else Y[rowY + nY[n]] = v;
           s += (double)v; q += (double)v * (double)v;
         }
-        if (stats != nullptr) { atomicAdd(&sStat[mt][0], s); atomicAdd(&sStat[mt][1], q); }
+        if (stats != nullptr) {      // the 16 lanes of a row reduce in registers, one LDS atomic per row and wave
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) { s += __shfl_down(s, off, 16); q += __shfl_down(q, off, 16); }
+          if (l15 == 0 && row_ok) { atomicAdd(&sStat[mt][0], s); atomicAdd(&sStat[mt][1], q); }
+        }
       }
     }
   } else {
@@ -226,20 +230,24 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + ty + 16 * i;
-      if (m >= M) continue;
-      const float bv = (bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
-      const long long rowY = baseY + mY[m];
+      const bool row_ok = m < M;
+      const float bv = (row_ok && bias != nullptr && sk == 0) ? bias[mB[m]] : 0.f;
+      const long long rowY = row_ok ? baseY + mY[m] : 0;
       double s = 0.0, q = 0.0;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + tx + 16 * j;
-        if (n >= N) continue;
+        if (!row_ok || n >= N) continue;
         const float v = acc[i][j] + bv;
         if (atomic_out) atomicAdd(&Y[rowY + nY[n]], v);
         else Y[rowY + nY[n]] = v;
         s += (double)v; q += (double)v * (double)v;
       }
-      if (stats != nullptr) { atomicAdd(&sStat[ty + 16 * i][0], s); atomicAdd(&sStat[ty + 16 * i][1], q); }
+      if (stats != nullptr) {        // tx = 0..15 share the row
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { s += __shfl_down(s, off, 16); q += __shfl_down(q, off, 16); }
+        if (tx == 0 && row_ok) { atomicAdd(&sStat[ty + 16 * i][0], s); atomicAdd(&sStat[ty + 16 * i][1], q); }
+      }
     }
   }
   if (stats != nullptr) {           // channel of row m = mB[m] (the bias / statistics index)

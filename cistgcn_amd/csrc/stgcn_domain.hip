@@ -327,10 +327,14 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_mfma_kernel(const flo
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = m0 + 4 * l4 + q;
-        if (co < g.Cout && pos_ok) {
-          const float v = acc[q] + (bias ? bias[co] : 0.f);
-          yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
-          if (ystats) { atomicAdd(&sStat[2 * co], (double)v); atomicAdd(&sStat[2 * co + 1], (double)v * (double)v); }
+        const bool ok = co < g.Cout && pos_ok;
+        const float v = ok ? acc[q] + (bias ? bias[co] : 0.f) : 0.f;
+        if (ok) yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
+        if (ystats) {          // the 16 lanes of a row hold the same channel: reduce them before touching LDS
+          float s1 = v, s2 = v * v;
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 16); s2 += __shfl_down(s2, off, 16); }
+          if (l15 == 0 && co < g.Cout) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
         }
       }
     }
