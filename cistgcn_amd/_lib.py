@@ -82,13 +82,13 @@ _SIGNATURES = {
     "cg_dstd_stats_fwd": [P, P, c_int, c_int, c_int, c_int, P],
     "cg_dstd_stats_bwd": [P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_se_gate_fwd": [P, P, P, P, c_int, c_int, c_int, P],
-    "cg_se_gate_bwd": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, P],
+    "cg_se_gate_bwd": [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_cumsum": [P, POINTER(View4), P, POINTER(View4), c_int, P],
     "cg_mpjpe_fwd": [P, P, P, LL, P],
     "cg_mpjpe_bwd": [P, P, P, P, LL, P],
     "cg_seed_bump": [P, P],
     "cg_stgcn_domain_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
-    "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cg_stgcn_domain_bwd_ws_floats": [c_int, c_int],
     "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],

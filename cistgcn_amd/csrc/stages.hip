@@ -275,15 +275,18 @@ extern "C" int cg_se_gate_fwd(const float* pooled, const float* W1, const float*
   return cg_launch_status();
 }
 
-// dW1 (H,C) and dW2 (C,H) are zeroed here and accumulated with f32 atomics over the batch.
+// dW1 (H,C) and dW2 (C,H) are accumulated with f32 atomics over the batch; they are zeroed here unless the caller
+// hands over zero-filled memory (prezeroed != 0: slices of a scratch pool cleared once per step).
 extern "C" int cg_se_gate_bwd(const float* pooled, const float* W1, const float* W2, const float* gate, const float* dgate,
-                              float* dpooled, float* dW1, float* dW2, int B, int C, int H, void* stream_) {
+                              float* dpooled, float* dW1, float* dW2, int B, int C, int H, int prezeroed, void* stream_) {
   if (!pooled || !W1 || !W2 || !gate || !dgate || !dpooled || !dW1 || !dW2) return CG_EARG;
   if (B <= 0 || C <= 0 || H <= 0) return CG_ESHAPE;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(dW1, 0, (size_t)C * H * 4, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(dW2, 0, (size_t)C * H * 4, stream);
-  if (e != hipSuccess) return (int)e;
+  if (!prezeroed) {
+    hipError_t e = hipMemsetAsync(dW1, 0, (size_t)C * H * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dW2, 0, (size_t)C * H * 4, stream);
+    if (e != hipSuccess) return (int)e;
+  }
   hipLaunchKernelGGL(cg_se_gate_bwd_kernel, dim3(B), dim3(64), (size_t)(2 * C + 2 * H) * 4, stream, pooled, W1, W2, gate, dgate, dpooled, dW1, dW2, C, H);
   return cg_launch_status();
 }

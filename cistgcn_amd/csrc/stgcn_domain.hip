@@ -632,14 +632,15 @@ extern "C" long long cg_stgcn_domain_bwd_ws_floats(int Cin, int Cout) {
 
 extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
                                    float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain,
-                                   void* stream_) {
+                                   int ws_prezeroed, void* stream_) {
   if (!x || !adj || !W || !dy || !dx || !dadj || !dW || !ws) return CG_EARG;
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, true);
   if (st != CG_OK) return st;
   hipStream_t stream = (hipStream_t)stream_;
   const int n_w = Cout * Cin, n_b = Cout;
-  hipError_t e = hipMemsetAsync(ws, 0, (size_t)CG_DOM_REPLICAS * (n_w + n_b) * sizeof(float), stream);
+  hipError_t e = hipSuccess;
+  if (!ws_prezeroed) e = hipMemsetAsync(ws, 0, (size_t)CG_DOM_REPLICAS * (n_w + n_b) * sizeof(float), stream);
   if (e != hipSuccess) return (int)e;
   const size_t lds = cg_dom_lds_bytes(g, true);
   const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;

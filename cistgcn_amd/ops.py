@@ -73,7 +73,34 @@ class _Arena:
         return s
 
 
+class _ZeroPool:
+    """Per-device f32 scratch that is all-zero at the start of every step (opt-in, see `step_scratch`): split-K /
+    accumulated contraction outputs, zero halos and replicated dW accumulators are carved from it, so that one
+    memset per step replaces one per launch (~110 graph nodes of the B=16 step).  A slice is valid until the next
+    `begin_step`; tensors that must outlive the step (parameter gradients) have to be consumed before it."""
+
+    def __init__(self, device, n):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.cur = 0
+        self.high = 0
+
+    def begin_step(self):
+        if self.high:
+            _lib.call("cg_zero", _ptr(self.buf), self.high * 4, _stream(self.buf))
+        self.cur = 0
+
+    def take(self, n):
+        n64 = (n + 63) & ~63                 # 256-byte slots
+        if self.cur + n64 > self.buf.numel():
+            return None
+        s = self.buf[self.cur:self.cur + n]
+        self.cur += n64
+        self.high = max(self.high, self.cur)
+        return s
+
+
 _arenas = {}
+_zero_pools = {}
 _seeds = {}
 _ARENA_CHECK = bool(int(__import__("os").environ.get("CISTGCN_ARENA_CHECK", "0")))
 
@@ -94,6 +121,30 @@ def _arena(device):
     return a
 
 
+def step_scratch(device, enable=True, floats=1 << 25):
+    """Opt in (or out) of the per-step zero pool on `device`.  Only for callers that run exactly one forward +
+    backward per `begin_step` and consume the gradients before the next one (runtime.GraphedStep / EagerStep):
+    gradients of that step may alias pool memory, which the next `begin_step` clears."""
+    device = _dev(device)
+    if enable:
+        if device not in _zero_pools:
+            _zero_pools[device] = _ZeroPool(device, int(floats))
+    else:
+        _zero_pools.pop(device, None)
+
+
+def _zeros(n, device):
+    """(flat zero-filled f32 tensor of n elements, True if it came from the step pool)"""
+    pool = _zero_pools.get(_dev(device)) if _zero_pools else None
+    if pool is not None:
+        s = pool.take(n)
+        if s is not None:
+            return s, True
+    z = torch.empty(n, dtype=torch.float32, device=device)
+    _lib.call("cg_zero", _ptr(z), n * 4, _stream(z))
+    return z, False
+
+
 def seed_state(device):
     device = _dev(device)
     s = _seeds.get(device)
@@ -110,6 +161,10 @@ def begin_step(device, bump_seed=False):
     """Start of a forward pass: re-zero the statistics scratch, optionally advance the dropout seed."""
     device = _dev(device)
     _arena(device).begin_step()
+    if _zero_pools:
+        pool = _zero_pools.get(device)
+        if pool is not None:
+            pool.begin_step()
     if bump_seed:
         s = seed_state(device)
         _lib.call("cg_seed_bump", _ptr(s), _stream(s))
@@ -192,7 +247,7 @@ def _label_strides(t, labels):
 
 class _Prep:
     """One contraction ready to launch: descriptor, output tensor, optional channel-sum slice."""
-    __slots__ = ("desc", "y", "stats", "zero")
+    __slots__ = ("desc", "y", "stats", "zero", "tag")
 
 
 def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None,
@@ -213,7 +268,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     sy = _label_strides(y, ly)
     p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label or stats_label, x.device, True)
     r = _Prep()
-    r.y, r.zero, r.stats = y, p.splitk > 1, None
+    r.y, r.zero, r.stats, r.tag = y, p.splitk > 1, None, spec
     if stats_label is not None and p.splitk == 1:
         r.stats = _arena(x.device).take(2 * sizes[stats_label] * _lib.STAT_REPLICAS)   # replicated f64 channel sums of y
     d = _lib.ContractDesc()
@@ -247,8 +302,7 @@ def _contract_launch(builders, device, groups=None):
         for key in order:
             offs[key] = total
             total += (slots[key] + 3) & ~3
-        zbuf = torch.empty(total, dtype=torch.float32, device=device)
-        _lib.call("cg_zero", _ptr(zbuf), total * 4, _stream(zbuf))
+        zbuf, _ = _zeros(total, device)
         for i, r in enumerate(probe):
             key = ("g", groups[i]) if groups[i] is not None else (("s", i) if r.zero else None)
             if key is None:
@@ -651,9 +705,10 @@ class _SEGate(torch.autograd.Function):
         H = w1.shape[0]
         dgate = dgate if dgate.is_contiguous() else _copy(dgate)
         dp = torch.empty_like(pooled)
-        dw1, dw2 = torch.empty_like(w1), torch.empty_like(w2)
+        dw, _ = _zeros(2 * C * H, pooled.device)
+        dw1, dw2 = dw[:C * H].view(w1.shape), dw[C * H:].view(w2.shape)
         _lib.call("cg_se_gate_bwd", _ptr(pooled), _ptr(w1), _ptr(w2), _ptr(gate), _ptr(dgate), _ptr(dp), _ptr(dw1),
-                  _ptr(dw2), B, C, H, _stream(pooled))
+                  _ptr(dw2), B, C, H, 1, _stream(pooled))
         return dp, dw1, dw2
 
 
@@ -766,8 +821,7 @@ def add3(a, b, c=None):
 def _halo(x, pad):
     """zero halo of `pad` on the last two axes of a (possibly strided) 4-D tensor"""
     B, C, H, W = x.shape
-    xp = torch.empty(B, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
-    _lib.call("cg_zero", _ptr(xp), xp.numel() * 4, _stream(x))
+    xp = _zeros(B * C * (H + 2 * pad) * (W + 2 * pad), x.device)[0].view(B, C, H + 2 * pad, W + 2 * pad)
     _add_into(xp[:, :, pad:pad + H, pad:pad + W], x)
     return xp
 
@@ -990,9 +1044,9 @@ class _StgcnDomain(torch.autograd.Function):
         dadj = torch.empty_like(adj)
         dw = torch.empty_like(w)
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
-        ws = torch.empty(_lib.lib().cg_stgcn_domain_bwd_ws_floats(Cin, Cout), dtype=torch.float32, device=x.device)
+        ws, _ = _zeros(_lib.lib().cg_stgcn_domain_bwd_ws_floats(Cin, Cout), x.device)
         _lib.call("cg_stgcn_domain_bwd", _ptr(x), _ptr(adj), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dadj), _ptr(dw), _ptr(db),
-                  _ptr(ws), B, Cin, Cout, T, V, ctx.domain, _stream(x))
+                  _ptr(ws), B, Cin, Cout, T, V, ctx.domain, 1, _stream(x))
         return dx, dadj, dw, db, None, None
 
 

@@ -148,6 +148,7 @@ class GraphedStep:
         # EXPERIMENTAL (off): independent branches on forked streams -> parallel graph branches.  ROCm 7.2's
         # hipStreamEndCapture crashes on this many forked streams (round-1 GPU run), so the step is one linear chain.
         model.branch_streams = bool(branches)
+        ops.step_scratch(x.device, True)       # one fwd+bwd per begin_step, gradients consumed before the next: pool is safe
         self.x, self.target = x.clone(), target.clone()
         self.params = [p for p in model.parameters() if p.requires_grad]
         side = torch.cuda.Stream()
@@ -183,6 +184,7 @@ class EagerStep:
     def __init__(self, model, x, target, flat=None):
         self.model, self.flat, self.x, self.target = model, flat, x, target
         self.params = [p for p in model.parameters() if p.requires_grad]
+        ops.step_scratch(x.device, True)
 
     def replay(self):
         for p in self.params:

@@ -135,7 +135,8 @@ int cg_dstd_stats_bwd(const float* x, const float* dout, float* dx, int B, int C
 /* SELayer excitation, SE.py:9-14,30-35: gate = sigmoid(W2 relu(W1 pooled)); W1 (H,C), W2 (C,H) */
 int cg_se_gate_fwd(const float* pooled, const float* W1, const float* W2, float* gate, int B, int C, int H, void* stream);
 int cg_se_gate_bwd(const float* pooled, const float* W1, const float* W2, const float* gate, const float* dgate,
-                   float* dpooled, float* dW1, float* dW2, int B, int C, int H, void* stream);
+                   float* dpooled, float* dW1, float* dW2, int B, int C, int H, int prezeroed, void* stream);
+/* prezeroed != 0: dW1/dW2 are already zero (slices of the per-step zero pool), no memset is issued */
 /* cumsum over axis 1 of a strided 4-D view (B,L,R1,R2), CISTGCN.py:589 (reverse = adjoint) */
 int cg_cumsum(const float* x, const CgView4* xv, float* y, const CgView4* yv, int reverse, void* stream);
 /* MPJPE, losses/losses.py:50-61 (reduce_axis=[]): pred/target contiguous (N,3); loss is one float */
@@ -153,13 +154,14 @@ int cg_seed_bump(unsigned long long* seed, void* stream);
  * run back to back without the intermediate G touching HBM.  Optional per-channel f64 sums of y
  * (ystats, [Cout][2], zero on entry) feed the train-mode BatchNorm that follows (:235).
  * Backward: dx, dAdj, dW, db from dy.  dW/db partial sums go through `ws`, a caller-owned scratch of
- * cg_stgcn_domain_bwd_ws_floats(Cin, Cout) floats (zeroed here; replicated accumulators keep the fp32
- * atomics off a single address), and are folded into dW/db by a second tiny kernel. */
+ * cg_stgcn_domain_bwd_ws_floats(Cin, Cout) floats (zeroed here unless ws_prezeroed != 0; replicated accumulators
+ * keep the fp32 atomics off a single address), and are folded into dW/db by a second tiny kernel. */
 int cg_stgcn_domain_fwd(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                         int B, int Cin, int Cout, int T, int V, int domain, void* stream);
 long long cg_stgcn_domain_bwd_ws_floats(int Cin, int Cout);
 int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj,
-                        float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain, void* stream);
+                        float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain,
+                        int ws_prezeroed, void* stream);
 
 /* ---- optimizer on the flat parameter buffer -----------------------------------
  * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,

@@ -288,6 +288,26 @@ def check_reduce_and_gate(device):
          [_rand(g, 4, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate")
 
 
+def check_zero_pool(device):
+    """Per-step zero pool (ops.step_scratch): split-K outputs, halos, SE / ST-GCN dW accumulators carved from one
+    buffer that begin_step clears - same results as with per-launch memsets, also on the second step (dirty pool)."""
+    ops.step_scratch(device, True, floats=1 << 20)
+    try:
+        for _ in range(2):
+            ops.begin_step(device)
+            pool = ops._zero_pools[ops._dev(device)]
+            g = _gen(11)
+            a, b = _rand(g, 3, 300, 7), _rand(g, 3, 300, 5)       # K = 900 -> split-K
+            _run(lambda a_, b_: ops.contract("bko,bkc->oc", a_, b_), lambda a_, b_: torch.einsum("bko,bkc->oc", a_, b_), [a, b],
+                 device, what="pooled split-K", rel=2e-5)
+            assert pool.cur > 0, "split-K output did not come from the pool"
+            check_reduce_and_gate(device)
+            check_dilated_convs(device)
+            check_stgcn_domain(device, shapes=((2, 3, 3, 6, 9),))
+    finally:
+        ops.step_scratch(device, False)
+
+
 def check_copies(device):
     g = _gen(4)
     a, b, c = _rand(g, 2, 3, 4, 5), _rand(g, 2, 6, 4, 5), _rand(g, 2, 2)
