@@ -49,7 +49,8 @@ class NormAct(ctypes.Structure):
 class ContractDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("bias", c_void_p), ("stats", c_void_p), ("tab", c_void_p),
                 ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("splitk", c_int), ("kchunk", c_int),
-                ("a_kfast", c_int), ("x_kfast", c_int), ("accumulate", c_int), ("x_vec", c_int), ("stat_ch", c_int), ("pad", c_int), ("block0", c_longlong)]
+                ("a_kfast", c_int), ("x_kfast", c_int), ("accumulate", c_int), ("x_vec", c_int), ("stat_ch", c_int), ("mode", c_int), ("block0", c_longlong),
+                ("ws", c_void_p)]
 
 
 class StatsArgs(ctypes.Structure):
@@ -65,6 +66,7 @@ LL = c_longlong
 _SIGNATURES = {
     "cg_contract": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, LL, P],
     "cg_contract_many": [POINTER(ContractDesc), c_int, P],
+    "cg_contract_kred_ws_floats": [c_int, c_int, c_int],
     "cg_chan_stats": [P, POINTER(View4), P, P, P],
     "cg_chan_stats_many": [POINTER(StatsArgs), c_int, P],
     "cg_norm_act_fwd_many": [POINTER(NormAct), c_int, P],

@@ -29,8 +29,10 @@ struct CgContractDesc {
   int G, M, N, K, splitk, kchunk, a_kfast, x_kfast;
   int accumulate;            // 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
   int x_vec;                 // 1: X is contiguous and 16-byte aligned along n in groups of four -> float4 loads
-  int stat_ch, pad;          // number of channels of `stats` (replica stride = 2 * stat_ch doubles)
+  int stat_ch;               // number of channels of `stats` (replica stride = 2 * stat_ch doubles)
+  int mode;                  // 0: tiled kernel below; 2: K-reduction kernel (weight gradients, see cg_kred_body)
   long long block0;          // first block id of this problem inside the launch
+  float* ws;                 // mode 2: zeroed scratch of cg_contract_kred_ws_floats(G, M, N) floats
 };
 #define CG_MAX_BATCH 16
 struct CgContractBatch { int n; int pad; CgContractDesc d[CG_MAX_BATCH]; };
@@ -257,7 +259,131 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
   }
 }
 
-__global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch batch) {
+// ---------------------------------------------------------------------------------------------
+// K-reduction variant (mode 2): weight gradients of the pointwise maps, Y[m,n] = sum_k A[m,k] X[n,k] with a
+// handful of outputs and K = batch x positions (1e4 .. 1e6).  Both operands are contiguous along k in aligned
+// groups of four, so every lane feeds the matrix cores straight from global memory with float4 loads: lane
+// (l15, l4) of a wave reads A[row 16i + l15][k0 + 4*l4 .. +3]; MFMA step s of a 16-k group then takes component s,
+// i.e. the four k-slots of one v_mfma_f32_16x16x4_f32 are k0 + 4*l4 + s for l4 = 0..3 (A and X agree on the
+// assignment, and a sum does not care about the order).  No LDS staging and no barrier inside the K loop; the
+// four waves of a workgroup take alternate 16-k groups.  Partial tiles are combined in LDS, added to one of
+// CG_KR_REPL zero-initialised replicas in `ws` (fp32 atomics, split / replicas contenders per address) and the
+// last workgroup of a tile folds the replicas into Y.  Output tiles are 16x16 or 32x32 (one or four MFMA tiles per
+// wave: at 64x64 the f32 matrix pipe, not HBM, would bound the loop).  Runs inside cg_contract_many_kernel, so a
+// batch that mixes both kinds of problem stays one launch.
+// ---------------------------------------------------------------------------------------------
+#define CG_KR_REPL 16
+#define CG_KR_QT 1024         // k quads staged per workgroup: kchunk <= 4096
+
+static inline int cg_kred_ti(int M, int N) { return (M > N ? M : N) <= 16 ? 1 : 2; }   // 16x16 or 32x32 output tiles
+
+template <int TI>
+__device__ __forceinline__ void cg_kred_body(const CgContractDesc& d, long long bid, float* red, int32_t* sQA, int32_t* sQX,
+                                             int* sLast) {
+  constexpr int BT = 16 * TI, LDR = BT + 1;
+  constexpr int U = 4;                               // 16-k groups in flight per wave (64 consecutive k)
+  const float* __restrict__ A = d.A; const float* __restrict__ X = d.X; float* __restrict__ Y = d.Y;
+  const int G = d.G, M = d.M, N = d.N, K = d.K, splitk = d.splitk, kchunk = d.kchunk;
+  const int32_t* gA = d.tab;
+  const int32_t* gX = gA + G;
+  const int32_t* gY = gX + G;
+  const int32_t* mA = gY + G;
+  const int32_t* mY = mA + M;
+  const int32_t* mB = mY + M;
+  const int32_t* nX = mB + M;
+  const int32_t* nY = nX + N;
+  const int32_t* kA = nY + N;
+  const int32_t* kX = kA + K;
+  const int tiles_n = (N + BT - 1) / BT, tiles_m = (M + BT - 1) / BT;
+  const int tn = (int)(bid % tiles_n); bid /= tiles_n;
+  const int tm = (int)(bid % tiles_m); bid /= tiles_m;
+  const int sk = (int)(bid % splitk);  bid /= splitk;
+  const int g = (int)bid;
+  const int m0 = tm * BT, n0 = tn * BT;
+  const int kbeg = sk * kchunk, kend = min(K, kbeg + kchunk);
+  const int nq = (kend - kbeg) >> 2;                  // K % 4 == 0 and kchunk % 16 == 0
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+
+  for (int q = tid; q < nq; q += 256) { sQA[q] = kA[kbeg + 4 * q]; sQX[q] = kX[kbeg + 4 * q]; }
+  for (int e = tid; e < BT * LDR; e += 256) red[e] = 0.f;
+  long long aoff[TI], xoff[TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i) {
+    const int m = m0 + 16 * i + l15, n = n0 + 16 * i + l15;
+    aoff[i] = m < M ? (long long)gA[g] + mA[m] : -1;
+    xoff[i] = n < N ? (long long)gX[g] + nX[n] : -1;
+  }
+  __syncthreads();
+
+  cg_f32x4 acc[TI][TI];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ngroups = (nq + 3) >> 2;
+  for (int t0 = wv * U; t0 < ngroups; t0 += 4 * U) {  // wave-uniform trip count
+    float4 av[U][TI], xv[U][TI];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = 4 * (t0 + u) + l4;
+      const bool ok = q < nq;
+      const int ka = ok ? sQA[q] : 0, kx = ok ? sQX[q] : 0;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        av[u][i] = (ok && aoff[i] >= 0) ? *reinterpret_cast<const float4*>(A + aoff[i] + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[u][i] = (ok && xoff[i] >= 0) ? *reinterpret_cast<const float4*>(X + xoff[i] + kx) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < TI; ++i) {
+        const float a4[4] = {av[u][i].x, av[u][i].y, av[u][i].z, av[u][i].w};
+#pragma unroll
+        for (int j = 0; j < TI; ++j) {
+          const float x4[4] = {xv[u][j].x, xv[u][j].y, xv[u][j].z, xv[u][j].w};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s4], x4[s4], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // four partial tiles -> one in LDS
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * i + 4 * l4 + r) * LDR + 16 * j + l15], acc[i][j][r]);
+  __syncthreads();
+  const long long gmn = (long long)G * M * N;
+  float* rep = d.ws + (long long)(sk % CG_KR_REPL) * gmn + (long long)g * M * N;
+  for (int e = tid; e < BT * BT; e += 256) {
+    const int mt = e / BT, nt = e % BT, m = m0 + mt, n = n0 + nt;
+    if (m < M && n < N) atomicAdd(&rep[(long long)m * N + n], red[mt * LDR + nt]);
+  }
+  __threadfence();                                    // this workgroup's adds are visible before it is counted
+  __syncthreads();
+  unsigned int* cnt = reinterpret_cast<unsigned int*>(d.ws + (long long)CG_KR_REPL * gmn) + ((long long)g * tiles_m + tm) * tiles_n + tn;
+  if (tid == 0) *sLast = atomicAdd(cnt, 1u) == (unsigned int)(splitk - 1);
+  __syncthreads();
+  if (*sLast) {                                       // every split of this tile has been added: fold the replicas
+    __threadfence();
+    const volatile float* wsv = d.ws + (long long)g * M * N;
+    const int nrep = splitk < CG_KR_REPL ? splitk : CG_KR_REPL;
+    const long long baseY = gY[g];
+    for (int e = tid; e < BT * BT; e += 256) {
+      const int mt = e / BT, nt = e % BT, m = m0 + mt, n = n0 + nt;
+      if (m >= M || n >= N) continue;
+      float sum = d.bias != nullptr ? d.bias[mB[m]] : 0.f;
+      for (int r = 0; r < nrep; ++r) sum += wsv[r * gmn + (long long)m * N + n];
+      if (d.accumulate) atomicAdd(&Y[baseY + mY[m] + nY[n]], sum);
+      else Y[baseY + mY[m] + nY[n]] = sum;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 5) void cg_contract_many_kernel(CgContractBatch batch) {
   constexpr int kTile = CG_BK * CG_LDT > CG_BK_THIN * 65 ? CG_BK * CG_LDT : CG_BK_THIN * 65;
   __shared__ float As[kTile];                          // wide tile: BK x 80; thin tile: BK_THIN x 17
   __shared__ float Xs[kTile];                          // wide tile: BK x 80; thin tile: BK_THIN x 65
@@ -270,11 +396,29 @@ __global__ __launch_bounds__(256) void cg_contract_many_kernel(CgContractBatch b
     if (bid >= batch.d[i].block0) pi = i;
   const CgContractDesc& d = batch.d[pi];
   bid -= d.block0;
-  if (d.M <= 16) cg_contract_body<16, 1, CG_BK_THIN>(d, bid, As, Xs, sKA, sKX, sStat);
+  if (d.mode == 2) {                                   // K-reduction problems reuse the tile / table storage
+    static_assert(CG_KT >= CG_KR_QT && kTile >= 32 * 33, "LDS reuse");
+    if ((d.M > d.N ? d.M : d.N) <= 16) cg_kred_body<1>(d, bid, As, sKA, sKX, reinterpret_cast<int*>(sStat));
+    else cg_kred_body<2>(d, bid, As, sKA, sKX, reinterpret_cast<int*>(sStat));
+  }
+  else if (d.M <= 16) cg_contract_body<16, 1, CG_BK_THIN>(d, bid, As, Xs, sKA, sKX, sStat);
   else cg_contract_body<64, 4, CG_BK>(d, bid, As, Xs, sKA, sKX, sStat);
 }
 
+// include/cistgcn_hip.h : floats of zeroed scratch a mode-2 problem needs (replicas + per-tile arrival counters)
+extern "C" long long cg_contract_kred_ws_floats(int G, int M, int N) {
+  if (G <= 0 || M <= 0 || N <= 0) return 0;
+  const int bt = 16 * cg_kred_ti(M, N);
+  return (long long)CG_KR_REPL * G * M * N + (long long)G * ((M + bt - 1) / bt) * ((N + bt - 1) / bt);
+}
+
 static long long cg_contract_blocks(CgContractDesc& d) {
+  if (d.mode == 2) {
+    const int bt = 16 * cg_kred_ti(d.M, d.N);
+    const int kchunk = (d.K + d.splitk - 1) / d.splitk;
+    d.kchunk = ((kchunk + 15) / 16) * 16;
+    return (long long)((d.N + bt - 1) / bt) * ((d.M + bt - 1) / bt) * d.splitk * d.G;
+  }
   int kchunk = (d.K + d.splitk - 1) / d.splitk;
   const int bk = d.M <= 16 ? CG_BK_THIN : CG_BK;
   d.kchunk = ((kchunk + bk - 1) / bk) * bk;
@@ -296,10 +440,28 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
     if (d.stats && (d.splitk > 1 || d.accumulate)) return CG_EARG;
     if (d.x_vec && ((d.N & 3) || ((uintptr_t)d.X & 15))) return CG_EARG;
     if (d.stats && d.stat_ch <= 0) return CG_EARG;
-    d.block0 = total;
-    total += cg_contract_blocks(d);
+    if (d.mode != 0 && d.mode != 2) return CG_EARG;
+    if (d.mode == 2) {
+      if (!d.ws || d.stats || (d.K & 3) || (((uintptr_t)d.A | (uintptr_t)d.X) & 15)) return CG_EARG;
+      if ((d.K + d.splitk - 1) / d.splitk > 4 * CG_KR_QT - 16) return CG_ESHAPE;
+    }
     batch.d[i] = d;
   }
+  // K-reduction problems have few, long-running workgroups: give them the lowest block ids so that they start first
+  // and the short tile workgroups of the other problems fill in around them (the kernel finds a problem by scanning
+  // for the largest block0 <= block id, so block0 must ascend with the position in the batch: reorder the batch).
+  CgContractBatch sorted;
+  sorted.n = n; sorted.pad = 0;
+  int w = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int i = 0; i < n; ++i)
+      if ((batch.d[i].mode == 2) == (pass == 0)) {
+        sorted.d[w] = batch.d[i];
+        sorted.d[w].block0 = total;
+        total += cg_contract_blocks(sorted.d[w]);
+        ++w;
+      }
+  batch = sorted;
   if (total > 2147483647LL) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_contract_many_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, batch);
   return cg_launch_status();
@@ -320,6 +482,6 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
-  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.stat_ch = M; d.pad = 0; d.block0 = 0;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.stat_ch = M; d.mode = 0; d.block0 = 0; d.ws = nullptr;
   return cg_contract_many(&d, 1, stream_);
 }

@@ -174,7 +174,7 @@ def begin_step(device, bump_seed=False):
 # generic contraction
 # ----------------------------------------------------------------------------------------------
 class _Plan:
-    __slots__ = ("tables", "G", "M", "N", "K", "splitk", "a_kfast", "x_kfast", "dense", "x_vec")
+    __slots__ = ("tables", "G", "M", "N", "K", "splitk", "a_kfast", "x_kfast", "dense", "x_vec", "mode", "ws_floats")
 
 
 _plans = {}
@@ -192,9 +192,9 @@ def _min_stride(labels, sizes, strides):
     return min(vals) if vals else None
 
 
-def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense):
+def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense, aligned=False):
     key = (tuple(sorted(sizes.items())), la, lx, ly, tuple(sorted(sa.items())), tuple(sorted(sx.items())),
-           tuple(sorted(sy.items())), oa, ox, oy, bias_label, str(device), y_dense)
+           tuple(sorted(sy.items())), oa, ox, oy, bias_label, str(device), y_dense, aligned)
     p = _plans.get(key)
     if p is not None:
         return p
@@ -230,13 +230,41 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
     blocks = p.G * ((p.M + (15 if p.M <= 16 else 63)) // (16 if p.M <= 16 else 64)) * ((p.N + 63) // 64)
     p.splitk = 1
     p.dense = y_dense
-    if y_dense and p.K >= 256 and blocks < 512:
+    p.mode, p.ws_floats = 0, 0
+    if y_dense and p.K >= 256 and blocks < 512 and aligned and _KRED and _kred_ok(p, tabs):
+        # weight gradient of a pointwise map: K-reduction kernel (float4 along k straight into the matrix cores,
+        # replicated partial sums folded by the last workgroup)
+        bt = 16 if max(p.M, p.N) <= 16 else 32
+        tiles = p.G * ((p.M + bt - 1) // bt) * ((p.N + bt - 1) // bt)
+        p.mode = 2
+        p.splitk = int(max(1, (p.K + 4063) // 4064, min(512, (p.K + 255) // 256, max(1, _KRED_BLOCKS // tiles))))
+        p.ws_floats = int(_lib.lib().cg_contract_kred_ws_floats(p.G, p.M, p.N))
+    elif y_dense and p.K >= 256 and blocks < 512:
         # few output tiles and a long reduction (weight / bias gradients): spread K over workgroups
         # every split adds its tile with fp32 atomics: splitk blocks serialise on each output address (~0.1 us each on
         # MI355X) while each block walks K/splitk in ~1 us steps of 16 -> balance at splitk ~ sqrt(K/2)
         p.splitk = int(max(1, min((p.K + 63) // 64, (1024 + blocks - 1) // blocks, int((p.K / 2.0) ** 0.5))))
     _plans[key] = p
     return p
+
+
+_KRED = bool(int(__import__("os").environ.get("CISTGCN_KRED", "1")))     # tuning aid: 0 = always the tiled split-K path
+_KRED_BLOCKS = int(__import__("os").environ.get("CISTGCN_KRED_BLOCKS", "128"))
+_KRED_MAX = int(__import__("os").environ.get("CISTGCN_KRED_MAX", "64"))
+
+
+def _quads(tab):
+    """offsets contiguous in 16-byte aligned groups of four"""
+    if tab.size % 4:
+        return False
+    q = tab.reshape(-1, 4)
+    return bool((np.diff(q, axis=1) == 1).all() and (q[:, 0] % 4 == 0).all())
+
+
+def _kred_ok(p, tabs):
+    if p.K % 4 or p.G * p.M * p.N > 65536 or max(p.M, p.N) > _KRED_MAX:
+        return False
+    return (_quads(tabs[8]) and _quads(tabs[9]) and all((tabs[i] % 4 == 0).all() for i in (0, 1, 3, 6)))
 
 
 def _label_strides(t, labels):
@@ -247,7 +275,7 @@ def _label_strides(t, labels):
 
 class _Prep:
     """One contraction ready to launch: descriptor, output tensor, optional channel-sum slice."""
-    __slots__ = ("desc", "y", "stats", "zero", "tag")
+    __slots__ = ("desc", "y", "stats", "zero", "tag", "ws_floats")
 
 
 def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None,
@@ -266,10 +294,13 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     shape = [sizes[l] for l in ly]
     y = out.view(shape) if out is not None else torch.empty(shape, dtype=torch.float32, device=x.device)
     sy = _label_strides(y, ly)
-    p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label or stats_label, x.device, True)
+    p = _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, 0, bias_label or stats_label, x.device, True,
+              a.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
     r = _Prep()
-    r.y, r.zero, r.stats, r.tag = y, p.splitk > 1, None, spec
-    if stats_label is not None and p.splitk == 1:
+    kred = p.mode == 2
+    r.y, r.zero, r.stats, r.tag = y, (p.splitk > 1 and not kred), None, spec
+    r.ws_floats = p.ws_floats
+    if stats_label is not None and p.splitk == 1 and p.mode == 0:
         r.stats = _arena(x.device).take(2 * sizes[stats_label] * _lib.STAT_REPLICAS)   # replicated f64 channel sums of y
     d = _lib.ContractDesc()
     d.A, d.X, d.Y, d.tab = a.data_ptr(), x.data_ptr(), y.data_ptr(), p.tables.data_ptr()
@@ -278,6 +309,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     d.G, d.M, d.N, d.K, d.splitk, d.a_kfast, d.x_kfast = p.G, p.M, p.N, p.K, p.splitk, p.a_kfast, p.x_kfast
     d.x_vec = 1 if (p.x_vec and x.data_ptr() % 16 == 0) else 0
     d.stat_ch = sizes[stats_label] if stats_label is not None else 0
+    d.mode, d.ws = p.mode, None          # the launcher points ws at zeroed scratch
     r.desc = d
     return r
 
@@ -297,6 +329,9 @@ def _contract_launch(builders, device, groups=None):
         if key is not None and key not in slots:
             slots[key] = r.y.numel()
             order.append(key)
+        if r.ws_floats:
+            slots[("w", i)] = r.ws_floats
+            order.append(("w", i))
     if order:
         offs, total = {}, 0
         for key in order:
@@ -305,13 +340,14 @@ def _contract_launch(builders, device, groups=None):
         zbuf, _ = _zeros(total, device)
         for i, r in enumerate(probe):
             key = ("g", groups[i]) if groups[i] is not None else (("s", i) if r.zero else None)
-            if key is None:
-                continue
-            stats = r.stats
-            probe[i] = builders[i](zbuf[offs[key]:offs[key] + slots[key]])
-            probe[i].stats = stats
-            if groups[i] is not None:
-                probe[i].desc.accumulate = 1
+            if key is not None:
+                stats = r.stats
+                probe[i] = builders[i](zbuf[offs[key]:offs[key] + slots[key]])
+                probe[i].stats = stats
+                if groups[i] is not None:
+                    probe[i].desc.accumulate = 1
+            if r.ws_floats:
+                probe[i].desc.ws = zbuf[offs[("w", i)]:].data_ptr()
     for c0 in range(0, len(probe), _MAX_CONTRACT_BATCH):
         chunk = probe[c0:c0 + _MAX_CONTRACT_BATCH]
         arr = (_lib.ContractDesc * len(chunk))(*[r.desc for r in chunk])

@@ -62,10 +62,15 @@ typedef struct CgContractDesc {
   int G, M, N, K, splitk, kchunk /* set by the library */, a_kfast, x_kfast;
   int accumulate;                /* 1: fp32 atomic adds into a zeroed Y shared by several problems */
   int x_vec;                     /* 1: X contiguous + 16-byte aligned along n in groups of four (float4 loads) */
-  int stat_ch, pad;              /* channels of `stats`: it holds CG_STAT_REPLICAS x stat_ch x 2 doubles */
+  int stat_ch;                   /* channels of `stats`: it holds CG_STAT_REPLICAS x stat_ch x 2 doubles */
+  int mode;                      /* 0: tiled kernel.  2: K-reduction kernel for weight gradients (few outputs, K = batch x
+                                    positions): requires K % 4 == 0, A and X contiguous along k in 16-byte aligned groups of
+                                    four, no `stats`, K / splitk <= 4080, and `ws` */
   long long block0;              /* set by the library */
+  float* ws;                     /* mode 2: ZEROED scratch of cg_contract_kred_ws_floats(G, M, N) floats */
 } CgContractDesc;
 int cg_contract_many(const CgContractDesc* descs, int n, void* stream);
+long long cg_contract_kred_ws_floats(int G, int M, int N);
 
 /* ---- per-channel statistics and the fused BatchNorm / Dropout / PReLU row kernel ---------------
  * stats[c] = { sum, sum of squares } over batch and positions of x*pre (f64, must be zero on entry).

@@ -288,6 +288,31 @@ def check_reduce_and_gate(device):
          [_rand(g, 4, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate")
 
 
+def check_contract_kred(device):
+    """weight-gradient shaped contractions (few outputs, long contiguous reduction) take the K-reduction kernel:
+    one / four matrix-core tiles per wave, ragged edges, several output tiles, batch index, bias"""
+    g = _gen(12)
+    cases = [
+        ("bohw,bchw->oc", (3, 7, 8, 12), (3, 5, 8, 12), None),          # 16x16 tile, K = 288
+        ("bohw,bchw->oc", (2, 22, 20, 20), (2, 22, 20, 20), None),       # 32x32 tile, K = 800
+        ("bohw,bchw->oc", (2, 40, 16, 32), (2, 60, 16, 32), None),       # 2 x 2 tiles of 32x32, K = 1024
+        ("gok,gck->goc", (3, 9, 512), (3, 6, 512), None),                # batch index
+        ("ok,ck->oc", (18, 5000), (33, 5000), 18),                       # several splits per replica, bias
+    ]
+    for spec, sa, sx, nb in cases:
+        a, x = _rand(g, *sa), _rand(g, *sx)
+        bias = _rand(g, nb) if nb else None
+        before = {k for k, p in ops._plans.items() if p.mode == 2}
+        if bias is None:
+            _run(lambda a_, x_: ops.contract(spec, a_, x_), lambda a_, x_: torch.einsum(spec, a_, x_), [a, x], device,
+                 what="kred " + spec, rel=3e-5)
+        else:
+            _run(lambda a_, x_, b_: ops.contract(spec, a_, x_, b_, "o"), lambda a_, x_, b_: torch.einsum(spec, a_, x_) + b_[:, None],
+                 [a, x, bias], device, what="kred+bias " + spec, rel=3e-5)
+        assert {k for k, p in ops._plans.items() if p.mode == 2} - before or before, "K-reduction plan was not selected for " + spec
+    assert any(p.mode == 2 for p in ops._plans.values())
+
+
 def check_zero_pool(device):
     """Per-step zero pool (ops.step_scratch): split-K outputs, halos, SE / ST-GCN dW accumulators carved from one
     buffer that begin_step clears - same results as with per-launch memsets, also on the second step (dirty pool)."""

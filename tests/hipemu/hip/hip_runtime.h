@@ -100,6 +100,8 @@ static inline T hipemu_atomic_add_fp(T* p, T v) {
 static inline float atomicAdd(float* p, float v) { return hipemu_atomic_add_fp(p, v); }
 static inline double atomicAdd(double* p, double v) { return hipemu_atomic_add_fp(p, v); }
 static inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
