@@ -62,8 +62,19 @@ __device__ __forceinline__ uint32_t cg_rand_u32(unsigned long long seed, unsigne
   return (uint32_t)(z >> 32);
 }
 
-// keep-scale for dropout: 0 (dropped) or 1/(1-p)
+// Dropout keep-scale: 0 (dropped) or 1/(1-p).  One 64-bit hash serves four consecutive elements (16 bits each), so
+// the vectorised row kernels draw once per float4; the scalar path derives the same bits from (idx >> 2, idx & 3).
+// The drop probability is therefore quantised to 1/65536.
+__device__ __forceinline__ unsigned long long cg_drop_bits(unsigned long long seed, unsigned int salt, unsigned long long quad) {
+  unsigned long long z = quad + seed * 0x9E3779B97F4A7C15ull + ((unsigned long long)salt << 40) + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float cg_drop_pick(unsigned long long bits, int j, float p) {
+  const uint32_t thr = (uint32_t)(p * 65536.0f);
+  return ((uint32_t)(bits >> (16 * j)) & 0xFFFFu) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+}
 __device__ __forceinline__ float cg_drop_scale(float p, unsigned long long seed, unsigned int salt, unsigned long long idx) {
-  const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
-  return cg_rand_u32(seed, salt, idx) >= thr ? 1.0f / (1.0f - p) : 0.0f;
+  return cg_drop_pick(cg_drop_bits(seed, salt, idx >> 2), (int)(idx & 3), p);
 }

@@ -30,7 +30,11 @@ __device__ __forceinline__ long long cg_row_base(const CgView4& v, int b, int c)
 // are amortised (a (B,C) BatchNorm1d input becomes one workgroup per channel)
 static int cg_rows_per_block(const CgView4& v) {
   const long long P = v.n[2] * v.n[3];
-  long long rb = 4096 / (P > 0 ? P : 1);
+  // large tensors: ~2048 workgroups (8 per CU), up to 32 K elements each, so that the per-workgroup prologue
+  // (replica fold, affine) and epilogue (block sums, atomics) stay small next to the streaming part
+  long long target = (v.n[0] * v.n[1] * P) / 2048;
+  target = target < 4096 ? 4096 : (target > 32768 ? 32768 : target);
+  long long rb = target / (P > 0 ? P : 1);
   if (rb < 1) rb = 1;
   if (rb > v.n[0]) rb = v.n[0];
   // small problems: keep at least ~512 workgroups in flight rather than amortising
@@ -155,7 +159,24 @@ struct CgNormAct {
 // nn.BatchNorm does); the folded form v*scale + (beta - mean*scale) cancels catastrophically when
 // |mean| >> std.
 struct CgChanAffine { float scale, shift, mean, rstd; };
-struct CgNormActBatch { int n; int rb[CG_ROW_MAX_BATCH]; int pad; CgNormAct a[CG_ROW_MAX_BATCH]; };
+// vec[i] != 0: every view the kernel touches is a contiguous-row NCHW view (s[3] = 1, s[2] = n[3]) with P % 4 == 0 and
+// 16-byte aligned rows -> float4 path, no per-element index arithmetic
+struct CgNormActBatch { int n; int rb[CG_ROW_MAX_BATCH]; int vec[CG_ROW_MAX_BATCH]; int pad; CgNormAct a[CG_ROW_MAX_BATCH]; };
+
+static bool cg_view_vec(const void* ptr, const CgView4& v) {
+  if (!ptr) return true;
+  const long long P = v.n[2] * v.n[3];
+  const bool rows = v.s[3] == 1 && (v.s[2] == v.n[3] || v.n[2] == 1);
+  return rows && (P & 3) == 0 && (v.s[0] & 3) == 0 && (v.s[1] & 3) == 0 && ((uintptr_t)ptr & 15) == 0;
+}
+// kind: 0 forward, 1 backward reduce, 2 backward apply
+static int cg_norm_act_vec(const CgNormAct& a, int kind) {
+  bool ok = cg_view_vec(a.x, a.xv) && cg_view_vec(a.add, a.av);
+  if (kind == 0) ok = ok && cg_view_vec(a.y, a.yv);
+  else ok = ok && cg_view_vec(a.dy, a.dyv);
+  if (kind == 2) ok = ok && cg_view_vec(a.dx, a.dxv) && cg_view_vec(a.dadd, a.dav);
+  return ok ? 1 : 0;
+}
 
 __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c, bool backward) {
   CgChanAffine r;
@@ -194,6 +215,15 @@ __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c
   return r;
 }
 
+__device__ __forceinline__ float cg_norm_act_y(const CgNormAct& a, const CgChanAffine& af, float alpha, float xval, float w,
+                                               float keep, float ad) {
+  float u = ((xval * w - af.mean) * af.scale + af.shift) * keep;
+  if (a.add && !a.add_post) u += ad;
+  if (a.alpha) u = u > 0.f ? u : alpha * u;
+  if (a.add && a.add_post) u += ad;
+  return u;
+}
+
 __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   const CgNormAct& a = batch.a[blockIdx.z];
   const int rb = batch.rb[blockIdx.z];
@@ -204,21 +234,41 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   const int nb = min(rb, (int)a.xv.n[0] - b0);
   const CgChanAffine af = cg_chan_affine(a, c, false);
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
-  const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
+  const bool drop = a.drop_p > 0.f;
+  const unsigned long long seed = drop ? *a.seed : 0ull;
   __shared__ double red[32];
   double ys = 0.0, yq = 0.0;
-  CG_CHUNK_LOOP(nb, P, e) {
-    CG_CHUNK_ROW(e, P, b0)
-    CG_POS(a.xv, p)
-    const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
-    float u = (a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)] * w - af.mean) * af.scale + af.shift;
-    if (a.drop_p > 0.f) u *= cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
-    const float ad = a.add ? a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)] : 0.f;
-    if (a.add && !a.add_post) u += ad;
-    if (a.alpha) u = u > 0.f ? u : alpha * u;
-    if (a.add && a.add_post) u += ad;
-    a.y[cg_row_base(a.yv, b, c) + CG_OFF(a.yv)] = u;
-    ys += (double)u; yq += (double)u * (double)u;
+  if (batch.vec[blockIdx.z]) {
+    const int P4 = P >> 2;
+    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
+      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+      const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+      const float4 xv4 = *reinterpret_cast<const float4*>(a.x + cg_row_base(a.xv, b, c) + p);
+      float4 ad4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.add) ad4 = *reinterpret_cast<const float4*>(a.add + cg_row_base(a.av, b, c) + p);
+      const unsigned long long bits = drop ? cg_drop_bits(seed, a.salt, (((unsigned long long)b * C + c) * P + p) >> 2) : 0ull;
+      float4 y4;
+      y4.x = cg_norm_act_y(a, af, alpha, xv4.x, w, drop ? cg_drop_pick(bits, 0, a.drop_p) : 1.f, ad4.x);
+      y4.y = cg_norm_act_y(a, af, alpha, xv4.y, w, drop ? cg_drop_pick(bits, 1, a.drop_p) : 1.f, ad4.y);
+      y4.z = cg_norm_act_y(a, af, alpha, xv4.z, w, drop ? cg_drop_pick(bits, 2, a.drop_p) : 1.f, ad4.z);
+      y4.w = cg_norm_act_y(a, af, alpha, xv4.w, w, drop ? cg_drop_pick(bits, 3, a.drop_p) : 1.f, ad4.w);
+      *reinterpret_cast<float4*>(a.y + cg_row_base(a.yv, b, c) + p) = y4;
+      if (a.ystats) {
+        ys += ((double)y4.x + (double)y4.y) + ((double)y4.z + (double)y4.w);
+        yq += ((double)y4.x * (double)y4.x + (double)y4.y * (double)y4.y) + ((double)y4.z * (double)y4.z + (double)y4.w * (double)y4.w);
+      }
+    }
+  } else {
+    CG_CHUNK_LOOP(nb, P, e) {
+      CG_CHUNK_ROW(e, P, b0)
+      CG_POS(a.xv, p)
+      const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+      const float keep = drop ? cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p) : 1.f;
+      const float ad = a.add ? a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)] : 0.f;
+      const float u = cg_norm_act_y(a, af, alpha, a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)], w, keep, ad);
+      a.y[cg_row_base(a.yv, b, c) + CG_OFF(a.yv)] = u;
+      ys += (double)u; yq += (double)u * (double)u;
+    }
   }
   if (a.ystats) {      // uniform per problem: every thread of the workgroup takes this branch
     ys = cg_block_sum(ys, red);
@@ -230,19 +280,48 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   }
 }
 
-// gradient at the affine output (after PReLU and dropout are undone); also returns pre-activation u
+// gradient at the affine output (after PReLU and dropout are undone) from loaded values; also returns the gated
+// input v, the pre-activation u and the gradient gu in front of the PReLU
+__device__ __forceinline__ float cg_norm_act_gh_val(const CgNormAct& a, const CgChanAffine& af, float alpha, float xval, float w,
+                                                    float keep, float ad, float g, float& v, float& u, float& gu) {
+  v = xval * w;
+  u = ((v - af.mean) * af.scale + af.shift) * keep;
+  if (a.add && !a.add_post) u += ad;
+  gu = a.alpha ? (u > 0.f ? g : alpha * g) : g;
+  return gu * keep;
+}
+
 __device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChanAffine& af, float alpha,
                                                 unsigned long long seed, int b, int c, long long C, int P,
                                                 int p, int i2_, int i3_, float& w, float& v, float& u, float& gu, float& g) {
   w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
-  v = a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)] * w;
-  float keep = 1.f;
-  if (a.drop_p > 0.f) keep = cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p);
-  u = ((v - af.mean) * af.scale + af.shift) * keep;
-  if (a.add && !a.add_post) u += a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)];
+  const float keep = a.drop_p > 0.f ? cg_drop_scale(a.drop_p, seed, a.salt, ((unsigned long long)b * C + c) * P + p) : 1.f;
+  const float ad = (a.add && !a.add_post) ? a.add[cg_row_base(a.av, b, c) + CG_OFF(a.av)] : 0.f;
   g = a.dy[cg_row_base(a.dyv, b, c) + CG_OFF(a.dyv)];
-  gu = a.alpha ? (u > 0.f ? g : alpha * g) : g;
-  return gu * keep;
+  return cg_norm_act_gh_val(a, af, alpha, a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)], w, keep, ad, g, v, u, gu);
+}
+
+// the four lanes of a float4: loads for the vector path of both backward passes
+struct CgNaQuad { float x[4], ad[4], g[4], keep[4]; float w; };
+__device__ __forceinline__ CgNaQuad cg_norm_act_quad(const CgNormAct& a, unsigned long long seed, int b, int c, long long C, int P, int p) {
+  CgNaQuad q;
+  q.w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
+  const float4 x4 = *reinterpret_cast<const float4*>(a.x + cg_row_base(a.xv, b, c) + p);
+  const float4 g4 = *reinterpret_cast<const float4*>(a.dy + cg_row_base(a.dyv, b, c) + p);
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.add && !a.add_post) a4 = *reinterpret_cast<const float4*>(a.add + cg_row_base(a.av, b, c) + p);
+  q.x[0] = x4.x; q.x[1] = x4.y; q.x[2] = x4.z; q.x[3] = x4.w;
+  q.g[0] = g4.x; q.g[1] = g4.y; q.g[2] = g4.z; q.g[3] = g4.w;
+  q.ad[0] = a4.x; q.ad[1] = a4.y; q.ad[2] = a4.z; q.ad[3] = a4.w;
+  if (a.drop_p > 0.f) {
+    const unsigned long long bits = cg_drop_bits(seed, a.salt, (((unsigned long long)b * C + c) * P + p) >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q.keep[j] = cg_drop_pick(bits, j, a.drop_p);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q.keep[j] = 1.f;
+  }
+  return q;
 }
 
 // pass 1 of backward: per-channel sums of g and g*xhat (f64), d alpha
@@ -259,14 +338,30 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormActBatch batch) {
   const float alpha = a.alpha ? a.alpha[a.alpha_n == 1 ? 0 : c] : 1.f;
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
-  CG_CHUNK_LOOP(nb, P, e) {
-    CG_CHUNK_ROW(e, P, b0)
-    CG_POS(a.xv, p)
-    float w, v, u, gu, g;
-    const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
-    s1 += (double)gh;
-    s2 += (double)gh * (double)((v - af.mean) * af.rstd);
-    if (a.alpha && !(u > 0.f)) sa += (double)g * (double)u;
+  if (batch.vec[blockIdx.z]) {
+    const int P4 = P >> 2;
+    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
+      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v, u, gu;
+        const float gh = cg_norm_act_gh_val(a, af, alpha, q.x[j], q.w, q.keep[j], q.ad[j], q.g[j], v, u, gu);
+        s1 += (double)gh;
+        s2 += (double)gh * (double)((v - af.mean) * af.rstd);
+        if (a.alpha && !(u > 0.f)) sa += (double)q.g[j] * (double)u;
+      }
+    }
+  } else {
+    CG_CHUNK_LOOP(nb, P, e) {
+      CG_CHUNK_ROW(e, P, b0)
+      CG_POS(a.xv, p)
+      float w, v, u, gu, g;
+      const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
+      s1 += (double)gh;
+      s2 += (double)gh * (double)((v - af.mean) * af.rstd);
+      if (a.alpha && !(u > 0.f)) sa += (double)g * (double)u;
+    }
   }
   s1 = cg_block_sum(s1, red);
   s2 = cg_block_sum(s2, red + 16);
@@ -298,17 +393,38 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormActBatch batch) {
     m2 = (float)(a.red[2 * c + 1] / cnt);
   }
   double sp = 0.0;
-  CG_CHUNK_LOOP(nb, P, e) {
-    CG_CHUNK_ROW(e, P, b0)
-    CG_POS(a.xv, p)
-    float w, v, u, gu, g;
-    const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
-    float gv;
-    if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
-    else gv = gh * af.scale;
-    if (a.dx) a.dx[cg_row_base(a.dxv, b, c) + CG_OFF(a.dxv)] = gv * w;
-    if (a.dadd) a.dadd[cg_row_base(a.dav, b, c) + CG_OFF(a.dav)] = gu;
-    if (a.dpre) sp += (double)gv * (double)a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)];
+  if (batch.vec[blockIdx.z]) {
+    const int P4 = P >> 2;
+    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
+      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p);
+      float dxq[4], daq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v, u, gu;
+        const float gh = cg_norm_act_gh_val(a, af, alpha, q.x[j], q.w, q.keep[j], q.ad[j], q.g[j], v, u, gu);
+        float gv;
+        if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
+        else gv = gh * af.scale;
+        dxq[j] = gv * q.w; daq[j] = gu;
+        if (a.dpre) sp += (double)gv * (double)q.x[j];
+      }
+      if (a.dx) *reinterpret_cast<float4*>(a.dx + cg_row_base(a.dxv, b, c) + p) = make_float4(dxq[0], dxq[1], dxq[2], dxq[3]);
+      if (a.dadd) *reinterpret_cast<float4*>(a.dadd + cg_row_base(a.dav, b, c) + p) = make_float4(daq[0], daq[1], daq[2], daq[3]);
+    }
+  } else {
+    CG_CHUNK_LOOP(nb, P, e) {
+      CG_CHUNK_ROW(e, P, b0)
+      CG_POS(a.xv, p)
+      float w, v, u, gu, g;
+      const float gh = cg_norm_act_gh(a, af, alpha, seed, b, c, C, P, p, i2_, i3_, w, v, u, gu, g);
+      float gv;
+      if (a.bn_mode == 1) gv = af.scale * (gh - m1 - (v - af.mean) * af.rstd * m2);
+      else gv = gh * af.scale;
+      if (a.dx) a.dx[cg_row_base(a.dxv, b, c) + CG_OFF(a.dxv)] = gv * w;
+      if (a.dadd) a.dadd[cg_row_base(a.dav, b, c) + CG_OFF(a.dav)] = gu;
+      if (a.dpre) sp += (double)gv * (double)a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)];
+    }
   }
   if (a.dpre) {
     sp = cg_block_sum(sp, red);
@@ -350,7 +466,7 @@ static int cg_norm_act_launch(const CgNormAct* arr, const int* sel, int n, int k
     const CgNormAct& a = arr[sel ? sel[i] : i];
     int rb = cg_rows_per_block(a.xv);
     if (kind == 2 && a.dpre) rb = 1;      // the gate gradient is one sum per (batch, channel) row
-    batch.a[i] = a; batch.rb[i] = rb;
+    batch.a[i] = a; batch.rb[i] = rb; batch.vec[i] = cg_norm_act_vec(a, kind);
     gx = gx > a.xv.n[1] ? gx : a.xv.n[1];
     const long long chunks = (a.xv.n[0] + rb - 1) / rb;
     gy = gy > chunks ? gy : chunks;

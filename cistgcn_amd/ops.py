@@ -251,6 +251,9 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
 _KRED = bool(int(__import__("os").environ.get("CISTGCN_KRED", "1")))     # tuning aid: 0 = always the tiled split-K path
 _KRED_BLOCKS = int(__import__("os").environ.get("CISTGCN_KRED_BLOCKS", "128"))
 _KRED_MAX = int(__import__("os").environ.get("CISTGCN_KRED_MAX", "64"))
+# measured on MI355X (A/B on one box): below ~1e5 reduction elements the tiled split-K plan is as fast or faster
+# (B=16 step +2.5 % with K-reduction everywhere), above it the K-reduction kernel wins (B=256, C=64 step -3.3 %)
+_KRED_MIN_K = int(__import__("os").environ.get("CISTGCN_KRED_MIN_K", "65536"))
 
 
 def _quads(tab):
@@ -262,7 +265,7 @@ def _quads(tab):
 
 
 def _kred_ok(p, tabs):
-    if p.K % 4 or p.G * p.M * p.N > 65536 or max(p.M, p.N) > _KRED_MAX:
+    if p.K % 4 or p.K < _KRED_MIN_K or p.G * p.M * p.N > 65536 or max(p.M, p.N) > _KRED_MAX:
         return False
     return (_quads(tabs[8]) and _quads(tabs[9]) and all((tabs[i] % 4 == 0).all() for i in (0, 1, 3, 6)))
 

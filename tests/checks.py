@@ -110,9 +110,9 @@ def check_contract(device, quick=False):
         assert_close(_chan_sums(st), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
 
 
-def check_norm_act(device, quick=False):
+def _check_norm_act_shape(device, quick, T, V):
     g = _gen(2)
-    B, C, T, V = 4, 6, 5, 7
+    B, C = 4, 6
     x = _rand(g, B, C, T, V, scale=3.0) + 1.5
     add = _rand(g, B, C, T, V)
     pre = _rand(g, B, C)
@@ -175,6 +175,13 @@ def check_norm_act(device, quick=False):
                                      floor=max(1e-3, float(pr_ref.weight.grad.abs().max())))
                     for k in ("running_mean", "running_var", "num_batches_tracked"):
                         assert_close(getattr(bn_dev, k).float(), getattr(bn_ref, k).float(), what + " " + k, rel=2e-5)
+
+
+def check_norm_act(device, quick=False):
+    _check_norm_act_shape(device, quick, 5, 7)      # odd rows: strided scalar path
+    _check_norm_act_shape(device, True, 4, 6)       # rows of 24 contiguous floats: float4 path
+    g = _gen(2)
+    B, C, T, V = 4, 6, 5, 7
     # BatchNorm1d on (B,C) and (B,C,L), no-BN PReLU-only, strided input and mm-scale statistics
     for shape in ((6, C), (4, C, 9)):
         bn_ref = nn.BatchNorm1d(C)
@@ -230,7 +237,7 @@ def check_batched_ops(device):
     assert_close(_chan_sums(sts[0]), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "epilogue sums", rel=1e-6)
     assert sts[1] is None and sts[2] is None
     # row problems of different shapes in one launch, one of them emitting the sums of its output
-    shapes = [(4, 6, 5, 7), (4, 3, 1, 9), (6, 5)]
+    shapes = [(4, 6, 4, 7), (4, 3, 1, 9), (6, 5)]       # float4 rows, scalar rows, BatchNorm1d in one launch
     xs = [_rand(g, *sh, scale=2.0) + 0.5 for sh in shapes]
     bns_ref = [nn.BatchNorm2d(6), nn.BatchNorm2d(3), nn.BatchNorm1d(5)]
     bns_dev = [type(b)(b.num_features).to(device) for b in bns_ref]
@@ -274,6 +281,14 @@ def check_dropout(device):
     assert not torch.equal(y3.cpu(), vals)
     y4 = ops.norm_act(x.detach(), train=False, drop_p=p, salt=7)  # eval: identity
     assert torch.equal(y4.cpu(), torch.ones_like(vals))
+    # the float4 path (contiguous rows) and the strided scalar path draw the same mask for the same logical element
+    xs = torch.ones(8, 10, 22, 16, device=device).permute(0, 3, 1, 2)            # same logical shape, channel-last storage
+    y5 = ops.norm_act(xs, train=True, drop_p=p, salt=7)
+    assert torch.equal(y5.cpu(), y3.cpu())
+    xo = torch.ones(3, 4, 5, 7, device=device, requires_grad=True)                 # odd row length: scalar path, fwd/bwd agreement
+    yo = ops.norm_act(xo, train=True, drop_p=p, salt=9)
+    yo.backward(torch.ones_like(yo))
+    assert torch.equal(xo.grad.cpu(), yo.detach().cpu())
 
 
 def check_reduce_and_gate(device):
@@ -292,6 +307,18 @@ def check_contract_kred(device):
     """weight-gradient shaped contractions (few outputs, long contiguous reduction) take the K-reduction kernel:
     one / four matrix-core tiles per wave, ragged edges, several output tiles, batch index, bias"""
     g = _gen(12)
+    ops._KRED_MIN_K, saved = 0, ops._KRED_MIN_K          # the plan keeps short reductions on the tiled path; test sizes are short
+    try:
+        _check_contract_kred(device, g)
+    finally:
+        ops._KRED_MIN_K = saved
+    a, x = _rand(g, 2, 3, 8, 5000), _rand(g, 2, 5, 8, 5000)          # K = 80 000: selected by the default plan
+    _run(lambda a_, x_: ops.contract("bohw,bchw->oc", a_, x_), lambda a_, x_: torch.einsum("bohw,bchw->oc", a_, x_), [a, x], device,
+         what="kred long K", rel=3e-5)
+    assert any(p.mode == 2 and p.K == 80000 for p in ops._plans.values())
+
+
+def _check_contract_kred(device, g):
     cases = [
         ("bohw,bchw->oc", (3, 7, 8, 12), (3, 5, 8, 12), None),          # 16x16 tile, K = 288
         ("bohw,bchw->oc", (2, 22, 20, 20), (2, 22, 20, 20), None),       # 32x32 tile, K = 800
