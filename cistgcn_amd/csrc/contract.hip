@@ -30,7 +30,7 @@ struct CgContractDesc {
   int accumulate;            // 1: fp32 atomic adds into Y (several problems sum into one zeroed output)
   int x_vec;                 // 1: X is contiguous and 16-byte aligned along n in groups of four -> float4 loads
   int stat_ch;               // number of channels of `stats` (replica stride = 2 * stat_ch doubles)
-  int mode;                  // 0: tiled kernel below; 2: K-reduction kernel (weight gradients, see cg_kred_body)
+  int mode;                  // 0: tiled kernel below; 1: streaming kernel (cg_stream_body); 2: K-reduction (cg_kred_body)
   long long block0;          // first block id of this problem inside the launch
   float* ws;                 // mode 2: zeroed scratch of cg_contract_kred_ws_floats(G, M, N) floats
 };
@@ -260,6 +260,135 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming variant (mode 1): pointwise maps over a long position axis, Y[m,n] = sum_k A[m,k] X[k,n] with
+// K <= 128, N >= 1e5 and X contiguous along n.  The tile kernel above spends its time in dependent round trips
+// (tables -> k-step -> barrier -> k-step ... -> stores) with ~8 KB per workgroup in flight.  Here the whole A panel
+// sits in LDS once, every wave owns a 64-column strip and feeds the matrix cores straight from global memory:
+// lane (l15, l4) loads the float4 X[k = 4 ks + l4][n = strip + 4 l15 .. +3] - a wave instruction reads four full
+// 256-byte rows - and component q of that float4 is the B operand of MFMA tile q, whose 16 columns are therefore the
+// strided set {strip + 4 j + q}.  All k-steps of a chunk of 32 k are issued before the first MFMA, nothing in the
+// K loop waits on a barrier, and the lane ends up with four consecutive columns per output row (float4 stores).
+// ---------------------------------------------------------------------------------------------
+#define CG_ST_KMAX 128
+#define CG_ST_LDA 68                  // A panel row stride (floats): k-rows l4 = 0..3 of a fragment read fall on distinct banks
+
+template <int MI>
+__device__ __forceinline__ void cg_stream_body(const CgContractDesc& d, long long bid, float* As, int32_t* sKX, double* sStat_) {
+  const float* __restrict__ A = d.A; const float* __restrict__ X = d.X; float* __restrict__ Y = d.Y;
+  const float* __restrict__ bias = d.bias; double* __restrict__ stats = d.stats;
+  const int G = d.G, M = d.M, N = d.N, K = d.K;
+  const int32_t* gA = d.tab;
+  const int32_t* gX = gA + G;
+  const int32_t* gY = gX + G;
+  const int32_t* mA = gY + G;
+  const int32_t* mY = mA + M;
+  const int32_t* mB = mY + M;
+  const int32_t* nX = mB + M;
+  const int32_t* nY = nX + N;
+  const int32_t* kA = nY + N;
+  const int32_t* kX = kA + K;
+  double (*sStat)[2] = reinterpret_cast<double (*)[2]>(sStat_);
+  constexpr int BM = 16 * MI;
+  const int tiles_n = (N + 255) / 256, tiles_m = (M + BM - 1) / BM;
+  const int tn = (int)(bid % tiles_n); bid /= tiles_n;
+  const int tm = (int)(bid % tiles_m); bid /= tiles_m;
+  const int g = (int)bid;
+  const int m0 = tm * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  const int Kp = (K + 3) & ~3;
+
+  // A panel [Kp][BM] and the k offsets of X into LDS
+  const long long baseA = gA[g];
+  for (int e = tid; e < Kp * BM; e += 256) {
+    const int k = e / BM, mm = e - k * BM, m = m0 + mm;
+    As[k * CG_ST_LDA + mm] = (k < K && m < M) ? A[baseA + mA[m] + kA[k]] : 0.f;
+  }
+  for (int k = tid; k < Kp; k += 256) sKX[k] = k < K ? kX[k] : 0;
+  if (stats != nullptr && tid < 2 * BM) sStat[tid >> 1][tid & 1] = 0.0;
+  const int n = tn * 256 + 64 * wv + 4 * l15;          // first of this lane's four columns (N % 4 == 0)
+  const bool col_ok = n < N;
+  const long long xoff = col_ok ? (long long)gX[g] + nX[n] : 0;
+  __syncthreads();
+
+  cg_f32x4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[i][q] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int KU = 8;                                // k-steps (of four k) per chunk
+  const int nsteps = Kp >> 2;
+  for (int s0 = 0; s0 < nsteps; s0 += KU) {            // uniform over the workgroup
+    float4 xv[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int k = 4 * (s0 + u) + l4;
+      xv[u] = (col_ok && s0 + u < nsteps && k < K) ? *reinterpret_cast<const float4*>(X + xoff + sKX[k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (s0 + u < nsteps) {
+        const int k = 4 * (s0 + u) + l4;
+        const float x4[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float a = As[k * CG_ST_LDA + 16 * i + l15];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x4[q], acc[i][q], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  const long long baseY = gY[g];
+  const bool atomic_out = d.accumulate != 0;
+  const long long ycol = col_ok ? nY[n] : 0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mt = 16 * i + 4 * l4 + r, m = m0 + mt;
+      const bool ok = m < M && col_ok;
+      const float bv = (ok && bias != nullptr) ? bias[mB[m]] : 0.f;
+      float4 v = make_float4(acc[i][0][r] + bv, acc[i][1][r] + bv, acc[i][2][r] + bv, acc[i][3][r] + bv);
+      if (ok) {
+        float* yp = Y + baseY + mY[m] + ycol;
+        if (atomic_out) { atomicAdd(yp, v.x); atomicAdd(yp + 1, v.y); atomicAdd(yp + 2, v.z); atomicAdd(yp + 3, v.w); }
+        else *reinterpret_cast<float4*>(yp) = v;
+      }
+      if (stats != nullptr) {
+        double s1 = ok ? ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w) : 0.0;
+        double s2 = ok ? ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w) : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 16); s2 += __shfl_down(s2, off, 16); }
+        if (l15 == 0 && m < M) { atomicAdd(&sStat[mt][0], s1); atomicAdd(&sStat[mt][1], s2); }
+      }
+    }
+  }
+  if (stats != nullptr) {
+    __syncthreads();
+    double* rep = stats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * d.stat_ch;
+    if (tid < 2 * BM && m0 + (tid >> 1) < M) atomicAdd(&rep[2 * mB[m0 + (tid >> 1)] + (tid & 1)], sStat[tid >> 1][tid & 1]);
+  }
+}
+
+static inline int cg_stream_mi(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+
+__global__ __launch_bounds__(256, 3) void cg_contract_stream_kernel(CgContractBatch batch) {
+  __shared__ float As[CG_ST_KMAX * CG_ST_LDA];
+  __shared__ int32_t sKX[CG_ST_KMAX];
+  __shared__ double sStat[64 * 2];
+  long long bid = blockIdx.x;
+  int pi = 0;
+  for (int i = 1; i < batch.n; ++i)
+    if (bid >= batch.d[i].block0) pi = i;
+  const CgContractDesc& d = batch.d[pi];
+  bid -= d.block0;
+  if (d.M <= 16) cg_stream_body<1>(d, bid, As, sKX, sStat);
+  else if (d.M <= 32) cg_stream_body<2>(d, bid, As, sKX, sStat);
+  else cg_stream_body<4>(d, bid, As, sKX, sStat);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K-reduction variant (mode 2): weight gradients of the pointwise maps, Y[m,n] = sum_k A[m,k] X[n,k] with a
 // handful of outputs and K = batch x positions (1e4 .. 1e6).  Both operands are contiguous along k in aligned
 // groups of four, so every lane feeds the matrix cores straight from global memory with float4 loads: lane
@@ -413,6 +542,11 @@ extern "C" long long cg_contract_kred_ws_floats(int G, int M, int N) {
 }
 
 static long long cg_contract_blocks(CgContractDesc& d) {
+  if (d.mode == 1) {
+    const int bm = 16 * cg_stream_mi(d.M);
+    d.kchunk = d.K;
+    return (long long)((d.N + 255) / 256) * ((d.M + bm - 1) / bm) * d.G;
+  }
   if (d.mode == 2) {
     const int bt = 16 * cg_kred_ti(d.M, d.N);
     const int kchunk = (d.K + d.splitk - 1) / d.splitk;
@@ -430,9 +564,10 @@ static long long cg_contract_blocks(CgContractDesc& d) {
 // buffer they are carved from).
 extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream_) {
   if (!descs || n <= 0 || n > CG_MAX_BATCH) return CG_EARG;
-  CgContractBatch batch;
-  batch.n = n; batch.pad = 0;
-  long long total = 0;
+  CgContractBatch batch;                    // tiled + K-reduction problems: one launch
+  CgContractBatch strm;                     // streaming problems: their own kernel (register budget), one launch
+  batch.n = 0; batch.pad = 0; strm.n = 0; strm.pad = 0;
+  long long total = 0, stotal = 0;
   for (int i = 0; i < n; ++i) {
     CgContractDesc d = descs[i];
     if (!d.A || !d.X || !d.Y || !d.tab) return CG_EARG;
@@ -440,30 +575,38 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
     if (d.stats && (d.splitk > 1 || d.accumulate)) return CG_EARG;
     if (d.x_vec && ((d.N & 3) || ((uintptr_t)d.X & 15))) return CG_EARG;
     if (d.stats && d.stat_ch <= 0) return CG_EARG;
-    if (d.mode != 0 && d.mode != 2) return CG_EARG;
+    if (d.mode < 0 || d.mode > 2) return CG_EARG;
     if (d.mode == 2) {
       if (!d.ws || d.stats || (d.K & 3) || (((uintptr_t)d.A | (uintptr_t)d.X) & 15)) return CG_EARG;
       if ((d.K + d.splitk - 1) / d.splitk > 4 * CG_KR_QT - 16) return CG_ESHAPE;
     }
-    batch.d[i] = d;
+    if (d.mode == 1) {
+      if (!d.x_vec || d.x_kfast || d.splitk != 1 || ((uintptr_t)d.Y & 15)) return CG_EARG;
+      if (d.K > CG_ST_KMAX) return CG_ESHAPE;
+      d.block0 = stotal;
+      stotal += cg_contract_blocks(d);
+      strm.d[strm.n++] = d;
+    } else {
+      batch.d[batch.n++] = d;
+    }
   }
   // K-reduction problems have few, long-running workgroups: give them the lowest block ids so that they start first
   // and the short tile workgroups of the other problems fill in around them (the kernel finds a problem by scanning
   // for the largest block0 <= block id, so block0 must ascend with the position in the batch: reorder the batch).
   CgContractBatch sorted;
-  sorted.n = n; sorted.pad = 0;
+  sorted.n = batch.n; sorted.pad = 0;
   int w = 0;
   for (int pass = 0; pass < 2; ++pass)
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < batch.n; ++i)
       if ((batch.d[i].mode == 2) == (pass == 0)) {
         sorted.d[w] = batch.d[i];
         sorted.d[w].block0 = total;
         total += cg_contract_blocks(sorted.d[w]);
         ++w;
       }
-  batch = sorted;
-  if (total > 2147483647LL) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_contract_many_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, batch);
+  if (total > 2147483647LL || stotal > 2147483647LL) return CG_ESHAPE;
+  if (strm.n) hipLaunchKernelGGL(cg_contract_stream_kernel, dim3((unsigned)stotal), dim3(256), 0, (hipStream_t)stream_, strm);
+  if (sorted.n) hipLaunchKernelGGL(cg_contract_many_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream_, sorted);
   return cg_launch_status();
 }
 

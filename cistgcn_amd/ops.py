@@ -239,6 +239,9 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
         p.mode = 2
         p.splitk = int(max(1, (p.K + 4063) // 4064, min(512, (p.K + 255) // 256, max(1, _KRED_BLOCKS // tiles))))
         p.ws_floats = int(_lib.lib().cg_contract_kred_ws_floats(p.G, p.M, p.N))
+    elif (y_dense and aligned and _STREAM and p.x_vec and p.K <= 128 and p.N >= _STREAM_MIN_N and _quads(tabs[7])
+          and (tabs[4] % 4 == 0).all() and (tabs[2] % 4 == 0).all()):
+        p.mode = 1        # pointwise map over a long contiguous position axis: streaming kernel (A panel in LDS, X via float4)
     elif y_dense and p.K >= 256 and blocks < 512:
         # few output tiles and a long reduction (weight / bias gradients): spread K over workgroups
         # every split adds its tile with fp32 atomics: splitk blocks serialise on each output address (~0.1 us each on
@@ -249,6 +252,9 @@ def _plan(sizes, la, lx, ly, sa, sx, sy, oa, ox, oy, bias_label, device, y_dense
 
 
 _KRED = bool(int(__import__("os").environ.get("CISTGCN_KRED", "1")))     # tuning aid: 0 = always the tiled split-K path
+_STREAM = bool(int(__import__("os").environ.get("CISTGCN_STREAM", "1")))  # tuning aid: 0 = tiled path for pointwise maps
+# below ~6e4 positions a launch is latency bound either way and splitting a batch into two kernels costs a graph node
+_STREAM_MIN_N = int(__import__("os").environ.get("CISTGCN_STREAM_MIN_N", "65536"))
 _KRED_BLOCKS = int(__import__("os").environ.get("CISTGCN_KRED_BLOCKS", "128"))
 _KRED_MAX = int(__import__("os").environ.get("CISTGCN_KRED_MAX", "64"))
 # measured on MI355X (A/B on one box): below ~1e5 reduction elements the tiled split-K plan is as fast or faster
@@ -303,7 +309,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     kred = p.mode == 2
     r.y, r.zero, r.stats, r.tag = y, (p.splitk > 1 and not kred), None, spec
     r.ws_floats = p.ws_floats
-    if stats_label is not None and p.splitk == 1 and p.mode == 0:
+    if stats_label is not None and p.splitk == 1 and p.mode != 2:
         r.stats = _arena(x.device).take(2 * sizes[stats_label] * _lib.STAT_REPLICAS)   # replicated f64 channel sums of y
     d = _lib.ContractDesc()
     d.A, d.X, d.Y, d.tab = a.data_ptr(), x.data_ptr(), y.data_ptr(), p.tables.data_ptr()

@@ -63,7 +63,9 @@ typedef struct CgContractDesc {
   int accumulate;                /* 1: fp32 atomic adds into a zeroed Y shared by several problems */
   int x_vec;                     /* 1: X contiguous + 16-byte aligned along n in groups of four (float4 loads) */
   int stat_ch;                   /* channels of `stats`: it holds CG_STAT_REPLICAS x stat_ch x 2 doubles */
-  int mode;                      /* 0: tiled kernel.  2: K-reduction kernel for weight gradients (few outputs, K = batch x
+  int mode;                      /* 0: tiled kernel.  1: streaming kernel for pointwise maps over a long position axis:
+                                    requires x_vec, K <= 128, splitk 1, and Y contiguous along n in 16-byte aligned groups of
+                                    four (the n offsets of Y as those of X).  2: K-reduction kernel for weight gradients (few outputs, K = batch x
                                     positions): requires K % 4 == 0, A and X contiguous along k in 16-byte aligned groups of
                                     four, no `stats`, K / splitk <= 4080, and `ws` */
   long long block0;              /* set by the library */

@@ -340,6 +340,29 @@ def _check_contract_kred(device, g):
     assert any(p.mode == 2 for p in ops._plans.values())
 
 
+def check_contract_stream(device):
+    """pointwise maps over a long contiguous position axis take the streaming kernel: 1 / 2 / 4 matrix-core row tiles,
+    ragged K and M, bias, channel sums in the epilogue, last workgroup partially filled, several row tiles"""
+    g = _gen(13)
+    ops._STREAM_MIN_N, saved = 256, ops._STREAM_MIN_N
+    try:
+        for (O, Cc, B, H, W) in ((5, 7, 2, 9, 20), (22, 22, 3, 10, 12), (50, 50, 2, 8, 28), (70, 33, 2, 6, 44), (8, 128, 1, 5, 52)):
+            w, x, bias = _rand(g, O, Cc, scale=0.3), _rand(g, B, Cc, H, W), _rand(g, O)
+            before = sum(1 for p in ops._plans.values() if p.mode == 1)
+            _run(lambda w_, x_, b_: ops.contract("oc,bchw->bohw", w_, x_, b_, "o"),
+                 lambda w_, x_, b_: torch.einsum("oc,bchw->bohw", w_, x_) + b_.view(1, -1, 1, 1), [w, x, bias], device,
+                 what="stream %dx%d" % (O, Cc), rel=3e-5)
+            assert sum(1 for p in ops._plans.values() if p.mode == 1) > before, "streaming plan was not selected"
+            ops.begin_step(device)
+            y, st = ops.contract_stats("oc,bchw->bohw", w.to(device), x.to(device), bias.to(device), "o")
+            r = (torch.einsum("oc,bchw->bohw", w, x) + bias.view(1, -1, 1, 1)).double()
+            assert st is not None
+            assert_close(y, r, "stream+stats y", rel=3e-5)
+            assert_close(_chan_sums(st), torch.stack((r.sum((0, 2, 3)), (r * r).sum((0, 2, 3))), 1).reshape(-1), "stream channel sums", rel=1e-5)
+    finally:
+        ops._STREAM_MIN_N = saved
+
+
 def check_zero_pool(device):
     """Per-step zero pool (ops.step_scratch): split-K outputs, halos, SE / ST-GCN dW accumulators carved from one
     buffer that begin_step clears - same results as with per-launch memsets, also on the second step (dirty pool)."""
