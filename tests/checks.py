@@ -180,6 +180,15 @@ def _check_norm_act_shape(device, quick, T, V):
 def check_norm_act(device, quick=False):
     _check_norm_act_shape(device, quick, 5, 7)      # odd rows: strided scalar path
     _check_norm_act_shape(device, True, 4, 6)       # rows of 24 contiguous floats: float4 path
+    # a larger float4 case (several rows per workgroup, addend before the PReLU, per-channel slopes)
+    gb = _gen(21)
+    bn_ref, pr_ref = nn.BatchNorm2d(3), nn.PReLU(3)
+    bn_dev, pr_dev = nn.BatchNorm2d(3).to(device), nn.PReLU(3).to(device)
+    xb, ab = _rand(gb, 26, 3, 8, 120, scale=2.0) + 0.5, _rand(gb, 26, 3, 8, 120)
+    _run(lambda x_, a_: ops.norm_act(x_, bn=bn_dev, train=True, add=a_, prelu=pr_dev), lambda x_, a_: pr_ref(bn_ref(x_) + a_), [xb, ab],
+         device, what="norm_act two-pass float4")
+    assert_close(bn_dev.weight.grad, bn_ref.weight.grad, "two-pass dgamma", rel=2e-5, floor=float(bn_ref.weight.grad.abs().max()))
+    assert_close(pr_dev.weight.grad, pr_ref.weight.grad, "two-pass dalpha", rel=2e-5, floor=float(pr_ref.weight.grad.abs().max()))
     g = _gen(2)
     B, C, T, V = 4, 6, 5, 7
     # BatchNorm1d on (B,C) and (B,C,L), no-BN PReLU-only, strided input and mm-scale statistics
