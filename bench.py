@@ -49,6 +49,17 @@ def synth(B, T, V, rank, base=1234):
     return x, tgt
 
 
+def model_bytes_per_sequence(C, T, V, To=25):
+    """ALGORITHMIC HBM bytes of one sequence through the six DSTD_GC blocks + model I/O, forward and backward, exactly
+    the SURVEY section 8(d) formula (x in, out, both adjacency maps, gates; backward: x, dOut, both maps, dx)."""
+    w = [10, C, C, C, C, 10]
+    blocks = [(w[i], w[i + 1], T, V) for i in range(5)] + [(3, 3, V, To)]
+    fwd = sum(ci * t * v + co * t * v + v * t * t + t * v * v + 2 * co for ci, co, t, v in blocks)
+    bwd = sum(ci * t * v + co * t * v + v * t * t + t * v * v + ci * t * v for ci, co, t, v in blocks)
+    io = 3 * T * V + 10 * T * V + 2 * 10 * To * V + 4 * 3 * To * V
+    return 4 * (fwd + io), 4 * (bwd + io)
+
+
 def domain_shapes(C, T, V, To=25):
     """(Cin, Cout, T, V) of the six fused ST-GCN launches per domain in one forward."""
     w = [10, C, C, C, C, 10]
@@ -148,6 +159,7 @@ def main():
     ap.add_argument("--branches", action="store_true", help="EXPERIMENTAL: capture independent branches on forked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-eval", action="store_true", help="skip the eval-mode forward-only timing")
     ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
@@ -224,6 +236,25 @@ def main():
                    "loss": loss},
     }
     if rank == 0 and world == 1:
+        bf, bb = model_bytes_per_sequence(C, T, V)
+        gbs = (bf + bb) * out["value"] / 1e9
+        # whole-step view next to the per-kernel roofline: SURVEY 8(d) algorithmic bytes per sequence x sequences/s
+        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_sequence_fwd": bf, "algorithmic_bytes_per_sequence_bwd": bb,
+                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        if not args.no_eval:
+            from cistgcn_amd.runtime import GraphedForward
+            net.eval()
+            fwd = GraphedForward(net, x)
+            for _ in range(args.warmup):
+                fwd.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                fwd.replay()
+            torch.cuda.synchronize()
+            ef = (time.perf_counter() - t1) / args.steps
+            net.train()
+            out["eval_forward"] = {"value": B / ef, "unit": "sequences/sec", "ms_per_batch": ef * 1e3, "graph": True}
         if not args.no_roofline:
             nbytes, secs, per = roofline_domain_kernel(B, C, T, V, device)
             traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_pmc.sh), recorded under profiles/

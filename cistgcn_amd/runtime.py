@@ -178,6 +178,30 @@ class GraphedStep:
         return self.loss
 
 
+class GraphedForward:
+    """Eval-mode forward of one static batch as a HIP graph (inference / validation path, `environment/test.py:279-350`
+    of the reference calls the model under `no_grad` like this)."""
+
+    def __init__(self, model, x, warmup=2):
+        self.model = model
+        self.x = x.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model(self.x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        _drop_graph_attributes(model)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.pred, = model(self.x)
+
+    def replay(self):
+        self.graph.replay()
+        return self.pred
+
+
 class EagerStep:
     """Same step without graph capture (debugging / first-iteration reference)."""
 

@@ -89,6 +89,22 @@ def test_graph_replay_matches_eager(branches=False):
         assert torch.allclose(a, p.grad, rtol=1e-3, atol=max(1e-5, 1e-4 * float(p.grad.abs().max())))   # atomics reorder sums
 
 
+def test_eval_forward_graph_matches_eager():
+    """eval-mode forward captured in a HIP graph (bench.py's forward-only figure) = eager eval forward, also on new data"""
+    from cistgcn_amd.runtime import GraphedForward
+    net, _ = checks.build_pair(8, 10, 22, "cuda")
+    net.eval()
+    g = torch.Generator().manual_seed(6)
+    x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
+    fwd = GraphedForward(net, x)
+    x2 = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
+    fwd.x.copy_(x2)
+    pred_g = fwd.replay().clone()
+    with torch.no_grad():
+        pred, = net(x2)
+    assert torch.allclose(pred_g, pred, rtol=1e-5, atol=1e-3)
+
+
 def test_training_steps_with_graph_and_flat_adam():
     """End to end: HIP-graph step + flat gradient gather + one-kernel Adam train the model (loss goes down)."""
     from cistgcn_amd.runtime import FlatAdam, GraphedStep
