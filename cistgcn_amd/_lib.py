@@ -57,6 +57,10 @@ class StatsArgs(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("xv", View4), ("pre", c_void_p), ("stats", c_void_p)]
 
 
+class SumItem(ctypes.Structure):
+    _fields_ = [("a", c_void_p), ("av", View4)]
+
+
 class CopyItem(ctypes.Structure):
     _fields_ = [("y", c_void_p), ("yv", View4), ("a", c_void_p), ("av", View4)]
 
@@ -77,6 +81,7 @@ _SIGNATURES = {
     "cg_norm_act_bwd": [POINTER(NormAct), c_int, P],
     "cg_reduce_bc": [P, POINTER(View4), c_int, P, P, P],
     "cg_reduce_bc_bwd": [P, P, c_int, P, POINTER(View4), P],
+    "cg_sum_many": [P, POINTER(View4), POINTER(SumItem), c_int, P],
     "cg_add3": [P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P],
     "cg_zero": [P, LL, P],
     "cg_feature_lift_fwd": [P, P, LL, LL, LL, P],

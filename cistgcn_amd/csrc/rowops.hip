@@ -611,6 +611,59 @@ extern "C" int cg_add3(float* y, const CgView4* yv, const float* a, const CgView
   return cg_launch_status();
 }
 
+// y = sum of up to CG_SUM_MAX same-shape strided tensors in one launch: the gradient of a tensor that feeds several
+// consumers (a block input goes to the statistics, the gate/tower maps, both graph stages and the residuals) is
+// summed once instead of by one autograd accumulation kernel per extra consumer.
+#define CG_SUM_MAX 8
+struct CgSumArgs { float* y; CgView4 yv; int n; int vec; const float* a[CG_SUM_MAX]; CgView4 av[CG_SUM_MAX]; };
+
+__global__ void cg_sum_many_kernel(CgSumArgs s) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int P = (int)(s.yv.n[2] * s.yv.n[3]);
+  if (s.vec) {                                   // contiguous 16-byte aligned rows everywhere
+    float* yr = s.y + cg_row_base(s.yv, b, c);
+    for (int p = 4 * threadIdx.x; p < P; p += 4 * blockDim.x) {
+      float4 v = *reinterpret_cast<const float4*>(s.a[0] + cg_row_base(s.av[0], b, c) + p);
+      for (int i = 1; i < s.n; ++i) {
+        const float4 w = *reinterpret_cast<const float4*>(s.a[i] + cg_row_base(s.av[i], b, c) + p);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+      *reinterpret_cast<float4*>(yr + p) = v;
+    }
+    return;
+  }
+  CG_ROW_LOOP(P, p) {
+    CG_POS(s.yv, p)
+    float v = s.a[0][cg_row_base(s.av[0], b, c) + CG_OFF(s.av[0])];
+    for (int i = 1; i < s.n; ++i) v += s.a[i][cg_row_base(s.av[i], b, c) + CG_OFF(s.av[i])];
+    s.y[cg_row_base(s.yv, b, c) + CG_OFF(s.yv)] = v;
+  }
+}
+
+struct CgSumItem { const float* a; CgView4 av; };
+// include/cistgcn_hip.h : cg_sum_many
+extern "C" int cg_sum_many(float* y, const CgView4* yv, const CgSumItem* items, int n, void* stream_) {
+  if (!y || !yv || !items || n <= 0 || n > CG_SUM_MAX) return CG_EARG;
+  if (yv->n[0] <= 0 || yv->n[0] > 65535 || yv->n[1] <= 0 || yv->n[2] * yv->n[3] <= 0) return CG_ESHAPE;
+  CgSumArgs s;
+  s.y = y; s.yv = *yv; s.n = n;
+  bool vec = cg_view_vec(y, *yv);
+  for (int i = 0; i < CG_SUM_MAX; ++i) {
+    s.a[i] = i < n ? items[i].a : nullptr;
+    s.av[i] = i < n ? items[i].av : *yv;
+    if (i < n) {
+      if (!items[i].a) return CG_EARG;
+      for (int k = 0; k < 4; ++k)
+        if (items[i].av.n[k] != yv->n[k]) return CG_ESHAPE;
+      vec = vec && cg_view_vec(items[i].a, items[i].av);
+    }
+  }
+  s.vec = vec ? 1 : 0;
+  dim3 grid((unsigned)yv->n[1], (unsigned)yv->n[0]);
+  hipLaunchKernelGGL(cg_sum_many_kernel, grid, cg_row_block(*yv), 0, (hipStream_t)stream_, s);
+  return cg_launch_status();
+}
+
 // up to four strided copies in one launch (the slices of a channel concatenation)
 struct CgCopyItem { float* y; CgView4 yv; const float* a; CgView4 av; };
 struct CgCopyBatch { int n; int pad; CgCopyItem it[4]; };

@@ -377,11 +377,17 @@ class CISTGCN(nn.Module):
         doms = (m.dsgn, m.tsgn)
         if not all(d.interpretable for d in doms):
             return self._block(m, x)
-        xn = self._na(x, bn=m.global_norm)
-        stats = ops.dstd_stats(xn)
-        B, _, T, V = xn.shape
+        xn0 = self._na(x, bn=m.global_norm)
+        B, _, T, V = xn0.shape
         has_res = not isinstance(m.dsgn.residual, nn.Identity)
         has_bres = not isinstance(m.residual, nn.Identity)
+        # the normalised input feeds the statistics, the first-level maps, both graph stages and the identity residuals:
+        # one alias per consumer, so that backward sums their gradients in one launch (ops.fanout)
+        xa = list(ops.fanout(xn0, 4 + (0 if has_res else 2) + (0 if has_bres else 1)))
+        x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
+        x_res = xa[4:6] if not has_res else None
+        x_bres = xa[-1] if not has_bres else None
+        stats = ops.dstd_stats(x_stats)
         maps = [d.map_to_adj for d in doms]
         # 1. every first-level map of xn
         items = [_rows_item(xn, m.conv_s[0], tr), _rows_item(xn, m.conv_t[0], tr)]
@@ -406,8 +412,8 @@ class CISTGCN(nn.Module):
             calls.append(dict(x=o[k], bn=m.residual[1]))
         r = self._na_many(calls)
         gs, gt, t1 = r[0], r[1], r[2:6]
-        res = r[6:8] if has_res else [xn, xn]
-        bres = r[-1] if has_bres else xn
+        res = r[6:8] if has_res else x_res
+        bres = r[-1] if has_bres else x_bres
         # 3. collapsing convolutions
         items = [_cols_item(gs, m.conv_s[4], tr), _cols_item(gt, m.conv_t[4], tr)]
         for i, a in enumerate(maps):
@@ -446,10 +452,10 @@ class CISTGCN(nn.Module):
             conv = d.tcn[0]
             if self.fused_domain:
                 wmat = conv.weight.view(conv.out_channels, conv.in_channels)
-                ys.append(ops.stgcn_domain(xn, d.Adj, wmat, conv.bias, 0 if d.domain == "space" else 1, tr))
+                ys.append(ops.stgcn_domain(x_dom[i], d.Adj, wmat, conv.bias, 0 if d.domain == "space" else 1, tr))
             else:
                 spec = "bctv,bvtq->bcqv" if d.domain == "space" else "bctv,btvw->bctw"
-                ys.append(self._lin(_pointwise, ops.contract(spec, xn, d.Adj), conv))
+                ys.append(self._lin(_pointwise, ops.contract(spec, x_dom[i], d.Adj), conv))
         x12 = self._na_many([dict(x=ys[i], bn=d.tcn[1], drop=True, add=res[i], prelu=d.prelu) for i, d in enumerate(doms)])
         ab = self._na_many([dict(x=x12[0], pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1]),
                             dict(x=x12[1], pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])])
@@ -460,11 +466,11 @@ class CISTGCN(nn.Module):
         return self._na(h, pre=gate, add=bres, add_post=True, emit_stats=tr)
 
     # ---- FPN.forward, CISTGCN.py:74-79 -------------------------------------------------------------
-    def _fpn(self, m, x):
+    def _fpn(self, m, x, x_pool=None):
         blocks = (m.block1, m.block2, m.block3)
         ys = ops.dilated_convs(x, [b[0] for b in blocks])
         outs = self._na_many([dict(x=y, bn=b[1], prelu=b[3]) for y, b in zip(ys, blocks)])   # FPN dropout p = 0 (:533)
-        outs.append(ops.mean_bc(x))                                                # action context, broadcast below
+        outs.append(ops.mean_bc(x if x_pool is None else x_pool))                  # action context, broadcast below
         return _pointwise(ops.cat_channels(outs, bcast=(False, False, False, True)), m.compress)[0]
 
     # ---- ContextLayer.forward, CISTGCN.py:463-475 --------------------------------------------------
@@ -506,9 +512,11 @@ class CISTGCN(nn.Module):
             h = block(blk, h)
         h = h[0] if isinstance(h, tuple) else h                          # (tensor, channel sums) from a staged block
         h = h.permute(0, 2, 1, 3)                                       # NCTV -> NTCV (view)
-        z = self._na(self._fpn(self.txcnns[0], h), prelu=self.prelus[0])
+        ha = ops.fanout(h, 2)                                           # dilated convolutions | pooled context
+        z = self._na(self._fpn(self.txcnns[0], ha[0], ha[1]), prelu=self.prelus[0])
         for i in range(1, self.n_txcnn_layers):
-            z = self._na(self._fpn(self.txcnns[i], z), prelu=self.prelus[i], add=z, add_post=True)
+            za = ops.fanout(z, 3)                                       # ... | skip connection
+            z = self._na(self._fpn(self.txcnns[i], za[0], za[1]), prelu=self.prelus[i], add=za[2], add_post=True)
         d = self.dim_conversor
         z = self._na(self._lin(_pointwise, z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
         z = self._na(_pointwise(z, d[3])[0], prelu=d[4])                # PReLU(3): per-channel slopes (:545)

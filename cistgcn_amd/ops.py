@@ -772,6 +772,48 @@ def _add_into(y, a, b=None, c=None):
               ctypes.byref(vb) if vb is not None else None, _ptr(c), ctypes.byref(vc) if vc is not None else None, _stream(y))
 
 
+class _Fanout(torch.autograd.Function):
+    """n aliases of one tensor, one per consumer: backward sums the consumers' gradients with ONE kernel instead of
+    one autograd accumulation kernel per extra consumer."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty(gs[0].shape, dtype=torch.float32, device=gs[0].device)
+        y = out if out.dim() >= 2 else out.view(1, -1)
+        while gs:
+            part, gs = gs[:_SUM_MAX], gs[_SUM_MAX:]
+            if gs:                                  # more than eight consumers: fold the partial sum into the next round
+                gs.insert(0, out)
+            arr = (_lib.SumItem * len(part))()
+            for i, g in enumerate(part):
+                g = g if g.dim() >= 2 else g.view(1, -1)
+                arr[i].a, arr[i].av = g.data_ptr(), _view4(g)
+            vy = _view4(y)
+            _lib.call("cg_sum_many", _ptr(y), ctypes.byref(vy), arr, len(part), _stream(y))
+        return out, None
+
+
+_SUM_MAX = 8
+_FANOUT = bool(int(__import__("os").environ.get("CISTGCN_FANOUT", "1")))      # tuning aid: 0 = let autograd accumulate
+
+
+def fanout(x, n):
+    """n autograd-independent aliases of x (see _Fanout); n <= 1 returns (x,)"""
+    if n <= 1 or not _FANOUT or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * max(n, 1)
+    return _Fanout.apply(x, n)
+
+
 def _copy(t):
     y = torch.empty(t.shape, dtype=torch.float32, device=t.device)
     if t.dim() > 4 or t.dim() < 2:

@@ -126,6 +126,10 @@ int cg_reduce_bc_bwd(const float* dout, const int32_t* arg, int kind, float* dx,
 /* y = a (+ b) (+ c) on strided views: torch.cat slices (CISTGCN.py:77,378-380,388,468), halo
  * padding for the dilated FPN convolutions (:54-68), F.interpolate broadcast (:76), the tail
  * x[:, -1:] + x8^T + act (:595-597). */
+/* y = a[0] + ... + a[n-1] (n <= 8), same logical shape, any strides: sums the gradients of a multi-consumer tensor in one
+ * launch (replaces autograd's one accumulation kernel per extra consumer) */
+typedef struct CgSumItem { const float* a; CgView4 av; } CgSumItem;
+int cg_sum_many(float* y, const CgView4* yv, const CgSumItem* items, int n, void* stream);
 int cg_add3(float* y, const CgView4* yv, const float* a, const CgView4* av, const float* b, const CgView4* bv,
             const float* c, const CgView4* cv, void* stream);
 typedef struct CgCopyItem { float* y; CgView4 yv; const float* a; CgView4 av; } CgCopyItem;

@@ -404,6 +404,13 @@ def check_copies(device):
          lambda x_, y_, z_: x_[:, -1:] + y_.permute(0, 3, 2, 1) + z_, [x, y, z], device, what="tail add3")
     _run(lambda t: ops.cumsum_time(t.permute(0, 2, 3, 1)), lambda t: t.permute(0, 2, 3, 1).cumsum(1), [_rand(g, 2, 3, 6, 4)],
          device, what="cumsum")
+    # aliases for several consumers: their gradients are summed by one launch (3 consumers, strided + odd rows; 10 consumers,
+    # float4 rows, two rounds of the 8-way sum; 2-D tensor)
+    _run(lambda t: ops.add3(*[a * (i + 1.0) for i, a in enumerate(ops.fanout(t.permute(0, 2, 1, 3), 3))]),
+         lambda t: 6.0 * t.permute(0, 2, 1, 3), [_rand(g, 2, 3, 5, 7)], device, what="fanout 3 strided")
+    _run(lambda t: sum(a * (i + 1.0) for i, a in enumerate(ops.fanout(t, 10))), lambda t: 55.0 * t, [_rand(g, 2, 3, 4, 8)], device,
+         what="fanout 10")
+    _run(lambda t: sum(ops.fanout(t, 2)), lambda t: 2.0 * t, [_rand(g, 3, 6)], device, what="fanout 2-D")
 
 
 def check_dilated_convs(device):

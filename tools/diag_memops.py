@@ -32,13 +32,12 @@ def step():
 step()
 zero_sites.clear()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as prof:
     step()
 cnt = collections.Counter()
 for e in prof.events():
     if e.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::add_", "aten::add", "aten::zeros", "aten::contiguous", "aten::cat", "aten::sum", "aten::mul"):
-        st = [s for s in (e.stack or []) if "cistgcn_amd" in s or "runtime" in s][:2]
-        cnt[(e.name, " <- ".join(s.split("/")[-1] for s in st) or "(autograd engine)")] += 1
+        cnt[(e.name, str(e.input_shapes))] += 1
 for k, v in cnt.most_common(40): print("%4d  %-16s %s" % (v, k[0], k[1]))
 print("cg_zero:")
 for k, v in zero_sites.most_common(): print("%4d  %s" % (v, k))
