@@ -165,6 +165,7 @@ def main():
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+    args.branches = args.branches or os.environ.get("CISTGCN_BRANCHES", "0") == "1"
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

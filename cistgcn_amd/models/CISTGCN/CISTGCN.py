@@ -254,31 +254,26 @@ class CISTGCN(nn.Module):
 
     # ---- fork / join of independent branches -----------------------------------------------------
     def _parallel(self, thunks, inputs):
-        """Evaluate independent sub-graphs.  With `branch_streams` each one is issued on its own side stream,
-        forked from the current stream and joined afterwards; captured in a HIP graph they become parallel
-        branches, so the many small kernels of the gate / tower / domain paths overlap instead of queueing.
-        Tensors that cross streams are recorded on the consuming stream (caching-allocator contract)."""
+        """Evaluate independent sub-graphs.  With `branch_streams`, all but the last are issued on side streams forked
+        from the current stream and joined before returning (the last one stays on the current stream); captured in a HIP
+        graph they become parallel branches, and autograd replays each backward on its forward stream, so the small
+        kernels of the two branches overlap in both directions.  Fork and join are the only cross-stream edges: every
+        tensor that crosses is produced before the fork or consumed after the join, which is also what keeps the caching
+        allocator's per-stream reuse safe without record_stream."""
         if not (self.branch_streams and inputs[0].is_cuda) or len(thunks) < 2:
             return [t() for t in thunks]
         cur = torch.cuda.current_stream()
-        if not self._streams:
-            self._streams = [torch.cuda.Stream(device=inputs[0].device) for _ in range(16)]
+        while len(self._streams) < len(thunks) - 1:
+            self._streams.append(torch.cuda.Stream(device=inputs[0].device))
         results = []
-        for t in thunks:
-            s = self._streams[self._next_stream % len(self._streams)]
-            self._next_stream += 1
+        for t, s in zip(thunks[:-1], self._streams):
             s.wait_stream(cur)
-            for x in inputs:
-                x.record_stream(s)
             with torch.cuda.stream(s):
-                out = t()
-            results.append((out, s))
-        for out, s in results:
+                results.append(t())
+        results.append(thunks[-1]())
+        for s in self._streams[:len(thunks) - 1]:
             cur.wait_stream(s)
-            for o in (out if isinstance(out, (tuple, list)) else (out,)):
-                if isinstance(o, torch.Tensor):
-                    o.record_stream(cur)
-        return [out for out, _ in results]
+        return results
 
     # ---- fused row op with per-call dropout site id -------------------------------------------
     def _na(self, x, bn=None, prelu=None, drop=False, **kw):

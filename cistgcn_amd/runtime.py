@@ -145,8 +145,8 @@ class GraphedStep:
 
     def __init__(self, model, x, target, warmup=3, flat=None, branches=False):
         self.model, self.flat = model, flat
-        # EXPERIMENTAL (off): independent branches on forked streams -> parallel graph branches.  ROCm 7.2's
-        # hipStreamEndCapture crashes on this many forked streams (round-1 GPU run), so the step is one linear chain.
+        # Optional: the context branch on a forked stream (one fork / join per step, CISTGCN._parallel) -> a parallel graph
+        # branch.  Captures and replays correctly on ROCm 7.2 but measured no faster (5.44 vs 5.43 ms at B=16), so it is off.
         model.branch_streams = bool(branches)
         ops.step_scratch(x.device, True)       # one fwd+bwd per begin_step, gradients consumed before the next: pool is safe
         self.x, self.target = x.clone(), target.clone()
