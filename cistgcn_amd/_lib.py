@@ -61,6 +61,11 @@ class SumItem(ctypes.Structure):
     _fields_ = [("a", c_void_p), ("av", View4)]
 
 
+class Rank1(ctypes.Structure):
+    _fields_ = [("s", c_void_p), ("q", c_void_p), ("o", c_void_p), ("dout", c_void_p), ("ds", c_void_p), ("dq", c_void_p),
+                ("domain", c_int), ("pad", c_int)]
+
+
 class CopyItem(ctypes.Structure):
     _fields_ = [("y", c_void_p), ("yv", View4), ("a", c_void_p), ("av", View4)]
 
@@ -82,6 +87,8 @@ _SIGNATURES = {
     "cg_reduce_bc": [P, POINTER(View4), c_int, P, P, P],
     "cg_reduce_bc_bwd": [P, P, c_int, P, POINTER(View4), P],
     "cg_sum_many": [P, POINTER(View4), POINTER(SumItem), c_int, P],
+    "cg_rank1_adj_fwd": [POINTER(Rank1), c_int, c_int, c_int, c_int, P],
+    "cg_rank1_adj_bwd": [POINTER(Rank1), c_int, c_int, c_int, c_int, P],
     "cg_add3": [P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P],
     "cg_zero": [P, LL, P],
     "cg_feature_lift_fwd": [P, P, LL, LL, LL, P],

@@ -375,3 +375,120 @@ extern "C" int cg_seed_bump(unsigned long long* seed, void* stream_) {
   hipLaunchKernelGGL(cg_seed_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, seed);
   return cg_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Row G — rank-1 adjacency seed of Map2Adj (CISTGCN.py:183-189): the joint and time summaries s (B,V,T) and q (B,T,V)
+// are expanded to one J x J slab per (sample, joint) or (sample, frame):
+//   space (domain 0): o[b,v,t,u] = s[b,v,t] * q[b,u,v]      (B,V,T,T)
+//   time  (domain 1): o[b,t,v,w] = s[b,v,t] * q[b,t,w]      (B,T,V,V)
+// Forward is a pure write stream; backward reads each slab of d o ONCE and produces both d s (row sums against q)
+// and d q (column sums against s) - as two generic contractions it was read twice through 64x64 tiles of which one
+// column was used.  One workgroup per slab, both domains of a block in one launch (blockIdx.y).
+// ---------------------------------------------------------------------------------------------
+#define CG_R1_JMAX 64
+struct CgRank1 { const float* s; const float* q; float* o; const float* dout; float* ds; float* dq; int domain; int pad; };
+struct CgRank1Batch { int n, B, T, V; CgRank1 it[2]; };
+
+// slab j of sample b: vectors sv[i], qv[k] and their strides
+__device__ __forceinline__ void cg_rank1_geom(int domain, int b, int j, int T, int V, int& J, long long& s0, int& ss, long long& q0, int& qs) {
+  if (domain == 0) { J = T; s0 = ((long long)b * V + j) * T; ss = 1; q0 = (long long)b * T * V + j; qs = V; }       // j = joint v
+  else             { J = V; s0 = (long long)b * V * T + j; ss = T; q0 = ((long long)b * T + j) * V; qs = 1; }       // j = frame t
+}
+
+__global__ void cg_rank1_adj_fwd_kernel(CgRank1Batch batch) {
+  __shared__ float sv[CG_R1_JMAX], qv[CG_R1_JMAX];
+  const CgRank1& it = batch.it[blockIdx.y];
+  const int NG = it.domain == 0 ? batch.V : batch.T;
+  const int b = blockIdx.x / NG, j = blockIdx.x - b * NG;
+  if (b >= batch.B) return;
+  int J, ss, qs; long long s0, q0;
+  cg_rank1_geom(it.domain, b, j, batch.T, batch.V, J, s0, ss, q0, qs);
+  if ((int)threadIdx.x < J) sv[threadIdx.x] = it.s[s0 + (long long)threadIdx.x * ss];
+  else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + J) qv[threadIdx.x - 64] = it.q[q0 + (long long)(threadIdx.x - 64) * qs];
+  __syncthreads();
+  float* o = it.o + ((long long)b * NG + j) * J * J;
+  const int JJ = J * J;
+  if ((JJ & 3) == 0) {
+    for (int e = 4 * threadIdx.x; e < JJ; e += 4 * blockDim.x) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = (e + r) / J, k = (e + r) - i * J; v[r] = sv[i] * qv[k]; }
+      *reinterpret_cast<float4*>(o + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+    for (int e = threadIdx.x; e < JJ; e += blockDim.x) { const int i = e / J, k = e - i * J; o[e] = sv[i] * qv[k]; }
+  }
+}
+
+__global__ void cg_rank1_adj_bwd_kernel(CgRank1Batch batch) {
+  __shared__ float sv[CG_R1_JMAX], qv[CG_R1_JMAX];
+  __shared__ float slab[CG_R1_JMAX * (CG_R1_JMAX + 1)];
+  const CgRank1& it = batch.it[blockIdx.y];
+  const int NG = it.domain == 0 ? batch.V : batch.T;
+  const int b = blockIdx.x / NG, j = blockIdx.x - b * NG;
+  if (b >= batch.B) return;
+  int J, ss, qs; long long s0, q0;
+  cg_rank1_geom(it.domain, b, j, batch.T, batch.V, J, s0, ss, q0, qs);
+  const int LD = J + 1;
+  if ((int)threadIdx.x < J) sv[threadIdx.x] = it.s[s0 + (long long)threadIdx.x * ss];
+  else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + J) qv[threadIdx.x - 64] = it.q[q0 + (long long)(threadIdx.x - 64) * qs];
+  const float* d = it.dout + ((long long)b * NG + j) * J * J;
+  const int JJ = J * J;
+  if ((JJ & 3) == 0) {
+    for (int e = 4 * threadIdx.x; e < JJ; e += 4 * blockDim.x) {
+      const float4 v = *reinterpret_cast<const float4*>(d + e);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = (e + r) / J, k = (e + r) - i * J; slab[i * LD + k] = vv[r]; }
+    }
+  } else {
+    for (int e = threadIdx.x; e < JJ; e += blockDim.x) { const int i = e / J, k = e - i * J; slab[i * LD + k] = d[e]; }
+  }
+  __syncthreads();
+  // threads 0..J-1: d s[i] = sum_k slab[i][k] q[k];  threads 64..64+J-1: d q[k] = sum_i slab[i][k] s[i]
+  if ((int)threadIdx.x < J) {
+    const int i = threadIdx.x;
+    float acc = 0.f;
+    for (int k = 0; k < J; ++k) acc = fmaf(slab[i * LD + k], qv[k], acc);
+    it.ds[s0 + (long long)i * ss] = acc;
+  } else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + J) {
+    const int k = threadIdx.x - 64;
+    float acc = 0.f;
+    for (int i = 0; i < J; ++i) acc = fmaf(slab[i * LD + k], sv[i], acc);
+    it.dq[q0 + (long long)k * qs] = acc;
+  }
+}
+
+static int cg_rank1_check(const CgRank1* items, int n, int B, int T, int V, bool bwd) {
+  if (!items || n <= 0 || n > 2) return CG_EARG;
+  if (B <= 0 || T <= 0 || V <= 0 || T > CG_R1_JMAX || V > CG_R1_JMAX) return CG_ESHAPE;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].s || !items[i].q || (items[i].domain != 0 && items[i].domain != 1)) return CG_EARG;
+    if (!bwd && (!items[i].o || ((uintptr_t)items[i].o & 15))) return CG_EARG;
+    if (bwd && (!items[i].dout || !items[i].ds || !items[i].dq || ((uintptr_t)items[i].dout & 15))) return CG_EARG;
+  }
+  return CG_OK;
+}
+
+// include/cistgcn_hip.h : cg_rank1_adj_fwd / cg_rank1_adj_bwd
+extern "C" int cg_rank1_adj_fwd(const CgRank1* items, int n, int B, int T, int V, void* stream_) {
+  int st = cg_rank1_check(items, n, B, T, V, false);
+  if (st != CG_OK) return st;
+  CgRank1Batch batch;
+  batch.n = n; batch.B = B; batch.T = T; batch.V = V;
+  for (int i = 0; i < 2; ++i) batch.it[i] = items[i < n ? i : 0];
+  const int ng = T > V ? T : V;
+  hipLaunchKernelGGL(cg_rank1_adj_fwd_kernel, dim3((unsigned)((long long)B * ng), (unsigned)n), dim3(256), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
+}
+
+extern "C" int cg_rank1_adj_bwd(const CgRank1* items, int n, int B, int T, int V, void* stream_) {
+  int st = cg_rank1_check(items, n, B, T, V, true);
+  if (st != CG_OK) return st;
+  CgRank1Batch batch;
+  batch.n = n; batch.B = B; batch.T = T; batch.V = V;
+  for (int i = 0; i < 2; ++i) batch.it[i] = items[i < n ? i : 0];
+  const int ng = T > V ? T : V;
+  hipLaunchKernelGGL(cg_rank1_adj_bwd_kernel, dim3((unsigned)((long long)B * ng), (unsigned)n), dim3(256), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
+}

@@ -428,14 +428,18 @@ class CISTGCN(nn.Module):
         o = _run_items(items)
         g = self._na_many([dict(x=o[0], bn=m.map_s[1], drop=True, prelu=m.map_s[3]), dict(x=o[1], bn=m.map_t[1], drop=True, prelu=m.map_t[3])])
         # 6. rank-1 products  o[b,v,t,tau] = s[b,v,t] q[b,tau,v]  |  o[b,t,v,w] = s[b,v,t] q[b,t,w]
-        outer = []
+        seeds = []
         for i, d in enumerate(doms):
             q, s = o[2 + 2 * i][0].view(B, T, V), o[3 + 2 * i][0].view(B, V, T)
-            outer.append((("bvt,bxv->bvtx" if d.domain == "space" else "bvt,btw->btvw"), s, q, None, None, None))
-        oo = ops.contract_many(outer)
+            seeds.append((0 if d.domain == "space" else 1, s, q))
+        if T <= 64 and V <= 64:
+            oo = ops.rank1_adj(seeds)                        # both towers in one launch; backward reads each d o once
+        else:
+            oo = [y for y, _ in ops.contract_many([("bvt,bxv->bvtx" if dom == 0 else "bvt,btw->btvw", s, q, None, None, None)
+                                                   for dom, s, q in seeds])]
         # 7. gate output Linear + expansor first map
         items = [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
-        items += [_pw_item(oo[i][0], a.expansor[0], tr) for i, a in enumerate(maps)]
+        items += [_pw_item(oo[i], a.expansor[0], tr) for i, a in enumerate(maps)]
         o = _run_items(items)
         m.w1, m.w2 = o[0][0], o[1][0]
         e = self._na_many([dict(x=o[2 + i], bn=a.expansor[1], drop=True, prelu=a.expansor[3]) for i, a in enumerate(maps)])

@@ -1064,6 +1064,59 @@ class _Cumsum(torch.autograd.Function):
         return dx
 
 
+class _Rank1Adj(torch.autograd.Function):
+    """Rank-1 adjacency seeds of the Map2Adj towers of one block (CISTGCN.py:183-189), all domains in one launch:
+    inputs (s_0, q_0, s_1, q_1, ...) with s (B,V,T), q (B,T,V); outputs o_i (B,V,T,T) for domain 0, (B,T,V,V) for 1."""
+
+    @staticmethod
+    def forward(ctx, domains, *sq):
+        ctx.set_materialize_grads(False)
+        n = len(domains)
+        B, V, T = sq[0].shape
+        sq = [t if t.is_contiguous() else _copy(t) for t in sq]
+        outs = []
+        arr = (_lib.Rank1 * n)()
+        for i, dom in enumerate(domains):
+            s, q = sq[2 * i], sq[2 * i + 1]
+            _chk(s, "s"), _chk(q, "q")
+            if tuple(s.shape) != (B, V, T) or tuple(q.shape) != (B, T, V):
+                raise ValueError("rank1_adj: expected s (B,V,T) and q (B,T,V), got %s / %s" % (tuple(s.shape), tuple(q.shape)))
+            o = torch.empty((B, V, T, T) if dom == 0 else (B, T, V, V), dtype=torch.float32, device=s.device)
+            arr[i].s, arr[i].q, arr[i].o, arr[i].domain = s.data_ptr(), q.data_ptr(), o.data_ptr(), dom
+            outs.append(o)
+        _lib.call("cg_rank1_adj_fwd", arr, n, B, T, V, _stream(sq[0]))
+        ctx.domains, ctx.dims = domains, (B, T, V)
+        ctx.save_for_backward(*sq)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        sq = ctx.saved_tensors
+        B, T, V = ctx.dims
+        live = [i for i, d in enumerate(douts) if d is not None]
+        grads = [None] * (2 * len(ctx.domains))
+        if live:
+            arr = (_lib.Rank1 * len(live))()
+            keep = []
+            for k, i in enumerate(live):
+                d = douts[i] if (douts[i].is_contiguous() and douts[i].data_ptr() % 16 == 0) else _copy(douts[i])
+                ds, dq = torch.empty_like(sq[2 * i]), torch.empty_like(sq[2 * i + 1])
+                arr[k].s, arr[k].q, arr[k].dout = sq[2 * i].data_ptr(), sq[2 * i + 1].data_ptr(), d.data_ptr()
+                arr[k].ds, arr[k].dq, arr[k].domain = ds.data_ptr(), dq.data_ptr(), ctx.domains[i]
+                grads[2 * i], grads[2 * i + 1] = ds, dq
+                keep.append(d)
+            _lib.call("cg_rank1_adj_bwd", arr, len(live), B, T, V, _stream(sq[0]))
+        return (None,) + tuple(grads)
+
+
+def rank1_adj(pairs):
+    """pairs: [(domain, s (B,V,T), q (B,T,V)), ...] (at most two) -> list of adjacency seeds, one launch"""
+    flat = []
+    for _, s, q in pairs:
+        flat += [s, q]
+    return list(_Rank1Adj.apply(tuple(int(p[0]) for p in pairs), *flat))
+
+
 def cumsum_time(x):
     """cumulative sum over axis 1 of a 4-D (possibly strided) tensor"""
     return _Cumsum.apply(x)

@@ -148,6 +148,13 @@ int cg_se_gate_fwd(const float* pooled, const float* W1, const float* W2, float*
 int cg_se_gate_bwd(const float* pooled, const float* W1, const float* W2, const float* gate, const float* dgate,
                    float* dpooled, float* dW1, float* dW2, int B, int C, int H, int prezeroed, void* stream);
 /* prezeroed != 0: dW1/dW2 are already zero (slices of the per-step zero pool), no memset is issued */
+/* rank-1 adjacency seed of Map2Adj, CISTGCN.py:183-189 (`torch.matmul` of the joint and time summaries): s (B,V,T) and
+ * q (B,T,V) contiguous; domain 0: o[b,v,t,u] = s[b,v,t]*q[b,u,v] (B,V,T,T); domain 1: o[b,t,v,w] = s[b,v,t]*q[b,t,w]
+ * (B,T,V,V).  Up to two problems (the space and time tower of one block) per launch; backward reads d o once and writes
+ * both d s and d q.  T, V <= 64; o / dout 16-byte aligned. */
+typedef struct CgRank1 { const float* s; const float* q; float* o; const float* dout; float* ds; float* dq; int domain; int pad; } CgRank1;
+int cg_rank1_adj_fwd(const CgRank1* items, int n, int B, int T, int V, void* stream);
+int cg_rank1_adj_bwd(const CgRank1* items, int n, int B, int T, int V, void* stream);
 /* cumsum over axis 1 of a strided 4-D view (B,L,R1,R2), CISTGCN.py:589 (reverse = adjoint) */
 int cg_cumsum(const float* x, const CgView4* xv, float* y, const CgView4* yv, int reverse, void* stream);
 /* MPJPE, losses/losses.py:50-61 (reduce_axis=[]): pred/target contiguous (N,3); loss is one float */

@@ -429,6 +429,18 @@ def check_dilated_convs(device):
         assert_close(d.bias.grad, r.bias.grad, "dilated db", rel=2e-5, floor=float(r.bias.grad.abs().max()))
 
 
+def check_rank1_adj(device):
+    """rank-1 adjacency seeds (Map2Adj): both domains in one launch, float4 slabs (T*T % 4 == 0) and odd slabs"""
+    g = _gen(14)
+    for (B, T, V) in ((3, 6, 5), (2, 10, 22), (2, 25, 7), (1, 64, 3)):
+        s0, q0, s1, q1 = _rand(g, B, V, T), _rand(g, B, T, V), _rand(g, B, V, T), _rand(g, B, T, V)
+        _run(lambda a, b, c, d: torch.cat([t.reshape(-1) for t in ops.rank1_adj([(0, a, b), (1, c, d)])]),
+             lambda a, b, c, d: torch.cat([torch.einsum("bvt,bxv->bvtx", a, b).reshape(-1), torch.einsum("bvt,btw->btvw", c, d).reshape(-1)]),
+             [s0, q0, s1, q1], device, what="rank1_adj B%d T%d V%d" % (B, T, V))
+    s, q = _rand(g, 2, 5, 6), _rand(g, 2, 6, 5)
+    _run(lambda a, b: ops.rank1_adj([(1, a, b)])[0], lambda a, b: torch.einsum("bvt,btw->btvw", a, b), [s, q], device, what="rank1_adj single")
+
+
 def check_stage_kernels(device):
     g = _gen(6)
     x = 50 + 350 * _rand(g, 3, 6, 5, 3)
