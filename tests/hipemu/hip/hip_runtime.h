@@ -63,6 +63,19 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return r;
 }
 
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+  static_assert(sizeof(T) <= 16, "shuffle payload");
+  const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64;
+  *reinterpret_cast<T*>(hipemu::wave_slot(wave, lane)) = v;
+  hipemu::wave_barrier(wave);
+  const int src = lane ^ mask;
+  T r = v;
+  if (src < 64 && (src / width) == (lane / width) && wave * 64 + src < (int)blockDim.x) r = *reinterpret_cast<T*>(hipemu::wave_slot(wave, src));
+  hipemu::wave_barrier(wave);
+  return r;
+}
+
 // v_mfma_f32_16x16x4_f32 on one "wave": every lane contributes A[i = lane & 15][k = lane >> 4] and
 // B[k = lane >> 4][j = lane & 15]; lane receives D[row = 4 * (lane >> 4) + reg][col = lane & 15].
 typedef float hipemu_f32x4 __attribute__((vector_size(16)));
