@@ -110,7 +110,7 @@ def check_contract(device, quick=False):
         assert_close(_chan_sums(st), torch.stack((rw.sum((0, 2, 3)), (rw * rw).sum((0, 2, 3))), 1).reshape(-1), "contract wide sums K=%d" % K_, rel=1e-5)
 
 
-def _check_norm_act_shape(device, quick, T, V):
+def _check_norm_act_shape(device, quick, T, V, trains=(True, False)):
     g = _gen(2)
     B, C = 4, 6
     x = _rand(g, B, C, T, V, scale=3.0) + 1.5
@@ -124,7 +124,7 @@ def _check_norm_act_shape(device, quick, T, V):
             bn.running_mean.copy_(_rand(g, C)); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
         return bn
 
-    for train in (True, False):
+    for train in trains:
         for use_pre in (False, True):
             for add_mode in (None, "pre", "post"):
                 for alpha_n in ((1, C) if (quick and add_mode == "pre") else ((1,) if quick else (0, 1, C))):
@@ -179,12 +179,13 @@ def _check_norm_act_shape(device, quick, T, V):
 
 def check_norm_act(device, quick=False):
     _check_norm_act_shape(device, quick, 5, 7)      # odd rows: strided scalar path
-    _check_norm_act_shape(device, True, 4, 6)       # rows of 24 contiguous floats: float4 path
+    _check_norm_act_shape(device, True, 4, 6, trains=(True,) if quick else (True, False))   # rows of 24 contiguous floats: float4 path
     # a larger float4 case (several rows per workgroup, addend before the PReLU, per-channel slopes)
     gb = _gen(21)
     bn_ref, pr_ref = nn.BatchNorm2d(3), nn.PReLU(3)
     bn_dev, pr_dev = nn.BatchNorm2d(3).to(device), nn.PReLU(3).to(device)
-    xb, ab = _rand(gb, 26, 3, 8, 120, scale=2.0) + 0.5, _rand(gb, 26, 3, 8, 120)
+    nb = 5 if quick else 26
+    xb, ab = _rand(gb, nb, 3, 8, 120, scale=2.0) + 0.5, _rand(gb, nb, 3, 8, 120)
     _run(lambda x_, a_: ops.norm_act(x_, bn=bn_dev, train=True, add=a_, prelu=pr_dev), lambda x_, a_: pr_ref(bn_ref(x_) + a_), [xb, ab],
          device, what="norm_act two-pass float4")
     assert_close(bn_dev.weight.grad, bn_ref.weight.grad, "two-pass dgamma", rel=2e-5, floor=float(bn_ref.weight.grad.abs().max()))
@@ -312,28 +313,30 @@ def check_reduce_and_gate(device):
          [_rand(g, 4, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate")
 
 
-def check_contract_kred(device):
+def check_contract_kred(device, quick=False):
     """weight-gradient shaped contractions (few outputs, long contiguous reduction) take the K-reduction kernel:
     one / four matrix-core tiles per wave, ragged edges, several output tiles, batch index, bias"""
     g = _gen(12)
     ops._KRED_MIN_K, saved = 0, ops._KRED_MIN_K          # the plan keeps short reductions on the tiled path; test sizes are short
     try:
-        _check_contract_kred(device, g)
+        _check_contract_kred(device, g, quick)
     finally:
         ops._KRED_MIN_K = saved
+    if quick:                                                          # the CPU shim is slow on long reductions
+        return
     a, x = _rand(g, 2, 3, 8, 5000), _rand(g, 2, 5, 8, 5000)          # K = 80 000: selected by the default plan
     _run(lambda a_, x_: ops.contract("bohw,bchw->oc", a_, x_), lambda a_, x_: torch.einsum("bohw,bchw->oc", a_, x_), [a, x], device,
          what="kred long K", rel=3e-5)
     assert any(p.mode == 2 and p.K == 80000 for p in ops._plans.values())
 
 
-def _check_contract_kred(device, g):
+def _check_contract_kred(device, g, quick=False):
     cases = [
         ("bohw,bchw->oc", (3, 7, 8, 12), (3, 5, 8, 12), None),          # 16x16 tile, K = 288
         ("bohw,bchw->oc", (2, 22, 20, 20), (2, 22, 20, 20), None),       # 32x32 tile, K = 800
         ("bohw,bchw->oc", (2, 40, 16, 32), (2, 60, 16, 32), None),       # 2 x 2 tiles of 32x32, K = 1024
         ("gok,gck->goc", (3, 9, 512), (3, 6, 512), None),                # batch index
-        ("ok,ck->oc", (18, 5000), (33, 5000), 18),                       # several splits per replica, bias
+        ("ok,ck->oc", (18, 1280 if quick else 5000), (33, 1280 if quick else 5000), 18),   # several splits per replica, bias
     ]
     for spec, sa, sx, nb in cases:
         a, x = _rand(g, *sa), _rand(g, *sx)
