@@ -65,40 +65,74 @@ class FlatGrads:
         self._copy(1)
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """Adam on ONE flat fp32 buffer.  Semantics of the reference's optimizer,
     `torch.optim.Adam(params, lr, weight_decay)` (environment/utils.py:53-57): L2 decay added to the gradient,
     bias-corrected moments, eps after the square root; optional `clip_grad_value_` (environment/train.py:97-98).
     The parameters are re-homed into slices of one buffer (views, no copies afterwards), gradients arrive through
-    `FlatGrads`, so the 698 per-tensor update launches of the stock optimizer become one kernel."""
+    `FlatGrads`, so the 698 per-tensor update launches of the stock optimizer become two kernels (gather + update).
+
+    It is a `torch.optim.Optimizer` with one parameter group, so the reference's schedulers drive it unchanged:
+    `LearningRateWarmUP` writes `param_groups[0]['lr']` (environment/utils.py:6-27) and `lr_scheduler.StepLR /
+    MultiStepLR / CosineAnnealingLR` (:30-43) accept it; the learning rate is read from the group at every step."""
 
     def __init__(self, model, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, flat=None):
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        device = self.params[0].device
-        self.grads = flat if flat is not None else FlatGrads(self.params, device)
+        params = [p for p in (model.parameters() if isinstance(model, torch.nn.Module) else model) if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value))
+        self.params = params
+        device = params[0].device
+        self.grads = flat if flat is not None else FlatGrads(params, device)
         self.flat_param = torch.empty(self.grads.numel, dtype=torch.float32, device=device)
         off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p in params:
                 n = p.numel()
                 self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + n].view(p.shape)       # same values, new home
                 off += n
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.lr, self.betas, self.eps, self.weight_decay, self.clip_value = lr, betas, eps, weight_decay, clip_value
         self.step_count = 0
 
-    def step(self, grad_scale=1.0, gathered=False):
+    # the hyper-parameters live in the (single) parameter group, where schedulers and callers expect them
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", v))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, gathered=False):
         """One update.  `grad_scale` folds the 1/world of a data-parallel sum; `gathered` = the flat gradient
         buffer is already filled (e.g. by GraphedStep / after the all-reduce)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         if not gathered:
             self.grads.gather()
         self.step_count += 1
-        f = self.flat_param
+        g, f = self.param_groups[0], self.flat_param
         _lib.call("cg_adam_flat", ops._ptr(f), ops._ptr(self.grads.flat), ops._ptr(self.exp_avg), ops._ptr(self.exp_avg_sq),
-                  f.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, self.clip_value,
-                  self.step_count, ops._stream(f))
+                  f.numel(), float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], float(g["weight_decay"]), grad_scale,
+                  float(g["clip_value"]), self.step_count, ops._stream(f))
+        return loss
+
+    def state_dict(self):
+        """moments and step count on the flat buffer + the parameter group (checkpoint 'optimizer' entry, train.py:184-194)"""
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        return {"flat": True, "step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_group": group}
+
+    def load_state_dict(self, state):
+        if not state.get("flat"):
+            raise ValueError("FlatAdam.load_state_dict: not a FlatAdam state (per-tensor torch.optim.Adam states are not converted)")
+        self.step_count = int(state["step"])
+        self.exp_avg.copy_(state["exp_avg"]); self.exp_avg_sq.copy_(state["exp_avg_sq"])
+        self.param_groups[0].update(state["param_group"])
+
+
+def set_optimizer(model, opt):
+    """Counterpart of the reference's `set_optimizer` (environment/utils.py:53-57): Adam with the YAML's `lr` and
+    `weight_decay` (`opt.learning_config`), as one flat-buffer update."""
+    lc = opt.learning_config
+    return FlatAdam(model, lr=float(lc.lr), weight_decay=float(lc.weight_decay))
 
 
 def allreduce_mean_(flat, group=None):

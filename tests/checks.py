@@ -628,6 +628,36 @@ def check_flat_adam(device):
         opt_dev.step()
         for (k, pr), pd in zip(ref.named_parameters(), dev.parameters()):
             assert_close(pd, pr, "adam step %d %s" % (step, k), rel=1e-5)
+    # the optimizer is driven by stock schedulers and by writes to param_groups (the reference's warm-up helper does that)
+    sch_ref = torch.optim.lr_scheduler.StepLR(opt_ref, step_size=2, gamma=0.5)
+    sch_dev = torch.optim.lr_scheduler.StepLR(opt_dev, step_size=2, gamma=0.5)
+    for step in range(5):
+        if step == 3:
+            for o in (opt_ref, opt_dev):
+                for grp in o.param_groups:
+                    grp["lr"] = grp["lr"] * 3.0
+        for pr, pd in zip(ref.parameters(), dev.parameters()):
+            gr = torch.randn(pr.shape, generator=g)
+            pr.grad = gr.clone()
+            pd.grad = gr.clone().to(device)
+        opt_ref.step(); opt_dev.step()
+        sch_ref.step(); sch_dev.step()
+        assert abs(opt_ref.param_groups[0]["lr"] - opt_dev.param_groups[0]["lr"]) < 1e-12
+        for (k, pr), pd in zip(ref.named_parameters(), dev.parameters()):
+            assert_close(pd, pr, "adam scheduled step %d %s" % (step, k), rel=2e-5)
+    # checkpoint round trip of the optimizer state
+    state = opt_dev.state_dict()
+    dev_b = nn.Sequential(nn.Linear(13, 7), nn.BatchNorm1d(7), nn.Linear(7, 300), nn.PReLU())
+    dev_b.load_state_dict(dev.state_dict()); dev_b.to(device)
+    opt_b = FlatAdam(dev_b, lr=1.0)
+    opt_b.load_state_dict(state)
+    assert opt_b.step_count == opt_dev.step_count and abs(opt_b.lr - opt_dev.lr) < 1e-12
+    for pd, pb in zip(dev.parameters(), dev_b.parameters()):
+        gr = torch.randn(pd.shape, generator=g).to(device)
+        pd.grad, pb.grad = gr.clone(), gr.clone()
+    opt_dev.step(); opt_b.step()
+    for pd, pb in zip(dev.parameters(), dev_b.parameters()):
+        assert_close(pb, pd.detach().cpu(), "adam resumed", rel=1e-6)
     # clip_grad_value_ + gradient pre-scale (data-parallel mean)
     ref2, dev2 = nn.Linear(5, 4), nn.Linear(5, 4)
     dev2.load_state_dict(ref2.state_dict()); dev2.to(device)
