@@ -89,6 +89,8 @@ _SIGNATURES = {
     "cg_sum_many": [P, POINTER(View4), POINTER(SumItem), c_int, P],
     "cg_rank1_adj_fwd": [POINTER(Rank1), c_int, c_int, c_int, c_int, P],
     "cg_rank1_adj_bwd": [POINTER(Rank1), c_int, c_int, c_int, c_int, P],
+    "cg_gather_joints": [P, P, P, LL, c_int, c_int, P],
+    "cg_eval_scatter_mpjpe": [P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_add3": [P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P, POINTER(View4), P],
     "cg_zero": [P, LL, P],
     "cg_feature_lift_fwd": [P, P, LL, LL, LL, P],

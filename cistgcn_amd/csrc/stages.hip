@@ -492,3 +492,62 @@ extern "C" int cg_rank1_adj_bwd(const CgRank1* items, int n, int B, int T, int V
   hipLaunchKernelGGL(cg_rank1_adj_bwd_kernel, dim3((unsigned)((long long)B * ng), (unsigned)n), dim3(256), 0, (hipStream_t)stream_, batch);
   return cg_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation harness counterpart, environment/test.py:97-132 + losses.py:50-61:
+//   inputs[:, :, dim_used]                                     -> cg_gather_joints
+//   mygt = target.clone(); mygt[:, :, dim_used] = outputs; mygt[:, :, dim_repeat_32] = outputs[:, :, dim_repeat_22]
+//   mpjpe(mygt, target, reduce_axis=(0, 2))  (per predicted frame)   -> cg_eval_scatter_mpjpe (one pass, one launch)
+// `src[j]` = joint of the prediction that full-skeleton joint j takes, or -1 (keeps the ground truth).
+// ---------------------------------------------------------------------------------------------
+__global__ void cg_gather_joints_kernel(const float* __restrict__ x, float* __restrict__ y, const int32_t* __restrict__ idx,
+                                        long long rows, int Jin, int Jout) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * Jout) return;
+  const long long r = i / Jout;
+  const int k = (int)(i - r * Jout);
+  const float* s = x + (r * Jin + idx[k]) * 3;
+  float* d = y + i * 3;
+  d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+extern "C" int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long rows, int Jin, int Jout, void* stream_) {
+  if (!x || !y || !idx) return CG_EARG;
+  if (rows <= 0 || Jin <= 0 || Jout <= 0) return CG_ESHAPE;
+  const long long n = rows * Jout;
+  hipLaunchKernelGGL(cg_gather_joints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, x, y, idx, rows, Jin, Jout);
+  return cg_launch_status();
+}
+
+// one workgroup per (sample, frame): writes the J32 joints of `out` and adds the frame's mean joint error / B
+__global__ void cg_eval_scatter_mpjpe_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ out,
+                                             float* __restrict__ frame_err, const int32_t* __restrict__ src, int B, int To, int J32, int J22) {
+  __shared__ float red[16];
+  const int b = blockIdx.x / To, t = blockIdx.x - b * To;
+  const float* tg = target + ((long long)b * To + t) * J32 * 3;
+  const float* pr = pred + ((long long)b * To + t) * J22 * 3;
+  float* o = out + ((long long)b * To + t) * J32 * 3;
+  float e = 0.f;
+  for (int j = threadIdx.x; j < J32; j += blockDim.x) {
+    const int k = src[j];
+    const float gx = tg[3 * j], gy = tg[3 * j + 1], gz = tg[3 * j + 2];
+    const float px = k >= 0 ? pr[3 * k] : gx, py = k >= 0 ? pr[3 * k + 1] : gy, pz = k >= 0 ? pr[3 * k + 2] : gz;
+    o[3 * j] = px; o[3 * j + 1] = py; o[3 * j + 2] = pz;
+    const float dx = px - gx, dy = py - gy, dz = pz - gz;
+    e += sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  e = cg_block_sum(e, red);
+  if (threadIdx.x == 0) atomicAdd(&frame_err[t], e / ((float)J32 * (float)B));
+}
+
+extern "C" int cg_eval_scatter_mpjpe(const float* pred, const float* target, float* out, float* frame_err, const int32_t* src,
+                                     int B, int To, int J32, int J22, void* stream_) {
+  if (!pred || !target || !out || !frame_err || !src) return CG_EARG;
+  if (B <= 0 || To <= 0 || J32 <= 0 || J22 <= 0) return CG_ESHAPE;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipError_t e = hipMemsetAsync(frame_err, 0, (size_t)To * sizeof(float), stream);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(cg_eval_scatter_mpjpe_kernel, dim3((unsigned)((long long)B * To)), dim3(64), 0, stream, pred, target, out, frame_err,
+                     src, B, To, J32, J22);
+  return cg_launch_status();
+}

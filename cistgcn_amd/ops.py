@@ -1117,6 +1117,61 @@ def rank1_adj(pairs):
     return list(_Rank1Adj.apply(tuple(int(p[0]) for p in pairs), *flat))
 
 
+# ----------------------------------------------------------------------------------------------
+# evaluation harness counterpart (environment/test.py:97-132): no autograd, the reference runs it under no_grad
+# ----------------------------------------------------------------------------------------------
+_index_cache = {}
+
+
+def _index_tensor(values, device):
+    key = (tuple(int(v) for v in values), str(_dev(device)))
+    t = _index_cache.get(key)
+    if t is None:
+        t = _index_cache[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+    return t
+
+
+def gather_joints(x, dim_used):
+    """`inputs[:, :, dim_used]` (test.py:101): (B,T,J,3) -> (B,T,len(dim_used),3)"""
+    _chk(x, "x")
+    if x.dim() != 4 or x.shape[3] != 3:
+        raise ValueError("gather_joints: expected (B,T,J,3), got %s" % (tuple(x.shape),))
+    dim_used = [int(v) for v in dim_used]
+    if not dim_used or min(dim_used) < 0 or max(dim_used) >= x.shape[2]:
+        raise IndexError("gather_joints: joint index out of range")
+    x = x if x.is_contiguous() else _copy(x)
+    B, T, J, _ = x.shape
+    y = torch.empty(B, T, len(dim_used), 3, dtype=torch.float32, device=x.device)
+    _lib.call("cg_gather_joints", _ptr(x), _ptr(y), _ptr(_index_tensor(dim_used, x.device)), B * T, J, len(dim_used), _stream(x))
+    return y
+
+
+def eval_scatter_mpjpe(pred, target, dim_used, dim_repeat_32=(), dim_repeat_22=()):
+    """Post-processing of `_predict` (test.py:121-127) and the per-frame MPJPE (losses.py:50-61, reduce_axis (0,2)) in one
+    launch: returns (full-skeleton prediction (B,To,J,3), error per frame (To,))."""
+    _chk(pred, "pred"), _chk(target, "target")
+    if pred.dim() != 4 or target.dim() != 4 or pred.shape[:2] != target.shape[:2] or pred.shape[3] != 3 or target.shape[3] != 3:
+        raise ValueError("eval_scatter_mpjpe: expected pred (B,To,J22,3) and target (B,To,J32,3)")
+    B, To, J22, _ = pred.shape
+    J32 = target.shape[2]
+    if len(dim_used) != J22 or len(dim_repeat_32) != len(dim_repeat_22):
+        raise ValueError("eval_scatter_mpjpe: index lists do not match the tensors")
+    src = [-1] * J32
+    for k, j in enumerate(dim_used):
+        src[int(j)] = k
+    for j, k in zip(dim_repeat_32, dim_repeat_22):            # applied after the scatter, as in the reference
+        src[int(j)] = int(k)
+    if max(src) >= J22:
+        raise IndexError("eval_scatter_mpjpe: repeated joint index out of range")
+    pred = pred if pred.is_contiguous() else _copy(pred)
+    target = target if target.is_contiguous() else _copy(target)
+    out = torch.empty_like(target)
+    err = torch.empty(To, dtype=torch.float32, device=pred.device)
+    _lib.call("cg_eval_scatter_mpjpe", _ptr(pred), _ptr(target), _ptr(out), _ptr(err), _ptr(_index_tensor(src, pred.device)),
+              B, To, J32, J22, _stream(pred))
+    return out, err
+
+
 def cumsum_time(x):
     """cumulative sum over axis 1 of a 4-D (possibly strided) tensor"""
     return _Cumsum.apply(x)

@@ -181,6 +181,15 @@ int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const 
                         float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain,
                         int ws_prezeroed, void* stream);
 
+/* ---- evaluation harness counterpart, environment/test.py:97-132 ----------------------
+ * y[r,k,:] = x[r,idx[k],:] : `inputs[:, :, dim_used]` (32 -> 22 joints); x (rows,Jin,3), y (rows,Jout,3) contiguous */
+int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long rows, int Jin, int Jout, void* stream);
+/* out = target with the prediction scattered back (`mygt[:, :, dim_used] = outputs`, repeated joints copied, test.py:121-127)
+ * and frame_err[t] = mean over samples and joints of |out - target| (losses.mpjpe, reduce_axis (0,2), losses.py:50-61).
+ * pred (B,To,J22,3), target/out (B,To,J32,3); src[j] = prediction joint taken by skeleton joint j, or -1 (ground truth kept) */
+int cg_eval_scatter_mpjpe(const float* pred, const float* target, float* out, float* frame_err, const int32_t* src,
+                          int B, int To, int J32, int J22, void* stream);
+
 /* ---- optimizer on the flat parameter buffer -----------------------------------
  * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,
  * bias-corrected moments; optional clip_grad_value_ (environment/train.py:97-98) and gradient

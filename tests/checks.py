@@ -444,6 +444,30 @@ def check_rank1_adj(device):
     _run(lambda a, b: ops.rank1_adj([(1, a, b)])[0], lambda a, b: torch.einsum("bvt,btw->btvw", a, b), [s, q], device, what="rank1_adj single")
 
 
+def check_eval_harness(device):
+    """evaluation-harness kernels (input joint gather, prediction scatter + per-frame MPJPE) against the golden vectors of the
+    reference's `_predict` / `losses.mpjpe` and against the oracle on ragged sizes"""
+    from oracle import eval_ref as E
+    from helpers import load_case
+    rec = load_case("eval_h36m")
+    t = lambda k: torch.from_numpy(rec[k])
+    used, r22, r32 = rec["dim_used"].tolist(), rec["rep22"].tolist(), rec["rep32"].tolist()
+    got = ops.gather_joints(t("inputs").to(device), used)
+    assert torch.equal(got.cpu(), t("model_input")), "joint gather"
+    full, frames = ops.eval_scatter_mpjpe(t("model_output").to(device), t("target").to(device), used, r32, r22)
+    assert torch.equal(full.cpu(), t("predicted_full")), "scattered prediction"
+    assert_close(frames, t("mpjpe_frames"), "per-frame MPJPE", rel=1e-5)
+    g = _gen(15)
+    pred, tgt = _rand(g, 3, 7, 4, 3), _rand(g, 3, 7, 9, 3)                 # no repeated joints, odd sizes, strided input
+    used2 = [8, 0, 5, 2]
+    full, frames = ops.eval_scatter_mpjpe(pred.to(device), tgt.to(device), used2)
+    ref = E.scatter_prediction(pred, tgt, used2)
+    assert torch.equal(full.cpu(), ref)
+    assert_close(frames, E.mpjpe_frames(ref, tgt), "per-frame MPJPE (no repeats)", rel=1e-5)
+    xs = _rand(g, 2, 9, 6, 3).to(device).permute(0, 2, 1, 3)               # non-contiguous
+    assert torch.equal(ops.gather_joints(xs, [3, 3, 0]).cpu(), xs.cpu()[:, :, [3, 3, 0]])
+
+
 def check_stage_kernels(device):
     g = _gen(6)
     x = 50 + 350 * _rand(g, 3, 6, 5, 3)

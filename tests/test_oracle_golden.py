@@ -97,3 +97,15 @@ def test_ctor_does_not_mutate_config():
     O.CISTGCN(arch, learn)
     assert arch.model_params.input_gcn.model_complexity == [8] * 4
     assert arch.model_params.output_gcn.model_complexity == [3]
+
+
+def test_eval_postprocess_matches_reference():
+    """oracle/eval_ref.py against vectors produced by the reference's own `_predict` + `losses.mpjpe` (tools/gen_golden_eval.py)"""
+    from oracle import eval_ref as E
+    rec = load_case("eval_h36m")
+    t = lambda k: torch.from_numpy(rec[k])
+    used, r22, r32 = rec["dim_used"].tolist(), rec["rep22"].tolist(), rec["rep32"].tolist()
+    assert torch.equal(E.gather_used(t("inputs"), used), t("model_input"))
+    full = E.scatter_prediction(t("model_output"), t("target"), used, r32, r22)
+    assert torch.equal(full, t("predicted_full"))
+    assert_close(E.mpjpe_frames(full, t("target")), t("mpjpe_frames"), "per-frame MPJPE", rel=1e-6)
