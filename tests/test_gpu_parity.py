@@ -57,6 +57,42 @@ def test_gradients_as_accurate_as_cpu_fp32(cfg, mode):
     checks.check_model_vs_oracle("cuda", C, T, V, B, mode, smooth=True)
 
 
+def test_full_size_batch_is_consistent_with_its_chunks():
+    """BASELINE configs[2] size (C=64, B=256, 50->25, V=22): the launch plans that only exist at this size (streaming
+    contraction, K-reduction weight gradients, many rows per workgroup) against the small-batch plans the oracle tests pin.
+    Size-independent properties in eval mode (running statistics, no dropout): (a) a sample's prediction does not depend on
+    its batch; (b) MPJPE is a mean over samples, so the parameter gradients of the batch are the mean of its chunks'."""
+    from cistgcn_amd import ops
+    C, T, V, B, nchunk = 64, 50, 22, 256, 8
+    net, _ = checks.build_pair(C, T, V, "cuda")
+    net.eval()
+    g = torch.Generator().manual_seed(11)
+    x = (50 + 350 * torch.randn(B, T, V, 3, generator=g)).cuda()
+    tgt = (x[:, -1:].cpu() + 20 * torch.randn(B, 25, V, 3, generator=g)).cuda()
+    net.zero_grad()
+    pred, = net(x)
+    ops.mpjpe(pred, tgt).backward()
+    assert any(p.mode == 1 for p in ops._plans.values()) and any(p.mode == 2 for p in ops._plans.values()), "full-size plans not exercised"
+    big = {k: p.grad.clone() for k, p in net.named_parameters()}
+    pred = pred.detach()
+    acc = {k: torch.zeros_like(v) for k, v in big.items()}
+    step = B // nchunk
+    for c in range(nchunk):
+        sl = slice(c * step, (c + 1) * step)
+        net.zero_grad()
+        pc, = net(x[sl])
+        scale = max(1.0, float(pred[sl].abs().max()))
+        assert float((pc.detach() - pred[sl]).abs().max()) <= 1e-4 * scale, "prediction of chunk %d depends on the batch" % c
+        ops.mpjpe(pc, tgt[sl]).backward()
+        for k, p in net.named_parameters():
+            acc[k] += p.grad / nchunk
+    for k in big:
+        ref, got = acc[k].double(), big[k].double()
+        rms = float(ref.pow(2).mean().sqrt())
+        err = float((got - ref).pow(2).mean().sqrt())
+        assert err <= 2e-3 * rms + 1e-7, "gradient of %s: batch vs mean of chunks rms err %.3e (rms %.3e)" % (k, err, rms)
+
+
 def test_cpu_tensors_are_refused():
     from cistgcn_amd import ops
     with pytest.raises(RuntimeError):
