@@ -57,13 +57,25 @@ __global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
   const int P = (int)(xv.n[2] * xv.n[3]);
   const int nb = min(rb, (int)xv.n[0] - b0);
   double s = 0.0, q = 0.0;
-  CG_CHUNK_LOOP(nb, P, e) {
-    CG_CHUNK_ROW(e, P, b0)
-    CG_POS(xv, p)
-    const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
-    const float v = x[cg_row_base(xv, b, c) + CG_OFF(xv)] * w;
-    s += (double)v;
-    q += (double)v * (double)v;
+  if (it.pad) {                                   // pad = 1: contiguous 16-byte aligned rows (float4 path)
+    const int P4 = P >> 2;
+    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
+      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+      const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
+      const float4 v4 = *reinterpret_cast<const float4*>(x + cg_row_base(xv, b, c) + p);
+      const float v[4] = {v4.x * w, v4.y * w, v4.z * w, v4.w * w};
+      s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+      q += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+    }
+  } else {
+    CG_CHUNK_LOOP(nb, P, e) {
+      CG_CHUNK_ROW(e, P, b0)
+      CG_POS(xv, p)
+      const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
+      const float v = x[cg_row_base(xv, b, c) + CG_OFF(xv)] * w;
+      s += (double)v;
+      q += (double)v * (double)v;
+    }
   }
   s = cg_block_sum(s, red);
   q = cg_block_sum(q, red + 16);
@@ -75,6 +87,7 @@ __global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
 }
 
 struct CgStatsArgs { const float* x; CgView4 xv; const float* pre; double* stats; };
+static bool cg_view_vec(const void* ptr, const CgView4& v);      // contiguous 16-byte aligned rows (defined with the row kernels below)
 
 // include/cistgcn_hip.h : cg_chan_stats_many (up to CG_ROW_MAX_BATCH tensors per launch)
 extern "C" int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream_) {
@@ -88,7 +101,8 @@ extern "C" int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream_
     const long long P = a.xv.n[2] * a.xv.n[3];
     if (a.xv.n[0] <= 0 || a.xv.n[1] <= 0 || P <= 0) return CG_ESHAPE;
     const int rb = cg_rows_per_block(a.xv);
-    batch.it[i].x = a.x; batch.it[i].xv = a.xv; batch.it[i].pre = a.pre; batch.it[i].stats = a.stats; batch.it[i].rb = rb; batch.it[i].pad = 0;
+    batch.it[i].x = a.x; batch.it[i].xv = a.xv; batch.it[i].pre = a.pre; batch.it[i].stats = a.stats; batch.it[i].rb = rb;
+    batch.it[i].pad = cg_view_vec(a.x, a.xv) ? 1 : 0;          // float4 path flag
     gx = gx > a.xv.n[1] ? gx : a.xv.n[1];
     const long long chunks = (a.xv.n[0] + rb - 1) / rb;
     gy = gy > chunks ? gy : chunks;
