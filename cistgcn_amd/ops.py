@@ -324,6 +324,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
 
 
 _MAX_CONTRACT_BATCH = 16
+_ACC_MAX_FLOATS = 1 << 22      # shared-input gradients: fp32 atomics into one buffer up to this size, else separate outputs + one sum
 
 
 def _contract_launch(builders, device, groups=None):
@@ -440,7 +441,7 @@ class _ContractMany(torch.autograd.Function):
                 key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
                 builders.append(lambda out, s="%s,%s->%s" % (la, ly, lx), a=a, dy=dy: _contract_prepare(s, a, dy, out=out))
                 # large tensors: float atomics are slower than separate outputs + adds (MI355X ~1.3 TB/s of atomic bytes)
-                small = x.numel() * len(shared[key]) <= (1 << 22)
+                small = x.numel() * len(shared[key]) <= _ACC_MAX_FLOATS
                 slots.append(3 * i + 1); groups.append(key if (len(shared[key]) > 1 and small) else None)
             if ctx.needs_input_grad[3 + 3 * i]:
                 builders.append(_sum_keep_builder(dy, ly, bias_label))
@@ -448,12 +449,21 @@ class _ContractMany(torch.autograd.Function):
         res = [None] * (3 * len(ctx.metas))
         if builders:
             seen = set()
+            big = {}            # shared input too large for atomics: its gradients are separate outputs, summed by ONE launch below
             for slot, grp, r in zip(slots, groups, _contract_launch(builders, dev, groups)):
                 if grp is not None:
                     if grp in seen:
                         continue          # the shared buffer already holds the sum; hand it to autograd once
                     seen.add(grp)
+                elif slot % 3 == 1:
+                    x = saved[2 * (slot // 3) + 1]
+                    key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+                    if len(shared.get(key, ())) > 1:
+                        big.setdefault(key, []).append((slot, r.y))
+                        continue
                 res[slot] = r.y
+            for parts in big.values():      # autograd would add them pairwise: (n-1) x (2 reads + 1 write) of the tensor
+                res[parts[0][0]] = _sum_tensors([y for _, y in parts])
         return (None,) + tuple(res)
 
 
@@ -772,6 +782,30 @@ def _add_into(y, a, b=None, c=None):
               ctypes.byref(vb) if vb is not None else None, _ptr(c), ctypes.byref(vc) if vc is not None else None, _stream(y))
 
 
+def _sum_tensors(ts):
+    """sum of same-shape tensors in one launch per eight inputs (cg_sum_many)"""
+    if len(ts) == 1:
+        return ts[0]
+    out = torch.empty(ts[0].shape, dtype=torch.float32, device=ts[0].device)
+    y = out if out.dim() >= 2 else out.view(1, -1)
+    if y.dim() > 4:
+        y = y.reshape(y.shape[0], -1)
+    ts = list(ts)
+    while ts:
+        part, ts = ts[:_SUM_MAX], ts[_SUM_MAX:]
+        if ts:                                  # more than eight: fold the partial sum into the next round
+            ts.insert(0, out)
+        arr = (_lib.SumItem * len(part))()
+        for i, g in enumerate(part):
+            g = g if g.dim() >= 2 else g.view(1, -1)
+            if g.dim() > 4:
+                g = g.reshape(g.shape[0], -1)
+            arr[i].a, arr[i].av = g.data_ptr(), _view4(g)
+        vy = _view4(y)
+        _lib.call("cg_sum_many", _ptr(y), ctypes.byref(vy), arr, len(part), _stream(y))
+    return out
+
+
 class _Fanout(torch.autograd.Function):
     """n aliases of one tensor, one per consumer: backward sums the consumers' gradients with ONE kernel instead of
     one autograd accumulation kernel per extra consumer."""
@@ -788,19 +822,7 @@ class _Fanout(torch.autograd.Function):
             return None, None
         if len(gs) == 1:
             return gs[0], None
-        out = torch.empty(gs[0].shape, dtype=torch.float32, device=gs[0].device)
-        y = out if out.dim() >= 2 else out.view(1, -1)
-        while gs:
-            part, gs = gs[:_SUM_MAX], gs[_SUM_MAX:]
-            if gs:                                  # more than eight consumers: fold the partial sum into the next round
-                gs.insert(0, out)
-            arr = (_lib.SumItem * len(part))()
-            for i, g in enumerate(part):
-                g = g if g.dim() >= 2 else g.view(1, -1)
-                arr[i].a, arr[i].av = g.data_ptr(), _view4(g)
-            vy = _view4(y)
-            _lib.call("cg_sum_many", _ptr(y), ctypes.byref(vy), arr, len(part), _stream(y))
-        return out, None
+        return _sum_tensors(gs), None
 
 
 _SUM_MAX = 8

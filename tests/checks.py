@@ -246,6 +246,14 @@ def check_batched_ops(device):
     y0 = yr[0].detach().double()
     assert_close(_chan_sums(sts[0]), torch.stack((y0.sum((0, 2, 3)), (y0 * y0).sum((0, 2, 3))), 1).reshape(-1), "epilogue sums", rel=1e-6)
     assert sts[1] is None and sts[2] is None
+    # the large-tensor plan for shared inputs (separate gradient outputs summed by one launch instead of atomics)
+    ops._ACC_MAX_FLOATS, saved = 0, ops._ACC_MAX_FLOATS
+    try:
+        _, _, gr2 = run(device, True)
+    finally:
+        ops._ACC_MAX_FLOATS = saved
+    for i, (a, b) in enumerate(zip(gr2, grr)):
+        assert_close(a, b, "contract_many (summed outputs) grad%d" % i, rel=2e-5, floor=float(b.abs().max()))
     # row problems of different shapes in one launch, one of them emitting the sums of its output
     shapes = [(4, 6, 4, 7), (4, 3, 1, 9), (6, 5)]       # float4 rows, scalar rows, BatchNorm1d in one launch
     xs = [_rand(g, *sh, scale=2.0) + 0.5 for sh in shapes]
