@@ -50,7 +50,7 @@ class ContractDesc(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("X", c_void_p), ("Y", c_void_p), ("bias", c_void_p), ("stats", c_void_p), ("tab", c_void_p),
                 ("G", c_int), ("M", c_int), ("N", c_int), ("K", c_int), ("splitk", c_int), ("kchunk", c_int),
                 ("a_kfast", c_int), ("x_kfast", c_int), ("accumulate", c_int), ("x_vec", c_int), ("stat_ch", c_int), ("mode", c_int), ("block0", c_longlong),
-                ("ws", c_void_p)]
+                ("ws", c_void_p), ("chain", c_int), ("pad2", c_int)]
 
 
 class StatsArgs(ctypes.Structure):

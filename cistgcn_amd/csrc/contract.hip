@@ -33,6 +33,8 @@ struct CgContractDesc {
   int mode;                  // 0: tiled kernel below; 1: streaming kernel (cg_stream_body); 2: K-reduction (cg_kred_body)
   long long block0;          // first block id of this problem inside the launch
   float* ws;                 // mode 2: zeroed scratch of cg_contract_kred_ws_floats(G, M, N) floats
+  int chain;                 // mode 1: 1 + index (in the caller's array) of a problem whose product is ADDED to this one's
+  int pad2;                  //         output in registers (same G, M, N; it writes nothing itself), 0 = none
 };
 #define CG_MAX_BATCH 16
 struct CgContractBatch { int n; int pad; CgContractDesc d[CG_MAX_BATCH]; };
@@ -273,20 +275,16 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
 #define CG_ST_LDA 68                  // A panel row stride (floats): k-rows l4 = 0..3 of a fragment read fall on distinct banks
 
 template <int MI>
-__device__ __forceinline__ void cg_stream_body(const CgContractDesc& d, long long bid, float* As, int32_t* sKX, double* sStat_) {
-  const float* __restrict__ A = d.A; const float* __restrict__ X = d.X; float* __restrict__ Y = d.Y;
+__device__ __forceinline__ void cg_stream_body(const CgContractBatch& batch, const int pi, long long bid, float* As,
+                                               int32_t* sKX, double* sStat_) {
+  const CgContractDesc& d = batch.d[pi];
+  float* __restrict__ Y = d.Y;
   const float* __restrict__ bias = d.bias; double* __restrict__ stats = d.stats;
-  const int G = d.G, M = d.M, N = d.N, K = d.K;
-  const int32_t* gA = d.tab;
-  const int32_t* gX = gA + G;
-  const int32_t* gY = gX + G;
-  const int32_t* mA = gY + G;
-  const int32_t* mY = mA + M;
+  const int G = d.G, M = d.M, N = d.N;
+  const int32_t* gY = d.tab + 2 * G;
+  const int32_t* mY = gY + G + M;
   const int32_t* mB = mY + M;
-  const int32_t* nX = mB + M;
-  const int32_t* nY = nX + N;
-  const int32_t* kA = nY + N;
-  const int32_t* kX = kA + K;
+  const int32_t* nY = mB + M + N;
   double (*sStat)[2] = reinterpret_cast<double (*)[2]>(sStat_);
   constexpr int BM = 16 * MI;
   const int tiles_n = (N + 255) / 256, tiles_m = (M + BM - 1) / BM;
@@ -295,20 +293,9 @@ __device__ __forceinline__ void cg_stream_body(const CgContractDesc& d, long lon
   const int g = (int)bid;
   const int m0 = tm * BM;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-  const int Kp = (K + 3) & ~3;
-
-  // A panel [Kp][BM] and the k offsets of X into LDS
-  const long long baseA = gA[g];
-  for (int e = tid; e < Kp * BM; e += 256) {
-    const int k = e / BM, mm = e - k * BM, m = m0 + mm;
-    As[k * CG_ST_LDA + mm] = (k < K && m < M) ? A[baseA + mA[m] + kA[k]] : 0.f;
-  }
-  for (int k = tid; k < Kp; k += 256) sKX[k] = k < K ? kX[k] : 0;
   if (stats != nullptr && tid < 2 * BM) sStat[tid >> 1][tid & 1] = 0.0;
   const int n = tn * 256 + 64 * wv + 4 * l15;          // first of this lane's four columns (N % 4 == 0)
   const bool col_ok = n < N;
-  const long long xoff = col_ok ? (long long)gX[g] + nX[n] : 0;
-  __syncthreads();
 
   cg_f32x4 acc[MI][4];
 #pragma unroll
@@ -316,6 +303,30 @@ __device__ __forceinline__ void cg_stream_body(const CgContractDesc& d, long lon
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[i][q] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int KU = 8;                                // k-steps (of four k) per chunk
+  // the head problem and every problem chained to it (sum of several maps into one output: the input gradient of a
+  // tensor that feeds several pointwise maps) run through the same accumulators; only the head writes
+  // (the links are walked by INDEX into the kernel-argument struct: a loop-carried pointer into it would force the
+  // whole batch into scratch memory)
+  for (int li = pi; li >= 0; li = batch.d[li].chain - 1) {
+  const float* __restrict__ A = batch.d[li].A; const float* __restrict__ X = batch.d[li].X;
+  const int K = batch.d[li].K;
+  const int32_t* gA = batch.d[li].tab;
+  const int32_t* gX = gA + G;
+  const int32_t* mA = gX + 2 * G;
+  const int32_t* nX = mA + 3 * M;
+  const int32_t* kA = nX + 2 * N;
+  const int32_t* kX = kA + K;
+  const int Kp = (K + 3) & ~3;
+  if (li != pi) __syncthreads();                       // every wave is done with the previous A panel
+  // A panel [Kp][BM] and the k offsets of X into LDS
+  const long long baseA = gA[g];
+  for (int e = tid; e < Kp * BM; e += 256) {
+    const int k = e / BM, mm = e - k * BM, m = m0 + mm;
+    As[k * CG_ST_LDA + mm] = (k < K && m < M) ? A[baseA + mA[m] + kA[k]] : 0.f;
+  }
+  for (int k = tid; k < Kp; k += 256) sKX[k] = k < K ? kX[k] : 0;
+  const long long xoff = col_ok ? (long long)gX[g] + nX[n] : 0;
+  __syncthreads();
   const int nsteps = Kp >> 2;
   for (int s0 = 0; s0 < nsteps; s0 += KU) {            // uniform over the workgroup
     float4 xv[KU];
@@ -338,6 +349,7 @@ __device__ __forceinline__ void cg_stream_body(const CgContractDesc& d, long lon
       }
     }
   }
+  }   // chain
 
   const long long baseY = gY[g];
   const bool atomic_out = d.accumulate != 0;
@@ -379,13 +391,13 @@ __global__ __launch_bounds__(256, 3) void cg_contract_stream_kernel(CgContractBa
   __shared__ double sStat[64 * 2];
   long long bid = blockIdx.x;
   int pi = 0;
-  for (int i = 1; i < batch.n; ++i)
-    if (bid >= batch.d[i].block0) pi = i;
-  const CgContractDesc& d = batch.d[pi];
-  bid -= d.block0;
-  if (d.M <= 16) cg_stream_body<1>(d, bid, As, sKX, sStat);
-  else if (d.M <= 32) cg_stream_body<2>(d, bid, As, sKX, sStat);
-  else cg_stream_body<4>(d, bid, As, sKX, sStat);
+  for (int i = 0; i < batch.n; ++i)                     // chained members own no blocks (block0 < 0)
+    if (batch.d[i].block0 >= 0 && bid >= batch.d[i].block0) pi = i;
+  bid -= batch.d[pi].block0;
+  const int M = batch.d[pi].M;
+  if (M <= 16) cg_stream_body<1>(batch, pi, bid, As, sKX, sStat);
+  else if (M <= 32) cg_stream_body<2>(batch, pi, bid, As, sKX, sStat);
+  else cg_stream_body<4>(batch, pi, bid, As, sKX, sStat);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -568,6 +580,8 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
   CgContractBatch strm;                     // streaming problems: their own kernel (register budget), one launch
   batch.n = 0; batch.pad = 0; strm.n = 0; strm.pad = 0;
   long long total = 0, stotal = 0;
+  int smap[CG_MAX_BATCH];                   // caller index -> index in `strm`, -1 if not a streaming problem
+  for (int i = 0; i < CG_MAX_BATCH; ++i) smap[i] = -1;
   for (int i = 0; i < n; ++i) {
     CgContractDesc d = descs[i];
     if (!d.A || !d.X || !d.Y || !d.tab) return CG_EARG;
@@ -580,16 +594,33 @@ extern "C" int cg_contract_many(const CgContractDesc* descs, int n, void* stream
       if (!d.ws || d.stats || (d.K & 3) || (((uintptr_t)d.A | (uintptr_t)d.X) & 15)) return CG_EARG;
       if ((d.K + d.splitk - 1) / d.splitk > 4 * CG_KR_QT - 16) return CG_ESHAPE;
     }
+    if (d.mode != 1 && d.chain != 0) return CG_EARG;
     if (d.mode == 1) {
       if (!d.x_vec || d.x_kfast || d.splitk != 1 || ((uintptr_t)d.Y & 15)) return CG_EARG;
       if (d.K > CG_ST_KMAX) return CG_ESHAPE;
-      d.block0 = stotal;
-      stotal += cg_contract_blocks(d);
+      smap[i] = strm.n;
       strm.d[strm.n++] = d;
     } else {
       batch.d[batch.n++] = d;
     }
   }
+  // chains: `chain` indexes the caller's array; members (targets of a chain link) own no workgroups
+  bool member[CG_MAX_BATCH] = {false};
+  for (int i = 0; i < strm.n; ++i) {
+    const int c = strm.d[i].chain;
+    if (c == 0) continue;
+    if (c < 0 || c > n || smap[c - 1] < 0 || smap[c - 1] == i) return CG_EARG;
+    const CgContractDesc& t = strm.d[smap[c - 1]];
+    if (t.G != strm.d[i].G || t.M != strm.d[i].M || t.N != strm.d[i].N || member[smap[c - 1]]) return CG_ESHAPE;
+    member[smap[c - 1]] = true;
+    strm.d[i].chain = smap[c - 1] + 1;
+  }
+  for (int i = 0; i < strm.n; ++i) {
+    if (member[i]) { strm.d[i].block0 = -1; if (strm.d[i].stats || strm.d[i].bias) return CG_EARG; continue; }
+    strm.d[i].block0 = stotal;
+    stotal += cg_contract_blocks(strm.d[i]);
+  }
+  if (strm.n > 0 && stotal == 0) return CG_EARG;            // a chain without a head
   // K-reduction problems have few, long-running workgroups: give them the lowest block ids so that they start first
   // and the short tile workgroups of the other problems fill in around them (the kernel finds a problem by scanning
   // for the largest block0 <= block id, so block0 must ascend with the position in the batch: reorder the batch).
@@ -625,6 +656,6 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;
-  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.stat_ch = M; d.mode = 0; d.block0 = 0; d.ws = nullptr;
+  d.G = G; d.M = M; d.N = N; d.K = K; d.splitk = splitk; d.kchunk = 0; d.a_kfast = a_kfast; d.x_kfast = x_kfast; d.accumulate = 0; d.x_vec = 0; d.stat_ch = M; d.mode = 0; d.block0 = 0; d.ws = nullptr; d.chain = 0; d.pad2 = 0;
   return cg_contract_many(&d, 1, stream_);
 }

@@ -284,7 +284,7 @@ def _label_strides(t, labels):
 
 class _Prep:
     """One contraction ready to launch: descriptor, output tensor, optional channel-sum slice."""
-    __slots__ = ("desc", "y", "stats", "zero", "tag", "ws_floats")
+    __slots__ = ("desc", "y", "stats", "zero", "tag", "ws_floats", "chained")
 
 
 def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=None, sx=None, oa=0, ox=0, stats_label=None,
@@ -307,7 +307,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
               a.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
     r = _Prep()
     kred = p.mode == 2
-    r.y, r.zero, r.stats, r.tag = y, (p.splitk > 1 and not kred), None, spec
+    r.y, r.zero, r.stats, r.tag, r.chained = y, (p.splitk > 1 and not kred), None, spec, False
     r.ws_floats = p.ws_floats
     if stats_label is not None and p.splitk == 1 and p.mode != 2:
         r.stats = _arena(x.device).take(2 * sizes[stats_label] * _lib.STAT_REPLICAS)   # replicated f64 channel sums of y
@@ -318,7 +318,7 @@ def _contract_prepare(spec, a, x, bias=None, bias_label=None, sizes=None, sa=Non
     d.G, d.M, d.N, d.K, d.splitk, d.a_kfast, d.x_kfast = p.G, p.M, p.N, p.K, p.splitk, p.a_kfast, p.x_kfast
     d.x_vec = 1 if (p.x_vec and x.data_ptr() % 16 == 0) else 0
     d.stat_ch = sizes[stats_label] if stats_label is not None else 0
-    d.mode, d.ws = p.mode, None          # the launcher points ws at zeroed scratch
+    d.mode, d.ws, d.chain = p.mode, None, 0          # the launcher points ws at zeroed scratch / links chains
     r.desc = d
     return r
 
@@ -327,10 +327,13 @@ _MAX_CONTRACT_BATCH = 16
 _ACC_MAX_FLOATS = 1 << 22      # shared-input gradients: fp32 atomics into one buffer up to this size, else separate outputs + one sum
 
 
-def _contract_launch(builders, device, groups=None):
+def _contract_launch(builders, device, groups=None, chains=None):
     """builders: callables out -> _Prep (out = pre-zeroed flat buffer the result must be written into, or None).
     Runs all contractions in as few launches as possible.  Split-K outputs are carved from ONE zeroed buffer;
-    `groups[i]` (optional) names an accumulation group: all members add (fp32 atomics) into one shared zeroed output."""
+    `groups[i]` (optional) names an accumulation group: all members add (fp32 atomics) into one shared zeroed output;
+    `chains` (optional): lists of builder indices whose results are to be SUMMED - when all of them take the streaming
+    kernel with the same output geometry they run as one chained problem (the first one's `y` holds the sum, the others
+    get `chained = True` and no output), otherwise nothing changes and the caller sums."""
     probe = [b(None) for b in builders]            # plan lookup is cached, so probing is cheap
     groups = groups or [None] * len(builders)
     slots, order = {}, []                          # slot key -> numel
@@ -358,10 +361,19 @@ def _contract_launch(builders, device, groups=None):
                     probe[i].desc.accumulate = 1
             if r.ws_floats:
                 probe[i].desc.ws = zbuf[offs[("w", i)]:].data_ptr()
+    for ch in (chains or ()):
+        ds = [probe[i].desc for i in ch]
+        same_chunk = len({i // _MAX_CONTRACT_BATCH for i in ch}) == 1
+        if (len(ch) > 1 and same_chunk and all(d.mode == 1 and not d.accumulate and not d.stats and not d.bias for d in ds)
+                and len({(d.G, d.M, d.N) for d in ds}) == 1):
+            for a, b in zip(ch[:-1], ch[1:]):
+                probe[a].desc.chain = (b % _MAX_CONTRACT_BATCH) + 1
+            for i in ch[1:]:
+                probe[i].chained, probe[i].y = True, None
     for c0 in range(0, len(probe), _MAX_CONTRACT_BATCH):
         chunk = probe[c0:c0 + _MAX_CONTRACT_BATCH]
         arr = (_lib.ContractDesc * len(chunk))(*[r.desc for r in chunk])
-        _lib.call("cg_contract_many", arr, len(chunk), _stream(chunk[0].y))
+        _lib.call("cg_contract_many", arr, len(chunk), _stream(next(r.y for r in chunk if r.y is not None)))
     return probe
 
 
@@ -428,6 +440,8 @@ class _ContractMany(torch.autograd.Function):
             if ctx.needs_input_grad[2 + 3 * i] and grads[2 * i] is not None:
                 shared.setdefault((x.data_ptr(), tuple(x.shape), tuple(x.stride())), []).append(i)
         dev = saved[0].device
+        # order: weight, input, bias gradient per map (measured: input gradients first, so that all of a shared input's
+        # land in one launch chunk, is slower at both B=16 and B=256)
         for i, (spec, bias_label, _) in enumerate(ctx.metas):
             a, x, dy = saved[2 * i], saved[2 * i + 1], grads[2 * i]
             if dy is None:                    # this output was not used downstream
@@ -450,11 +464,20 @@ class _ContractMany(torch.autograd.Function):
         if builders:
             seen = set()
             big = {}            # shared input too large for atomics: its gradients are separate outputs, summed by ONE launch below
-            for slot, grp, r in zip(slots, groups, _contract_launch(builders, dev, groups)):
+            chains = {}         # ... unless they can run as one chained streaming problem (no intermediate tensors at all)
+            for bi, (slot, grp) in enumerate(zip(slots, groups)):
+                if grp is None and slot % 3 == 1:
+                    x = saved[2 * (slot // 3) + 1]
+                    key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+                    if len(shared.get(key, ())) > 1:
+                        chains.setdefault(key, []).append(bi)
+            for slot, grp, r in zip(slots, groups, _contract_launch(builders, dev, groups, _chain_lists(chains.values(), builders))):
                 if grp is not None:
                     if grp in seen:
                         continue          # the shared buffer already holds the sum; hand it to autograd once
                     seen.add(grp)
+                elif r.chained:
+                    continue              # summed into the head of its chain in registers
                 elif slot % 3 == 1:
                     x = saved[2 * (slot // 3) + 1]
                     key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
@@ -465,6 +488,25 @@ class _ContractMany(torch.autograd.Function):
             for parts in big.values():      # autograd would add them pairwise: (n-1) x (2 reads + 1 write) of the tensor
                 res[parts[0][0]] = _sum_tensors([y for _, y in parts])
         return (None,) + tuple(res)
+
+
+_CHAIN = bool(int(__import__("os").environ.get("CISTGCN_CHAIN", "1")))        # tuning aid: 0 = separate outputs + one sum
+
+
+def _chain_lists(cands, builders):
+    """Split each candidate list (builder indices whose outputs are to be summed) into runs that share the streaming
+    geometry; runs of one stay unchained."""
+    out = []
+    if not _CHAIN:
+        return out
+    for idxs in cands:
+        byg = {}
+        for i in idxs:
+            d = builders[i](None).desc            # cached plan: cheap
+            if d.mode == 1:
+                byg.setdefault((d.G, d.M, d.N, i // _MAX_CONTRACT_BATCH), []).append(i)
+        out += [v for v in byg.values() if len(v) > 1]
+    return out
 
 
 def contract_many(items):

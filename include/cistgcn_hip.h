@@ -70,6 +70,10 @@ typedef struct CgContractDesc {
                                     four, no `stats`, K / splitk <= 4080, and `ws` */
   long long block0;              /* set by the library */
   float* ws;                     /* mode 2: ZEROED scratch of cg_contract_kred_ws_floats(G, M, N) floats */
+  int chain;                     /* mode 1: 1 + index (in `descs`) of another mode-1 problem with the same G, M, N whose product is
+                                    added to this one's output in registers (the input gradient of a tensor that feeds several
+                                    pointwise maps); the chained problem writes nothing itself (no bias / stats).  0 = none */
+  int pad2;
 } CgContractDesc;
 int cg_contract_many(const CgContractDesc* descs, int n, void* stream);
 long long cg_contract_kred_ws_floats(int G, int M, int N);

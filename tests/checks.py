@@ -383,6 +383,44 @@ def check_contract_stream(device):
         ops._STREAM_MIN_N = saved
 
 
+def check_contract_chain(device):
+    """input gradient of a tensor that feeds several pointwise maps + one collapsing map, large-tensor plan: the pointwise
+    gradients run as ONE chained streaming problem (summed in registers), the rest is added by cg_sum_many"""
+    g = _gen(16)
+    x = _rand(g, 2, 6, 10, 16)                                    # N = 320 positions
+    ws = [_rand(g, 5, 6), _rand(g, 9, 6), _rand(g, 5, 6), _rand(g, 4, 6, 10)]
+    specs = ["oc,bchw->bohw", "oc,bchw->bohw", "oc,bchw->bohw", "och,bchw->bow"]
+    saved = (ops._ACC_MAX_FLOATS, ops._STREAM_MIN_N)
+    ops._ACC_MAX_FLOATS, ops._STREAM_MIN_N = 0, 64
+    try:
+        def run(dev, fused):
+            xs = _leaf(x, dev)
+            wl = [_leaf(w, dev) for w in ws]
+            if fused:
+                ops.begin_step(dev)
+                ys = [o[0] for o in ops.contract_many([(sp, w, xs, None, None, None) for sp, w in zip(specs, wl)])]
+            else:
+                ys = [torch.einsum(sp, w, xs) for sp, w in zip(specs, wl)]
+            torch.autograd.backward(ys, [_rand(_gen(60 + i), *y.shape).to(dev) for i, y in enumerate(ys)])
+            return [xs.grad] + [w.grad for w in wl]
+        chained = []
+        orig = ops._lib.call
+        def spy(name, *a):
+            if name == "cg_contract_many":
+                chained.append(sum(1 for i in range(a[1]) if a[0][i].chain))
+            return orig(name, *a)
+        ops._lib.call = spy
+        try:
+            got = run(device, True)
+        finally:
+            ops._lib.call = orig
+        assert max(chained) == 2, "the three pointwise input gradients were not chained: %s" % chained
+        for i, (a, b) in enumerate(zip(got, run("cpu", False))):
+            assert_close(a, b, "chained grad%d" % i, rel=3e-5, floor=float(b.abs().max()))
+    finally:
+        ops._ACC_MAX_FLOATS, ops._STREAM_MIN_N = saved
+
+
 def check_zero_pool(device):
     """Per-step zero pool (ops.step_scratch): split-K outputs, halos, SE / ST-GCN dW accumulators carved from one
     buffer that begin_step clears - same results as with per-launch memsets, also on the second step (dirty pool)."""
