@@ -12,6 +12,19 @@ OUT = os.path.join(HERE, "_build", "libcistgcn_emu.so")
 
 
 def build(force=False):
+    """Idempotent and safe under concurrent callers (pytest workers, spawned ranks): an exclusive file lock serialises the
+    builders and the library appears under its final name only when complete."""
+    import fcntl
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in deps):
@@ -26,9 +39,11 @@ def build(force=False):
         if res.returncode != 0:
             raise RuntimeError("g++ failed on %s:\n%s" % (s, res.stderr[-4000:]))
         objs.append(o)
-    res = subprocess.run(["g++", "-shared", "-pthread", "-o", OUT] + objs, capture_output=True, text=True)
+    tmp = OUT + ".tmp.%d" % os.getpid()
+    res = subprocess.run(["g++", "-shared", "-pthread", "-o", tmp] + objs, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stderr[-4000:])
+    os.replace(tmp, OUT)
     return OUT
 
 

@@ -48,6 +48,10 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.timeout(300)
 def test_two_rank_gradient_mean():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+    import build_emu
+    build_emu.build()          # compile the shim library ONCE here: the two workers would otherwise race to build it
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
