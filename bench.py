@@ -244,6 +244,10 @@ def main():
                                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         if not args.no_eval:
             from cistgcn_amd.runtime import GraphedForward
+            del step, one              # the training graph and its buffers go first: one capture alive at a time
+            for p in net.parameters():
+                p.grad = None
+            torch.cuda.synchronize()
             net.eval()
             fwd = GraphedForward(net, x)
             for _ in range(args.warmup):
