@@ -23,6 +23,10 @@ struct CgView4 {
   long long s[4];
 };
 
+// Zero fill by a kernel (rowops.hip).  hipMemsetAsync is NOT used anywhere in this library: as a node of a captured HIP
+// graph it was not reliably ordered against the neighbouring kernels (see cg_zero in rowops.hip).
+int cg_zero_fill(void* p, long long bytes, hipStream_t stream);
+
 static inline int cg_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CG_OK : (int)e;

@@ -651,8 +651,8 @@ extern "C" int cg_contract(const float* A, const float* X, float* Y, const float
   if (stats && splitk > 1) return CG_EARG;   // channel sums need final values
   if (splitk > 1) {
     if (y_dense_numel != (long long)G * M * N) return CG_ESHAPE;
-    hipError_t e = hipMemsetAsync(Y, 0, (size_t)y_dense_numel * sizeof(float), stream);
-    if (e != hipSuccess) return (int)e;
+    const int zs = cg_zero_fill(Y, y_dense_numel * (long long)sizeof(float), stream);
+    if (zs != CG_OK) return zs;
   }
   CgContractDesc d;
   d.A = A; d.X = X; d.Y = Y; d.bias = bias; d.stats = stats; d.tab = tables;

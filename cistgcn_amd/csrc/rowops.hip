@@ -712,8 +712,37 @@ extern "C" int cg_copy_many(const CgCopyItem* items, int n, void* stream_) {
   return cg_launch_status();
 }
 
-extern "C" int cg_zero(void* p, long long bytes, void* stream_) {
-  if (!p || bytes < 0) return CG_EARG;
-  hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream_);
-  return e == hipSuccess ? CG_OK : (int)e;
+// Zero fill as a KERNEL, not hipMemsetAsync: inside a captured HIP graph the memset node was observed not to be ordered
+// reliably against the kernels around it once the process had allocated and freed other device memory between replays
+// (zero halos of the dilated convolutions read NaN left by unrelated tensors; tools/diag_replay_stability.py).
+__global__ void cg_zero_kernel(uint4* __restrict__ p16, long long n16, unsigned char* __restrict__ tail, int ntail) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long k = i; k < n16; k += stride) p16[k] = make_uint4(0u, 0u, 0u, 0u);
+  if (i < ntail) tail[i] = 0;
 }
+
+int cg_zero_fill(void* p, long long bytes, hipStream_t stream) {
+  if (!p) return CG_EARG;
+  if (bytes < 0) return CG_ESHAPE;
+  if (bytes == 0) return CG_OK;
+  unsigned char* b = static_cast<unsigned char*>(p);
+  // unaligned head bytes, 16-byte aligned body, tail bytes
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(b);
+  long long head = (16 - (long long)(addr & 15)) & 15;
+  if (head > bytes) head = bytes;
+  const long long body = ((bytes - head) / 16) * 16;
+  const long long tail = bytes - head - body;
+  if (head > 0) hipLaunchKernelGGL(cg_zero_kernel, dim3(1), dim3(64), 0, stream, (uint4*)nullptr, 0LL, b, (int)head);
+  if (body > 0 || tail > 0) {
+    const long long n16 = body / 16;
+    long long blocks = (n16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cg_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint4*>(b + head), n16,
+                       b + head + body, (int)tail);
+  }
+  return cg_launch_status();
+}
+
+extern "C" int cg_zero(void* p, long long bytes, void* stream_) { return cg_zero_fill(p, bytes, (hipStream_t)stream_); }

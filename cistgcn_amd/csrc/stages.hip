@@ -283,9 +283,9 @@ extern "C" int cg_se_gate_bwd(const float* pooled, const float* W1, const float*
   if (B <= 0 || C <= 0 || H <= 0) return CG_ESHAPE;
   hipStream_t stream = (hipStream_t)stream_;
   if (!prezeroed) {
-    hipError_t e = hipMemsetAsync(dW1, 0, (size_t)C * H * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dW2, 0, (size_t)C * H * 4, stream);
-    if (e != hipSuccess) return (int)e;
+    int zs = cg_zero_fill(dW1, (long long)C * H * 4, stream);
+    if (zs == CG_OK) zs = cg_zero_fill(dW2, (long long)C * H * 4, stream);
+    if (zs != CG_OK) return zs;
   }
   hipLaunchKernelGGL(cg_se_gate_bwd_kernel, dim3(B), dim3(64), (size_t)(2 * C + 2 * H) * 4, stream, pooled, W1, W2, gate, dgate, dpooled, dW1, dW2, C, H);
   return cg_launch_status();
@@ -347,8 +347,8 @@ extern "C" int cg_mpjpe_fwd(const float* pred, const float* tgt, float* loss, lo
   if (!pred || !tgt || !loss) return CG_EARG;
   if (N <= 0) return CG_ESHAPE;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  const int zs = cg_zero_fill(loss, (long long)sizeof(float), stream);
+  if (zs != CG_OK) return zs;
   long long blocks = (N + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(cg_mpjpe_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pred, tgt, loss, N);
@@ -545,8 +545,8 @@ extern "C" int cg_eval_scatter_mpjpe(const float* pred, const float* target, flo
   if (!pred || !target || !out || !frame_err || !src) return CG_EARG;
   if (B <= 0 || To <= 0 || J32 <= 0 || J22 <= 0) return CG_ESHAPE;
   hipStream_t stream = (hipStream_t)stream_;
-  hipError_t e = hipMemsetAsync(frame_err, 0, (size_t)To * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  const int zs = cg_zero_fill(frame_err, (long long)To * (long long)sizeof(float), stream);
+  if (zs != CG_OK) return zs;
   hipLaunchKernelGGL(cg_eval_scatter_mpjpe_kernel, dim3((unsigned)((long long)B * To)), dim3(64), 0, stream, pred, target, out, frame_err,
                      src, B, To, J32, J22);
   return cg_launch_status();

@@ -640,8 +640,10 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   hipStream_t stream = (hipStream_t)stream_;
   const int n_w = Cout * Cin, n_b = Cout;
   hipError_t e = hipSuccess;
-  if (!ws_prezeroed) e = hipMemsetAsync(ws, 0, (size_t)CG_DOM_REPLICAS * (n_w + n_b) * sizeof(float), stream);
-  if (e != hipSuccess) return (int)e;
+  if (!ws_prezeroed) {
+    const int zs = cg_zero_fill(ws, (long long)CG_DOM_REPLICAS * (n_w + n_b) * (long long)sizeof(float), stream);
+    if (zs != CG_OK) return zs;
+  }
   const size_t lds = cg_dom_lds_bytes(g, true);
   const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;
   dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);

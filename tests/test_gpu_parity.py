@@ -125,6 +125,31 @@ def test_graph_replay_matches_eager(branches=False):
         assert torch.allclose(a, p.grad, rtol=1e-3, atol=max(1e-5, 1e-4 * float(p.grad.abs().max())))   # atomics reorder sums
 
 
+def test_graph_replay_survives_allocator_churn():
+    """Regression: eager allocations of every size class, filled with NaN and freed between replays, must not change the
+    captured step.  With hipMemsetAsync nodes in the graph the zero halos of the dilated convolutions picked the NaN up
+    (loss and all 698 gradients NaN after the first churn); every zero fill is a kernel now (cg_zero_fill)."""
+    from cistgcn_amd.runtime import GraphedStep
+    net, _ = checks.build_pair(8, 10, 22, "cuda")
+    net.train()
+    net.dropout = 0.0
+    g = torch.Generator().manual_seed(5)
+    x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
+    tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
+    step = GraphedStep(net, x, tgt, warmup=2)
+    ref = float(step.replay())
+    for _ in range(2):
+        hold = []
+        for n in (1, 16, 64, 256, 1024, 4096, 1 << 14, 1 << 16, 1 << 18, 1 << 20, 1 << 22):
+            for _k in range(64 if n <= (1 << 16) else 8):
+                hold.append(torch.full((n,), float("nan"), device="cuda"))
+        torch.cuda.synchronize()
+        del hold
+        loss = float(step.replay())
+        assert abs(loss - ref) <= 1e-5 * abs(ref), (loss, ref)
+        assert all(bool(torch.isfinite(p.grad).all()) for p in net.parameters())
+
+
 def test_eval_forward_graph_matches_eager():
     """eval-mode forward captured in a HIP graph (bench.py's forward-only figure) = eager eval forward, also on new data"""
     from cistgcn_amd.runtime import GraphedForward
