@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-mode forward-only timing")
+    ap.add_argument("--capture-tries", type=int, default=3,
+                    help="graphs captured before the run; the fastest is kept (buffer placement moves the step by +-3 %%)")
     ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
@@ -196,7 +198,7 @@ def main():
     x, tgt = synth(B, T, V, rank, args.data_seed)
     x, tgt = x.to(device), tgt.to(device)
     flat = FlatGrads(net.parameters(), device) if world > 1 else None
-    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat, branches=args.branches))
+    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat, branches=args.branches, tries=args.capture_tries))
 
     def one():
         step.replay()
@@ -233,6 +235,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "C": C, "per_gpu_batch": B, "global_batch": B * world, "T_in": T, "T_out": 25,
                    "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph, "graph_branches": bool(args.branches and not args.no_graph),
+                   "capture_tries_ms": getattr(step, "capture_ms", None),
                    "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
                    "loss": loss},
     }

@@ -110,7 +110,8 @@ def test_graph_replay_matches_eager(branches=False):
     tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
     net.dropout = 0.0
     sd = {k: v.clone() for k, v in net.state_dict().items()}
-    step = GraphedStep(net, x, tgt, warmup=2, branches=branches)
+    step = GraphedStep(net, x, tgt, warmup=2, branches=branches, tries=2)     # two captures, the faster one kept: its own grad buffers
+    assert len(step.capture_ms) == 2
     net.load_state_dict(sd)
     loss_g = step.replay().item()
     grads_g = [p.grad.clone() for p in net.parameters()]
