@@ -2,15 +2,21 @@
 """Headline benchmark: sequences/sec of forward + MPJPE + backward of CIST-GCN on synthetic
 H3.6M-shaped poses (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 60 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one batch resident in HBM: forward, loss, backward and, for
-N > 1, the gather of all gradients into the flat buffer plus its RCCL all-reduce.  No optimizer,
-no logging, no H2D.  Rank 0 prints ONE JSON line.
+N > 1, the weighted gather of all gradients into the flat buffer plus its RCCL all-reduce (two buckets,
+the first one overlapped with the rest of the backward pass).  No optimizer, no logging, no H2D
+(SURVEY.md §8d).  Rank 0 prints ONE JSON line.
+
+N = 1 times BASELINE.json configs[2] (CISTGCN-64, B=256, 50->25 frames, 22 joints: the largest
+single-GPU configuration and the one the %HBM metric is quoted on) as the headline and configs[1]
+(CISTGCN-8, B=16) under "secondary"; both carry a CPU baseline timed on this box's host cores.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -24,14 +30,17 @@ sys.path.insert(0, ROOT)
 
 # name -> (C, B per GPU, T_in, V); T_out = 25 everywhere
 WORKLOADS = {
-    "cistgcn8_b16_t50_v22": (8, 16, 50, 22),      # BASELINE.json configs[1] (default)
-    "cistgcn64_b256_t50_v22": (64, 256, 50, 22),  # configs[2] / per-GPU shard of configs[3]
+    "cistgcn8_b16_t50_v22": (8, 16, 50, 22),      # BASELINE.json configs[1]
+    "cistgcn64_b256_t50_v22": (64, 256, 50, 22),  # configs[2] (headline) / per-GPU shard of configs[3]
     "cistgcn32_b256_t50_v25": (32, 256, 50, 25),  # configs[4] shape
     "cistgcn8_b16_t10_v22": (8, 16, 10, 22),      # reference-YAML frames
     "cistgcn64_b256_t10_v22": (64, 256, 10, 22),
     "cistgcn32_b256_t10_v18": (32, 256, 10, 18),  # reference AMASS joints
 }
+HEADLINE, SECONDARY = "cistgcn64_b256_t50_v22", "cistgcn8_b16_t50_v22"
+MIXED_BATCHES = (64, 128, 256, 512)   # configs[4]: per-GPU batch of rank r = MIXED_BATCHES[r % 4]
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_PEAK_TFLOPS = 157.3    # same guide: fp32 vector = fp32-input MFMA peak
 
 
 def make_cfg(C, T, V, dropout):
@@ -49,52 +58,181 @@ def synth(B, T, V, rank, base=1234):
     return x, tgt
 
 
-def model_bytes_per_sequence(C, T, V, To=25):
-    """ALGORITHMIC HBM bytes of one sequence through the six DSTD_GC blocks + model I/O, forward and backward, exactly
-    the SURVEY section 8(d) formula (x in, out, both adjacency maps, gates; backward: x, dOut, both maps, dx)."""
-    w = [10, C, C, C, C, 10]
-    blocks = [(w[i], w[i + 1], T, V) for i in range(5)] + [(3, 3, V, To)]
-    fwd = sum(ci * t * v + co * t * v + v * t * t + t * v * v + 2 * co for ci, co, t, v in blocks)
-    bwd = sum(ci * t * v + co * t * v + v * t * t + t * v * v + ci * t * v for ci, co, t, v in blocks)
-    io = 3 * T * V + 10 * T * V + 2 * 10 * To * V + 4 * 3 * To * V
-    return 4 * (fwd + io), 4 * (bwd + io)
-
-
-def domain_shapes(C, T, V, To=25):
-    """(Cin, Cout, T, V) of the six fused ST-GCN launches per domain in one forward."""
+def block_shapes(C, T, V, To=25):
+    """(Cin, Cout, T, V) of the six DSTD_GC invocations of one forward (CISTGCN.py:520-524, 549-553)."""
     w = [10, C, C, C, C, 10]
     return [(w[i], w[i + 1], T, V) for i in range(5)] + [(3, 3, V, To)]
 
 
-def roofline_domain_kernel(B, C, T, V, device, reps=30):
-    """Times the dominant kernel (fused ST-GCN stage, space domain, forward) live with HIP events on the
-    stream it is launched on, over the six shapes it takes in one forward; algorithmic bytes per launch
-    = 4*B*(Cin*T*V + V*T*T + Cout*T*V) + weights."""
-    from cistgcn_amd import ops
-    tot_t, tot_b, per = 0.0, 0.0, []
-    for (ci, co, t, v) in domain_shapes(C, T, V):
-        x = torch.randn(B, ci, t, v, device=device)
-        adj = torch.randn(B, v, t, t, device=device) * 0.1
-        w = torch.randn(co, ci, device=device) * 0.1
-        b = torch.randn(co, device=device)
-        for _ in range(3):
-            ops.stgcn_domain(x, adj, w, b, 0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.stgcn_domain(x, adj, w, b, 0)
-        e1.record()
+def block_bytes(ci, co, t, v):
+    """SURVEY 8(d) algorithmic bytes of ONE DSTD_GC invocation per sample: forward = read x, write out, write both
+    adjacency maps, write the gates; backward = read x, dOut, both maps, write dx."""
+    fwd = 4 * (ci * t * v + co * t * v + v * t * t + t * v * v + 2 * co)
+    bwd = 4 * (ci * t * v + co * t * v + v * t * t + t * v * v + ci * t * v)
+    return fwd, bwd
+
+
+def model_bytes_per_sequence(C, T, V, To=25):
+    """ALGORITHMIC HBM bytes of one sequence through the six DSTD_GC blocks + model I/O, forward and backward."""
+    fb = [block_bytes(*s) for s in block_shapes(C, T, V, To)]
+    io = 4 * (3 * T * V + 10 * T * V + 2 * 10 * To * V + 4 * 3 * To * V)
+    return sum(f for f, _ in fb) + io, sum(b for _, b in fb) + io
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# live per-entry-point timing: HIP events (on the stream the library launches on) around every C-ABI call of one
+# eager training step, with the ALGORITHMIC bytes of each call computed from its arguments
+# ---------------------------------------------------------------------------------------------------------------------
+def _numel(v):
+    return int(v.n[0]) * int(v.n[1]) * int(v.n[2]) * int(v.n[3])
+
+
+def _call_bytes(name, args):
+    """(family, algorithmic bytes) of one C-ABI call: every operand and result counted once."""
+    from cistgcn_amd import _lib
+    if name == "cg_contract_many":
+        arr, n = args[0], args[1]
+        total = 0
+        for i in range(n):
+            d = arr[i]
+            total += 4 * (d.G * d.M * d.K + d.G * d.K * d.N + d.G * d.M * d.N)
+        return "contraction (cg_contract_many: tiled / streaming / K-reduction kernels)", total
+    if name in ("cg_norm_act_fwd_many", "cg_norm_act_bwd_many"):
+        arr, n = args[0], args[-2] if name.endswith("bwd_many") else args[1]
+        total = 0
+        for i in range(n):
+            a = arr[i]
+            e = _numel(a.xv)
+            if name == "cg_norm_act_fwd_many":
+                total += 4 * e * (2 + (1 if a.add else 0))                      # x (+ add) -> y
+            else:
+                total += 4 * e * (2 + (1 if a.dx else 0) + (1 if (a.add and not a.add_post) else 0) + (1 if a.dadd else 0))
+        return ("row kernels fwd (cg_norm_act_fwd)" if name.endswith("fwd_many") else "row kernels bwd (cg_norm_act_bwd reduce + apply)"), total
+    if name == "cg_chan_stats_many":
+        return "row kernels fwd (cg_norm_act_fwd)", sum(4 * _numel(args[0][i].xv) for i in range(args[1]))
+    if name in ("cg_stgcn_domain_fwd", "cg_stgcn_domain_bwd"):
+        B, ci, co, T, V, dom = args[-7:-1] if name.endswith("fwd") else args[-8:-2]
+        ng, j = (V, T) if dom == 0 else (T, V)
+        x, y, adj = B * ci * T * V, B * co * T * V, B * ng * j * j
+        if name.endswith("fwd"):
+            return "fused ST-GCN stage fwd (cg_stgcn_domain_fwd)", 4 * (x + adj + y + co * ci + co)
+        return "fused ST-GCN stage bwd (cg_stgcn_domain_bwd)", 4 * (2 * x + 2 * adj + y + 2 * co * ci)
+    return "other (%s)" % name, 0
+
+
+class CallProbe:
+    """Context manager: wraps cistgcn_amd._lib.call for the duration of one eager step."""
+
+    def __init__(self):
+        self.rows = []
+
+    def __enter__(self):
+        from cistgcn_amd import _lib
+        self._lib, self._orig = _lib, _lib.call
+
+        def call(name, *args):
+            fam, nbytes = _call_bytes(name, args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._orig(name, *args)
+            e1.record()
+            self.rows.append((fam, nbytes, e0, e1))
+
+        _lib.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.call = self._orig
+        return False
+
+    def families(self):
         torch.cuda.synchronize()
-        dt = e0.elapsed_time(e1) / reps * 1e-3
-        nbytes = 4.0 * (B * (ci * t * v + v * t * t + co * t * v) + co * ci + co)
-        per.append({"shape": [B, ci, co, t, v], "us": dt * 1e6, "GBps": nbytes / dt / 1e9})
-        tot_t += dt
-        tot_b += nbytes
-    return tot_b, tot_t, per
+        fam = {}
+        for name, nbytes, e0, e1 in self.rows:
+            f = fam.setdefault(name, {"launches": 0, "us": 0.0, "algorithmic_bytes": 0})
+            f["launches"] += 1
+            f["us"] += e0.elapsed_time(e1) * 1e3
+            f["algorithmic_bytes"] += nbytes
+        for f in fam.values():
+            f["GBps"] = f["algorithmic_bytes"] / max(f["us"], 1e-9) / 1e3
+            f["frac"] = f["GBps"] / HBM_PEAK_GBS
+        return fam
 
 
-def cpu_baseline_worker(C, B, T, V, dropout, budget_s):
-    """Runs in a child process with OMP_NUM_THREADS fixed: times the CPU oracle, prints one JSON line."""
+def family_rooflines(net, x, tgt, reps=3):
+    """One eager (un-graphed) training step per repetition with every library call bracketed by HIP events.
+    Kernels are long at the headline size, so the brackets see kernel time, not launch gaps."""
+    from cistgcn_amd.runtime import EagerStep
+    step = EagerStep(net, x, tgt)
+    for _ in range(2):
+        step.replay()
+    torch.cuda.synchronize()
+    acc = None
+    for _ in range(reps):
+        with CallProbe() as probe:
+            step.replay()
+        fam = probe.families()
+        if acc is None:
+            acc = fam
+        else:
+            for k, f in fam.items():
+                for kk in ("launches", "us", "algorithmic_bytes"):
+                    acc[k][kk] += f[kk]
+    other = {"launches": 0, "us": 0.0, "algorithmic_bytes": 0}
+    out = {}
+    for k, f in acc.items():
+        for kk in ("launches", "us", "algorithmic_bytes"):
+            f[kk] = f[kk] / reps
+        if k.startswith("other"):
+            for kk in other:
+                other[kk] += f[kk]
+            continue
+        f["GBps"] = f["algorithmic_bytes"] / max(f["us"], 1e-9) / 1e3
+        f["frac"] = f["GBps"] / HBM_PEAK_GBS
+        out[k] = f
+    out["other entry points (statistics, cat / sum copies, SE, FPN pooling, tail)"] = other
+    return out
+
+
+def block_roofline(C, B, T, V, device, dropout, reps=5):
+    """SURVEY 8(d) bytes of ONE DSTD_GC invocation (C -> C on (T,V): three of the six blocks, and the bulk of the step)
+    divided by the summed time of all its kernels, forward and backward, HIP events around the eager block."""
+    from cistgcn_amd import ops
+    from cistgcn_amd.models import CISTGCN_0
+    torch.manual_seed(0)
+    net = CISTGCN_0(*make_cfg(C, T, V, dropout)).to(device).train()
+    blk = net.st_gcnns[1]
+    x = torch.randn(B, C, T, V, device=device, requires_grad=True)
+    tf = tb = 0.0
+    for r in range(reps + 2):
+        ops.begin_step(device, bump_seed=False)
+        net._site = 0
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        x.grad = None
+        e[0].record()
+        y = net._block_staged(blk, x)
+        y = y[0] if isinstance(y, tuple) else y
+        e[1].record()
+        y.backward(torch.ones_like(y))
+        e[2].record()
+        torch.cuda.synchronize()
+        if r >= 2:
+            tf += e[0].elapsed_time(e[1]) * 1e-3
+            tb += e[1].elapsed_time(e[2]) * 1e-3
+    tf, tb = tf / reps, tb / reps
+    bf, bb = block_bytes(C, C, T, V)
+    flops = 2.0 * B * (C * V * T * T + C * T * V * V + 2 * C * C * T * V + 2 * C * C * T * V)   # both graph products, both tcn, compressor
+    return {"block": "DSTD_GC %d->%d on (T=%d, V=%d), B=%d, train mode, eager launches" % (C, C, T, V, B), "bound": "hbm",
+            "algorithmic_bytes_fwd": B * bf, "algorithmic_bytes_bwd": B * bb, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6,
+            "achieved": B * (bf + bb) / (tf + tb) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B * (bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS,
+            "fwd_frac": B * bf / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac": B * bb / tb / 1e9 / HBM_PEAK_GBS,
+            "dense_gflop_fwd": flops / 1e9, "f32_frac_fwd": flops / tf / 1e12 / F32_PEAK_TFLOPS}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = stock-PyTorch restatement pinned to the reference), child process with fixed thread count
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_worker(C, B, T, V, dropout, budget_s, max_steps):
     from oracle import cistgcn_ref as O
     torch.manual_seed(0)
     net = O.CISTGCN(*make_cfg(C, T, V, dropout)).train()
@@ -111,58 +249,139 @@ def cpu_baseline_worker(C, B, T, V, dropout, budget_s):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 30:
+        if el >= budget_s or n >= max_steps:
             break
     print(json.dumps({"rate": B * n / el, "steps": n, "seconds": el, "threads": torch.get_num_threads()}))
 
 
-def cpu_baseline(C, B, T, V, dropout, budget_s=16.0):
-    """The CPU oracle (stock-PyTorch restatement pinned to the reference, oracle/cistgcn_ref.py) timed on this
-    box's host cores on the same workload: forward + MPJPE + backward.  PyTorch's intra-op threading does not
-    scale on ~1.5 k tiny ops per step, so several thread counts are tried (one child process each, OMP_NUM_THREADS
-    fixed) and the BEST one is reported."""
+def cpu_baseline(C, B, T, V, dropout, thread_counts, budget_s, max_steps=30):
+    """The CPU oracle timed on this box's host cores on the same workload (forward + MPJPE + backward), one child process
+    per thread count (OMP_NUM_THREADS fixed); the BEST count is reported.  PyTorch's intra-op threading does not scale on
+    ~1.5 k small ops per step, so more threads are not always faster."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    counts = sorted({min(ncpu, c) for c in (8, 16, 32, ncpu)})
+    counts = sorted({min(ncpu, c) for c in thread_counts})
     tried, best = [], None
     for nt in counts:
         env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt), HIP_VISIBLE_DEVICES="")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(C), str(B), str(T), str(V), str(dropout),
-               str(budget_s / len(counts))]
-        print("bench.py: cpu baseline with %d threads ..." % nt, file=sys.stderr, flush=True)
+               str(budget_s / len(counts)), str(max_steps)]
+        print("bench.py: cpu baseline C=%d B=%d with %d threads ..." % (C, B, nt), file=sys.stderr, flush=True)
         try:
-            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+            res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
             r = json.loads(res.stdout.strip().splitlines()[-1])
         except Exception as e:        # a failed trial must not take the GPU result down with it
             tried.append("%d thr: failed (%s)" % (nt, type(e).__name__))
             continue
-        tried.append("%d thr: %.1f seq/s (%d steps, %.1f s)" % (nt, r["rate"], r["steps"], r["seconds"]))
+        tried.append("%d thr: %.2f seq/s (%d steps, %.1f s)" % (nt, r["rate"], r["steps"], r["seconds"]))
         if best is None or r["rate"] > best[0]:
             best = (r["rate"], nt)
     if best is None:
         return {"value": None, "unit": "sequences/sec", "cores": 0, "kind": "port", "sample": "; ".join(tried)}
     return {"value": best[0], "unit": "sequences/sec", "cores": best[1], "kind": "port",
-            "sample": "fwd+bwd steps of the bench workload (B=%d) on the host, torch %s CPU, best of: %s" % (B, torch.__version__, "; ".join(tried))}
+            "sample": "fwd+bwd steps of the same workload (C=%d, B=%d, T=%d, V=%d) on the host (%d logical CPUs), torch %s CPU, "
+                      "1 warm-up step, best of: %s" % (C, B, T, V, ncpu, torch.__version__, "; ".join(tried))}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def timed_training(workload, args, device, rank, world, steps, warmup, batch=None):
+    """Builds the model and the captured step for `workload`, runs `warmup` untimed and exactly `steps` timed steps
+    bracketed by barrier + synchronize; returns (result dict, net, x, tgt) - the step object is released."""
+    import torch.distributed as dist
+    from cistgcn_amd import ops
+    from cistgcn_amd.models import CISTGCN_0
+    from cistgcn_amd.runtime import DataParallelStep, EagerStep, GraphedStep
+    C, B, T, V = WORKLOADS[workload]
+    B = batch or B
+    torch.manual_seed(0)
+    net = CISTGCN_0(*make_cfg(C, T, V, args.dropout)).to(device).train()
+    ops.manual_seed(args.data_seed + rank, device)
+    x, tgt = synth(B, T, V, rank, args.data_seed)
+    x, tgt = x.to(device), tgt.to(device)
+    if world > 1:
+        step = DataParallelStep(net, x, tgt, graph=not args.no_graph, cut_block=None if args.buckets > 1 else -1)
+    elif args.no_graph:
+        step = EagerStep(net, x, tgt)
+    else:
+        step = GraphedStep(net, x, tgt, warmup=3, branches=args.branches, tries=args.capture_tries)
+    for _ in range(warmup):
+        step.replay()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    total_b = B
+    if world > 1:
+        t = torch.tensor([el, float(B)], device=device, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        el, total_b = float(tmax[0].item()), int(round(float(t[1].item())))
+    loss = float(step.loss.item())
+    if not (loss == loss):
+        raise SystemExit("bench.py: loss is NaN on rank %d for %s" % (rank, workload))
+    res = {"workload": workload, "value": total_b * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "seconds": el,
+           "loss": loss, "capture_ms": getattr(step, "capture_ms", None), "global_batch": total_b, "per_gpu_batch": B,
+           "shard_weight": getattr(step, "weight", None),
+           "buckets": len(step.flat.buckets) if world > 1 else None}
+    del step
+    for p in net.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
+    return res, net, x, tgt
+
+
+def eval_forward(net, x, steps, warmup):
+    from cistgcn_amd.runtime import GraphedForward
+    net.eval()
+    fwd = GraphedForward(net, x)
+    for _ in range(warmup):
+        fwd.replay()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        fwd.replay()
+    torch.cuda.synchronize()
+    ef = (time.perf_counter() - t1) / steps
+    net.train()
+    del fwd
+    return {"value": x.shape[0] / ef, "unit": "sequences/sec", "ms_per_batch": ef * 1e3, "graph": True}
+
+
+def step_roofline(C, T, V, seq_per_s):
+    bf, bb = model_bytes_per_sequence(C, T, V)
+    gbs = (bf + bb) * seq_per_s / 1e9
+    return {"bound": "hbm", "algorithmic_bytes_per_sequence_fwd": bf, "algorithmic_bytes_per_sequence_bwd": bb,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         C, B, T, V = [int(v) for v in sys.argv[2:6]]
-        return cpu_baseline_worker(C, B, T, V, float(sys.argv[6]), float(sys.argv[7]))
+        return cpu_baseline_worker(C, B, T, V, float(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=60, help="timed steps of the headline workload (60 x ~30 ms > 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cistgcn8_b16_t50_v22", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--branches", action="store_true", help="EXPERIMENTAL: capture independent branches on forked streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-mode forward-only timing")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (CISTGCN-8, B=16) line")
     ap.add_argument("--capture-tries", type=int, default=3,
-                    help="graphs captured before the run; the fastest is kept (buffer placement moves the step by +-3 %%)")
+                    help="graphs captured before the run; the MEDIAN one is kept (buffer placement moves the step by +-3 %%)")
     ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
+    ap.add_argument("--buckets", type=int, default=2, help="N>1: 2 = two-phase backward with the first bucket's all-reduce overlapped, 1 = one bucket")
+    ap.add_argument("--mixed-batches", action="store_true", help="N>1: per-GPU batch of rank r = (64,128,256,512)[r %% 4] (BASELINE configs[4])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank code path on a box with fewer GPUs than ranks)")
@@ -186,95 +405,64 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from cistgcn_amd import _lib, ops
-    from cistgcn_amd.models import CISTGCN_0
-    from cistgcn_amd.runtime import EagerStep, FlatGrads, GraphedStep, allreduce_mean_
+    from cistgcn_amd import _lib
     _lib.lib()   # fail loudly if the HIP library is missing
 
     C, B, T, V = WORKLOADS[args.workload]
-    torch.manual_seed(0)
-    net = CISTGCN_0(*make_cfg(C, T, V, args.dropout)).to(device).train()
-    ops.manual_seed(args.data_seed + rank, device)
-    x, tgt = synth(B, T, V, rank, args.data_seed)
-    x, tgt = x.to(device), tgt.to(device)
-    flat = FlatGrads(net.parameters(), device) if world > 1 else None
-    step = (EagerStep(net, x, tgt, flat) if args.no_graph else GraphedStep(net, x, tgt, warmup=3, flat=flat, branches=args.branches, tries=args.capture_tries))
-
-    def one():
-        step.replay()
-        if world > 1:
-            allreduce_mean_(flat.flat)
-
-    for _ in range(args.warmup):
-        one()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    loss = float(step.loss.item())
-    if not (loss == loss):
-        bad = [k for k, p in net.named_parameters() if not bool(torch.isfinite(p).all())]
-        badg = [k for k, p in net.named_parameters() if p.grad is not None and not bool(torch.isfinite(p.grad).all())]
-        raise SystemExit("bench.py: loss is NaN on rank %d (x finite: %s, non-finite params: %s, non-finite grads: %d e.g. %s)"
-                         % (rank, bool(torch.isfinite(x).all()), bad[:3], len(badg), badg[:3]))
-
+    batch = MIXED_BATCHES[rank % len(MIXED_BATCHES)] if (args.mixed_batches and world > 1) else None
+    res, net, x, tgt = timed_training(args.workload, args, device, rank, world, args.steps, args.warmup, batch)
     out = {
         "metric": "sequences/sec (fwd+bwd) H3.6M 22-joint 50->25" if (T, V) == (50, 22) else "sequences/sec (fwd+bwd)",
-        "value": B * world * args.steps / el, "unit": "sequences/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": res["value"], "unit": "sequences/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": args.workload, "C": C, "per_gpu_batch": B, "global_batch": B * world, "T_in": T, "T_out": 25,
-                   "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph, "graph_branches": bool(args.branches and not args.no_graph),
-                   "capture_tries_ms": getattr(step, "capture_ms", None),
+        "config": {"workload": args.workload, "C": C, "per_gpu_batch": res["per_gpu_batch"], "global_batch": res["global_batch"],
+                   "T_in": T, "T_out": 25, "V": V, "dropout": args.dropout, "parallelism": "dp%d" % world, "graph": not args.no_graph,
+                   "graph_branches": bool(args.branches and not args.no_graph), "timed_seconds": res["seconds"],
+                   "capture_probe_ms": res["capture_ms"], "capture_kept": "median" if res["capture_ms"] else None,
                    "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
-                   "loss": loss},
+                   "gradient_buckets": res["buckets"], "mixed_batches": bool(batch), "loss": res["loss"]},
     }
     if rank == 0 and world == 1:
-        bf, bb = model_bytes_per_sequence(C, T, V)
-        gbs = (bf + bb) * out["value"] / 1e9
-        # whole-step view next to the per-kernel roofline: SURVEY 8(d) algorithmic bytes per sequence x sequences/s
-        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_sequence_fwd": bf, "algorithmic_bytes_per_sequence_bwd": bb,
-                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        out["step_roofline"] = step_roofline(C, T, V, out["value"])
         if not args.no_eval:
-            from cistgcn_amd.runtime import GraphedForward
-            del step, one              # the training graph and its buffers go first: one capture alive at a time
-            for p in net.parameters():
-                p.grad = None
-            torch.cuda.synchronize()
-            net.eval()
-            fwd = GraphedForward(net, x)
-            for _ in range(args.warmup):
-                fwd.replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                fwd.replay()
-            torch.cuda.synchronize()
-            ef = (time.perf_counter() - t1) / args.steps
-            net.train()
-            out["eval_forward"] = {"value": B / ef, "unit": "sequences/sec", "ms_per_batch": ef * 1e3, "graph": True}
+            out["eval_forward"] = eval_forward(net, x, args.steps, args.warmup)
         if not args.no_roofline:
-            nbytes, secs, per = roofline_domain_kernel(B, C, T, V, device)
+            fams = family_rooflines(net, x, tgt)
+            dom = max((k for k in fams if not k.startswith("other")), key=lambda k: fams[k]["us"])
             traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_pmc.sh), recorded under profiles/
-            tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
             if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "hbm", "achieved": nbytes / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": nbytes / secs / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "cg_stgcn_domain_fwd_kernel<0>", "avg_us": secs / len(per) * 1e6,
-                               "algorithmic_bytes_per_launch_avg": nbytes / len(per), "per_shape": per}
+                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
+            f = fams[dom]
+            out["roofline"] = {"bound": "hbm", "achieved": f["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f["frac"],
+                               "traffic": traffic, "kernel": dom, "launches_per_step": f["launches"],
+                               "avg_us": f["us"] / max(1, f["launches"]),
+                               "algorithmic_bytes_per_launch_avg": f["algorithmic_bytes"] / max(1, f["launches"]),
+                               "how": "dominant family by summed time of one eager step; HIP events around every C-ABI call on the "
+                                      "launch stream, algorithmic bytes = each operand/result of each call once",
+                               "per_family": fams}
+            del net
+            torch.cuda.synchronize()
+            out["block_roofline"] = block_roofline(C, B, T, V, device, args.dropout)
+        else:
+            del net
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, B, T, V, args.dropout)
+            big = B * C >= 4096
+            out["cpu_baseline"] = cpu_baseline(C, B, T, V, args.dropout, (16,) if big else (8, 16, 32), 1.0 if big else 12.0, 1 if big else 30)
+        if not args.no_secondary and args.workload != SECONDARY:
+            torch.cuda.empty_cache()
+            C2, B2, T2, V2 = WORKLOADS[SECONDARY]
+            r2, net2, x2, _ = timed_training(SECONDARY, args, device, rank, world, 400, 20)
+            sec = {"config": "BASELINE configs[1]: %s" % SECONDARY, "value": r2["value"], "unit": "sequences/sec", "ms_per_step": r2["ms_per_step"],
+                   "steps": 400, "timed_seconds": r2["seconds"], "capture_probe_ms": r2["capture_ms"], "loss": r2["loss"],
+                   "step_roofline": step_roofline(C2, T2, V2, r2["value"])}
+            if not args.no_eval:
+                sec["eval_forward"] = eval_forward(net2, x2, 400, 20)
+            del net2
+            if not args.no_cpu_baseline:
+                sec["cpu_baseline"] = cpu_baseline(C2, B2, T2, V2, args.dropout, (8, 16, 32), 12.0)
+            out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

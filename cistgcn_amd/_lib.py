@@ -106,7 +106,8 @@ _SIGNATURES = {
     "cg_stgcn_domain_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cg_stgcn_domain_bwd_ws_floats": [c_int, c_int],
-    "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, P],
+    "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, c_float, P],
+    "cg_scale": [P, LL, c_float, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -38,14 +38,15 @@ extern "C" int cg_adam_flat(float* param, const float* grad, float* exp_avg, flo
 
 // ---------------------------------------------------------------------------------------------
 // Gather the per-tensor gradients (698 tensors) into one flat fp32 buffer (direction 0), or scatter
-// the flat buffer back (direction 1), in ONE launch: the flat buffer is what RCCL all-reduces and
+// the flat buffer back (direction 1), in ONE launch (the gather multiplies by `scale`: the replica weight B_r*world/sum B
+// of a data-parallel step with unequal per-GPU batches): the flat buffer is what RCCL all-reduces and
 // what cg_adam_flat consumes.  Work is pre-chunked on the host: chunk i copies `chunk_len[i]`
 // elements of tensor `chunk_tensor[i]` starting at element `chunk_begin[i]`; tensor t lives at
 // ptrs[t] and at flat + flat_off[t].
 // ---------------------------------------------------------------------------------------------
 __global__ void cg_multi_copy_kernel(float* const* __restrict__ ptrs, const long long* __restrict__ flat_off,
                                      const int32_t* __restrict__ chunk_tensor, const int32_t* __restrict__ chunk_begin,
-                                     const int32_t* __restrict__ chunk_len, float* __restrict__ flat, int direction) {
+                                     const int32_t* __restrict__ chunk_len, float* __restrict__ flat, int direction, float scale) {
   const int ch = blockIdx.x;
   const int t = chunk_tensor[ch];
   const long long b = chunk_begin[ch];
@@ -53,15 +54,29 @@ __global__ void cg_multi_copy_kernel(float* const* __restrict__ ptrs, const long
   float* p = ptrs[t] + b;
   float* f = flat + flat_off[t] + b;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (direction == 0) f[i] = p[i]; else p[i] = f[i];
+    if (direction == 0) f[i] = p[i] * scale; else p[i] = f[i];
   }
 }
 
 extern "C" int cg_multi_copy(void* ptrs, const long long* flat_off, const int32_t* chunk_tensor, const int32_t* chunk_begin,
-                             const int32_t* chunk_len, int n_chunks, float* flat, int direction, void* stream_) {
+                             const int32_t* chunk_len, int n_chunks, float* flat, int direction, float scale, void* stream_) {
   if (!ptrs || !flat_off || !chunk_tensor || !chunk_begin || !chunk_len || !flat) return CG_EARG;
   if (n_chunks <= 0) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_multi_copy_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream_,
-                     (float* const*)ptrs, flat_off, chunk_tensor, chunk_begin, chunk_len, flat, direction);
+                     (float* const*)ptrs, flat_off, chunk_tensor, chunk_begin, chunk_len, flat, direction, scale);
+  return cg_launch_status();
+}
+
+// p[i] *= s : the 1/world of a data-parallel gradient mean when no optimizer kernel follows to absorb it
+__global__ void cg_scale_kernel(float* __restrict__ p, long long n, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= s;
+}
+
+extern "C" int cg_scale(float* p, long long n, float s, void* stream_) {
+  if (!p) return CG_EARG;
+  if (n <= 0) return CG_ESHAPE;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(cg_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, n, s);
   return cg_launch_status();
 }

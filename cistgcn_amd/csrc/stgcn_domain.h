@@ -1,0 +1,21 @@
+// Shared between the two translation units of the fused ST-GCN stage (stgcn_domain.hip: VALU kernels for narrow layers
+// and the C ABI; stgcn_domain_mfma.hip: matrix-core kernels for wide layers).
+#pragma once
+#include "cg_common.h"
+
+// geometry of the matrix-core kernels (see the header comment of stgcn_domain_mfma.hip)
+struct CgDomM {
+  int B, Cin, Cout, T, V;
+  int NG, J;                 // groups per sample (joints | frames), contraction length (frames | joints)
+  int GT, ntiles;            // groups per tile, tiles per sample
+  int total, per;            // tiles, tiles per workgroup (contiguous range)
+  int Js, RS;                // column stride of a group inside a row of the [channel][position] images, row stride (== 4 mod 8)
+  int Jr, Jsa;               // adjacency slab: rows per group (J up to 16), row stride (Jr + 4)
+  int CiM, CoM, WS;          // channels up to 16, row stride of the weight image
+  unsigned magicJ, magicGT;  // ceil(2^32 / d) for the index divisions by J and GT
+};
+
+int cg_domm_geom(CgDomM& g, int B, int Cin, int Cout, int T, int V, int domain);
+size_t cg_domm_lds_bytes(const CgDomM& g);
+int cg_domm_bwd_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
+                       int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);

@@ -17,6 +17,7 @@
 //   sG [Cinp][PP]    graph product, PP = GT*Jp positions
 //   sWt[Cin][Coutp]  W transposed (fwd) / sW [Cout][Cinp] (bwd)
 #include "cg_common.h"
+#include "stgcn_domain.h"
 #include <stdlib.h>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
@@ -643,6 +644,17 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   if (!ws_prezeroed) {
     const int zs = cg_zero_fill(ws, (long long)CG_DOM_REPLICAS * (n_w + n_b) * (long long)sizeof(float), stream);
     if (zs != CG_OK) return zs;
+  }
+  // wide layers: every product on the matrix cores (stgcn_domain_mfma.hip); narrow ones (C <= 10 on both sides: CISTGCN-8,
+  // the output block) stay on the VALU kernel below, where a 16-wide MFMA tile would be mostly padding
+  if ((Cin >= 16 || Cout >= 16) && (domain == 1 ? V : T) <= 64 && getenv("CG_DOM_BWD_VALU") == nullptr) {
+    st = cg_domm_bwd_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, domain, stream);
+    if (st != CG_ESHAPE) {
+      if (st != CG_OK) return st;
+      hipLaunchKernelGGL(cg_dom_fold_replicas_kernel, dim3((unsigned)((n_w + n_b + 255) / 256)), dim3(256), 0, stream, ws, CG_DOM_REPLICAS,
+                         n_w, n_b, dW, dbias);
+      return cg_launch_status();
+    }
   }
   const size_t lds = cg_dom_lds_bytes(g, true);
   const long long nwg = ((long long)B * g.ntiles + g.per - 1) / g.per;

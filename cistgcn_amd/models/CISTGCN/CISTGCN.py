@@ -249,6 +249,8 @@ class CISTGCN(nn.Module):
         for part in (self.st_gcnns_o, self.st_gcnns, self.txcnns):
             _init_small(part, 0.1, False)
         self._site = 0
+        self.backward_cut = None      # (input block index, fn): the step runtime cuts the autograd graph behind that block
+        self.act_trace = None         # dict: PReLU module -> (output, post-activation addend) of the last forward (diagnostics)
         self.branch_streams = False   # True: independent branches of a block run on forked HIP streams (runtime.GraphedStep)
         self._streams, self._next_stream = [], 0
 
@@ -278,13 +280,7 @@ class CISTGCN(nn.Module):
     # ---- fused row op with per-call dropout site id -------------------------------------------
     def _na(self, x, bn=None, prelu=None, drop=False, **kw):
         """x is a tensor or the (y, channel-sums) pair returned by the linear-map helpers."""
-        if isinstance(x, tuple):
-            x, st = x
-            if st is not None:
-                kw["stats"] = st
-        self._site += 1
-        return ops.norm_act(x, bn=bn, train=self.training, prelu=prelu, drop_p=self.dropout if drop else 0.0,
-                            salt=self._site, **kw)
+        return self._na_many([dict(x=x, bn=bn, prelu=prelu, drop=drop, **kw)])[0]
 
     def _lin(self, fn, x, layer, bn=True):
         """linear map `fn` followed (bn=True) by a BatchNorm: ask the kernel for channel sums in train mode"""
@@ -362,7 +358,16 @@ class CISTGCN(nn.Module):
             drop = kw.pop("drop", False)
             kw.update(train=self.training, drop_p=self.dropout if drop else 0.0, salt=self._site)
             out.append(kw)
-        return ops.norm_act_many(out)
+        ys = ops.norm_act_many(out)
+        if self.act_trace is not None:
+            # branch record of every PReLU (its output, and the addend when that is added behind the activation):
+            # lets a checker replay another implementation of the network on the very same branches
+            for kw, y in zip(out, ys):
+                if kw.get("prelu") is not None:
+                    y = y[0] if isinstance(y, tuple) else y
+                    add = kw.get("add") if kw.get("add_post") else None
+                    self.act_trace[kw["prelu"]] = (y.detach(), add.detach() if add is not None else None)
+        return ys
 
     def _block_staged(self, m, x):
         """DSTD_GC.forward (CISTGCN.py:373-390) with the gate paths (:378-384), the four Map2Adj towers (:183-189) and
@@ -382,7 +387,7 @@ class CISTGCN(nn.Module):
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
         x_res = xa[4:6] if not has_res else None
         x_bres = xa[-1] if not has_bres else None
-        stats = ops.dstd_stats(x_stats)
+        stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
         maps = [d.map_to_adj for d in doms]
         # 1. every first-level map of xn
         items = [_rows_item(xn, m.conv_s[0], tr), _rows_item(xn, m.conv_t[0], tr)]
@@ -419,8 +424,8 @@ class CISTGCN(nn.Module):
         for i, a in enumerate(maps):
             calls += [dict(x=o[2 + 2 * i], bn=a.time_compress[4], drop=True), dict(x=o[3 + 2 * i], bn=a.joint_compress[4], drop=True)]
         r = self._na_many(calls)
-        hs = ops.cat_channels([r[0].view(B, -1), stats])
-        ht = ops.cat_channels([r[1].view(B, -1), stats])
+        hs = ops.cat_channels([r[0].view(B, -1), stats_s])
+        ht = ops.cat_channels([r[1].view(B, -1), stats_t])
         # 5. gate Linear + last tower maps
         items = [_lin_item(hs, m.map_s[0], tr), _lin_item(ht, m.map_t[0], tr)]
         for i, a in enumerate(maps):
@@ -460,7 +465,8 @@ class CISTGCN(nn.Module):
                             dict(x=x12[1], pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])])
         c = m.compressor
         h = self._na(self._lin(_pointwise, ops.cat_channels(ab), c[0]), bn=c[1], prelu=c[2])
-        gate = ops.se_gate(ops.mean_bc(h), c[3].w1, c[3].w2)
+        h_pool, h = ops.fanout(h, 2)                                     # squeeze | excite
+        gate = ops.se_gate(ops.mean_bc(h_pool), c[3].w1, c[3].w2)
         # the next block starts with a BatchNorm of this output: let the kernel emit its channel sums (train mode)
         return self._na(h, pre=gate, add=bres, add_post=True, emit_stats=tr)
 
@@ -489,15 +495,16 @@ class CISTGCN(nn.Module):
         m.seq_joints = ops.contract("bt,bv->btv", m.displacements, m.joints)
         n = m.norm_map
         h = self._na(self._lin(_pointwise, m.seq_joints, n[0]), bn=n[1], drop=True, prelu=n[3])
-        h = self._na(h, pre=ops.se_gate(ops.mean_bc(h), n[4].w1, n[4].w2))
+        h_pool, h = ops.fanout(h, 2)
+        h = self._na(h, pre=ops.se_gate(ops.mean_bc(h_pool), n[4].w1, n[4].w2))
         h = self._na(self._lin(_pointwise, h, n[5]), bn=n[6], drop=True, prelu=n[8])
         m.seq_joints_n = h
         f = m.fconv
         h = self._na(self._lin(_pointwise, h.view(B, 1, To, V), f[0]), bn=f[1], prelu=f[2])
         h = self._na(self._lin(_pointwise, h, f[3]), bn=f[4], prelu=f[5])
         m.seq_joints_dims = h
-        hp = h.permute(0, 2, 3, 1)
-        return self._na(hp, pre=ops.se_gate(ops.mean_bc(hp), m.SE.w1, m.SE.w2))
+        hp_pool, hp = ops.fanout(h.permute(0, 2, 3, 1), 2)
+        return self._na(hp, pre=ops.se_gate(ops.mean_bc(hp_pool), m.SE.w1, m.SE.w2))
 
     # ---- CISTGCN.forward, CISTGCN.py:567-597 -------------------------------------------------------
     def forward(self, x):
@@ -507,8 +514,10 @@ class CISTGCN(nn.Module):
         self._site, self._next_stream = 0, 0
         h = ops.feature_lift(x)                                         # (B,10,T,V)
         block = self._block_staged if self.staged else self._block
-        for blk in self.st_gcnns:
+        for i, blk in enumerate(self.st_gcnns):
             h = block(blk, h)
+            if self.backward_cut is not None and self.backward_cut[0] == i:
+                h = self.backward_cut[1](h)                               # runtime.DataParallelStep: two-phase backward
         h = h[0] if isinstance(h, tuple) else h                          # (tensor, channel sums) from a staged block
         h = h.permute(0, 2, 1, 3)                                       # NCTV -> NTCV (view)
         ha = ops.fanout(h, 2)                                           # dilated convolutions | pooled context
@@ -519,9 +528,9 @@ class CISTGCN(nn.Module):
         d = self.dim_conversor
         z = self._na(self._lin(_pointwise, z.permute(0, 2, 1, 3), d[0]), bn=d[1], prelu=d[2])
         z = self._na(_pointwise(z, d[3])[0], prelu=d[4])                # PReLU(3): per-channel slopes (:545)
-        x7 = ops.cumsum_time(z.permute(0, 2, 3, 1))                     # (B,T_out,V,3)
+        x7, x7o = ops.fanout(ops.cumsum_time(z.permute(0, 2, 3, 1)), 2)   # (B,T_out,V,3): context branch | output block
         def output_blocks():
-            x8 = x7.permute(0, 3, 2, 1)                                 # (B,3,V,T_out) view
+            x8 = x7o.permute(0, 3, 2, 1)                                # (B,3,V,T_out) view
             for blk in self.st_gcnns_o:
                 x8 = block(blk, x8)
             return x8[0] if isinstance(x8, tuple) else x8

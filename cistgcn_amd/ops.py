@@ -122,15 +122,44 @@ def _arena(device):
 
 
 def step_scratch(device, enable=True, floats=1 << 25):
-    """Opt in (or out) of the per-step zero pool on `device`.  Only for callers that run exactly one forward +
-    backward per `begin_step` and consume the gradients before the next one (runtime.GraphedStep / EagerStep):
-    gradients of that step may alias pool memory, which the next `begin_step` clears."""
+    """Opt in (or out) of a per-step zero pool on `device` for the whole process.  Only for callers that run exactly one
+    forward + backward per `begin_step` and consume the gradients before the next one: gradients of that step may alias
+    pool memory, which the next `begin_step` clears.  The step runtime does NOT use this switch: it owns a private pool and
+    installs it only around its own step (`step_pool`), so no other forward in the process ever sees pool-backed gradients."""
     device = _dev(device)
     if enable:
         if device not in _zero_pools:
             _zero_pools[device] = _ZeroPool(device, int(floats))
     else:
         _zero_pools.pop(device, None)
+
+
+def new_step_pool(device, floats=1 << 25):
+    """A private zero pool (see `step_pool`)."""
+    return _ZeroPool(_dev(device), int(floats))
+
+
+class step_pool:
+    """Context manager: `pool` is the zero pool of its device inside the block and only there.  runtime.GraphedStep /
+    EagerStep wrap each of their own forward + backward passes in it; parameter gradients produced inside may alias the
+    pool and are valid until that object's next step (it gathers or consumes them right after the pass)."""
+
+    def __init__(self, pool):
+        self.pool = pool
+
+    def __enter__(self):
+        dev = self.pool.buf.device
+        self.prev = _zero_pools.get(dev)
+        _zero_pools[dev] = self.pool
+        return self.pool
+
+    def __exit__(self, *exc):
+        dev = self.pool.buf.device
+        if self.prev is None:
+            _zero_pools.pop(dev, None)
+        else:
+            _zero_pools[dev] = self.prev
+        return False
 
 
 def _zeros(n, device):
@@ -523,6 +552,7 @@ def contract_many(items):
 class _Contract(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, x, bias, spec, bias_label, stats_label):
+        ctx.set_materialize_grads(False)      # the channel-sum output never receives a gradient: do not zero-fill one
         ctx.spec, ctx.bias_label = spec, bias_label
         ctx.save_for_backward(a, x)
         if stats_label is None:
@@ -534,6 +564,8 @@ class _Contract(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _=None):
+        if dy is None:
+            return None, None, None, None, None, None
         a, x = ctx.saved_tensors
         ins, ly = ctx.spec.split("->")
         la, lx = ins.split(",")

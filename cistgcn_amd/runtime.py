@@ -16,19 +16,27 @@ _CHUNK = 2048
 
 
 class FlatGrads:
-    """One contiguous fp32 buffer holding all parameter gradients, filled by a single gather kernel."""
+    """One contiguous fp32 buffer holding all parameter gradients, filled by a single gather kernel.  The buffer can be
+    cut into contiguous BUCKETS of whole tensors (`set_buckets`), gathered one at a time: the data-parallel step
+    all-reduces the bucket of the layers whose gradients land first while the rest of the backward pass still runs."""
 
     def __init__(self, params, device):
         self.params = [p for p in params if p.requires_grad]
         sizes = [p.numel() for p in self.params]
-        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        # every tensor starts on a 16-byte boundary of the flat buffer (slots padded to 4 floats; the padding stays zero):
+        # parameters re-homed into the same layout (FlatAdam) keep the aligned float4 launch plans
+        self.offsets = np.concatenate([[0], np.cumsum([(n + 3) & ~3 for n in sizes])]).astype(np.int64)
+        self.sizes = sizes
         self.numel = int(self.offsets[-1])
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
-        ct, cb, cl = [], [], []
+        ct, cb, cl, first = [], [], [], []
         for t, n in enumerate(sizes):
+            first.append(len(ct))
             for b in range(0, n, _CHUNK):
                 ct.append(t); cb.append(b); cl.append(min(_CHUNK, n - b))
+        first.append(len(ct))
         self.n_chunks = len(ct)
+        self._first_chunk = first                 # tensor index -> index of its first chunk
         dev = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
         self._off = dev(self.offsets[:-1], np.int64)
         self._ct, self._cb, self._cl = dev(ct, np.int32), dev(cb, np.int32), dev(cl, np.int32)
@@ -37,12 +45,27 @@ class FlatGrads:
             self._ptr_host = self._ptr_host.pin_memory()
         self._ptr_dev = torch.zeros(len(sizes), dtype=torch.int64, device=device)
         self._last_ptrs = None
+        self.buckets = [(0, len(sizes))]          # tensor index ranges
 
-    def _copy(self, direction):
+    def set_buckets(self, tensor_cuts):
+        """Cut the buffer at the given tensor indices, e.g. [k] -> buckets [0,k) and [k,n)."""
+        cuts = [0] + sorted(int(c) for c in tensor_cuts if 0 < int(c) < len(self.params)) + [len(self.params)]
+        self.buckets = [(a, b) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        return self.buckets
+
+    def bucket_view(self, k):
+        a, b = self.buckets[k]
+        return self.flat[int(self.offsets[a]):int(self.offsets[b])]
+
+    def _copy(self, direction, bucket=None, scale=1.0):
+        a, b = self.buckets[bucket] if bucket is not None else (0, len(self.params))
         ptrs = []
         for i, p in enumerate(self.params):
             if p.grad is None:
-                raise RuntimeError("FlatGrads: parameter %d has no gradient" % i)
+                if a <= i < b:
+                    raise RuntimeError("FlatGrads: parameter %d has no gradient" % i)
+                ptrs.append(0)                   # outside this bucket (its gradient lands in a later phase): not touched
+                continue
             if not p.grad.is_contiguous():
                 raise RuntimeError("FlatGrads: non-contiguous gradient")
             ptrs.append(p.grad.data_ptr())
@@ -52,17 +75,20 @@ class FlatGrads:
             self._ptr_host.copy_(torch.tensor(ptrs, dtype=torch.int64))
             self._ptr_dev.copy_(self._ptr_host)          # synchronous: the host staging buffer is reused
             self._last_ptrs = ptrs
-        _lib.call("cg_multi_copy", ops._ptr(self._ptr_dev), ops._ptr(self._off), ops._ptr(self._ct), ops._ptr(self._cb),
-                  ops._ptr(self._cl), self.n_chunks, ops._ptr(self.flat), direction, ops._stream(self.flat))
+        c0, c1 = self._first_chunk[a], self._first_chunk[b]
+        if c1 <= c0:
+            return
+        _lib.call("cg_multi_copy", ops._ptr(self._ptr_dev), ops._ptr(self._off), ops._ptr(self._ct[c0:]), ops._ptr(self._cb[c0:]),
+                  ops._ptr(self._cl[c0:]), c1 - c0, ops._ptr(self.flat), direction, float(scale), ops._stream(self.flat))
 
-    def gather(self):
-        """p.grad -> flat (one launch)."""
-        self._copy(0)
-        return self.flat
+    def gather(self, bucket=None, scale=1.0):
+        """p.grad * scale -> flat (one launch); `bucket` restricts it to one bucket of tensors."""
+        self._copy(0, bucket, scale)
+        return self.flat if bucket is None else self.bucket_view(bucket)
 
-    def scatter(self):
+    def scatter(self, bucket=None):
         """flat -> p.grad (one launch)."""
-        self._copy(1)
+        self._copy(1, bucket)
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -82,14 +108,12 @@ class FlatAdam(torch.optim.Optimizer):
         self.params = params
         device = params[0].device
         self.grads = flat if flat is not None else FlatGrads(params, device)
-        self.flat_param = torch.empty(self.grads.numel, dtype=torch.float32, device=device)
-        off = 0
+        self.flat_param = torch.zeros(self.grads.numel, dtype=torch.float32, device=device)
         with torch.no_grad():
-            for p in params:
-                n = p.numel()
+            for p, off in zip(params, self.grads.offsets[:-1]):
+                n, off = p.numel(), int(off)
                 self.flat_param[off:off + n].copy_(p.detach().reshape(-1))
-                p.data = self.flat_param[off:off + n].view(p.shape)       # same values, new home
-                off += n
+                p.data = self.flat_param[off:off + n].view(p.shape)       # same values, new (16-byte aligned) home
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.step_count = 0
@@ -115,17 +139,65 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
-        """moments and step count on the flat buffer + the parameter group (checkpoint 'optimizer' entry, train.py:184-194)"""
+        """The checkpoint 'optimizer' entry (train.py:184-194) in the layout of the reference's own optimizer,
+        `torch.optim.Adam.state_dict()`: per-parameter `step / exp_avg / exp_avg_sq` + one parameter group, so that a
+        checkpoint written here resumes in the reference (`model_loader.py:23`) and vice versa."""
         group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        return {"flat": True, "step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_group": group}
+        group.pop("clip_value", None)
+        for k, v in (("amsgrad", False), ("maximize", False), ("foreach", None), ("capturable", False), ("differentiable", False),
+                     ("fused", None)):
+            group.setdefault(k, v)
+        group["params"] = list(range(len(self.params)))
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in enumerate(zip(self.params, self.grads.offsets[:-1])):
+                n, off = p.numel(), int(off)
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": [group], "clip_value": self.param_groups[0].get("clip_value", 0.0)}
 
     def load_state_dict(self, state):
-        if not state.get("flat"):
-            raise ValueError("FlatAdam.load_state_dict: not a FlatAdam state (per-tensor torch.optim.Adam states are not converted)")
-        self.step_count = int(state["step"])
-        self.exp_avg.copy_(state["exp_avg"]); self.exp_avg_sq.copy_(state["exp_avg_sq"])
-        self.param_groups[0].update(state["param_group"])
+        """Accepts a `torch.optim.Adam` state dict (what the reference stores in `ckpt['optimizer']`, and what
+        `state_dict()` above writes) or the flat layout of earlier builds."""
+        if state.get("flat"):
+            if state["exp_avg"].numel() == self.exp_avg.numel():
+                self.exp_avg.copy_(state["exp_avg"]); self.exp_avg_sq.copy_(state["exp_avg_sq"])
+            else:                                   # written before the slots were padded to 16 bytes: dense layout
+                o = 0
+                for p, off in zip(self.params, self.grads.offsets[:-1]):
+                    n, off = p.numel(), int(off)
+                    self.exp_avg[off:off + n].copy_(state["exp_avg"][o:o + n]); self.exp_avg_sq[off:off + n].copy_(state["exp_avg_sq"][o:o + n])
+                    o += n
+            self.step_count = int(state["step"])
+            self.param_groups[0].update(state["param_group"])
+            return
+        groups = state.get("param_groups")
+        if not groups or len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one parameter group over %d tensors" % len(self.params))
+        if groups[0].get("amsgrad") or groups[0].get("maximize"):
+            raise ValueError("FlatAdam.load_state_dict: amsgrad / maximize states are not supported")
+        per = state.get("state", {})
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for i, (p, off) in enumerate(zip(self.params, self.grads.offsets[:-1])):
+            st = per.get(i, per.get(str(i)))
+            if st is None:
+                continue
+            n, off = p.numel(), int(off)
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("FlatAdam.load_state_dict: moment %d has shape %s, parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1)); self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters are at different step counts %s" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        g = self.param_groups[0]
+        for k in ("lr", "betas", "eps", "weight_decay", "initial_lr"):
+            if k in groups[0]:
+                g[k] = groups[0][k]
+        if "clip_value" in state:
+            g["clip_value"] = state["clip_value"]
 
 
 def set_optimizer(model, opt):
@@ -136,19 +208,21 @@ def set_optimizer(model, opt):
 
 
 def allreduce_mean_(flat, group=None):
-    """In-place mean over the data-parallel group: RCCL all-reduce(sum) over xGMI (backend "nccl" on
-    ROCm) or gloo in the CPU tests, then the 1/world scale folded into the same buffer."""
+    """In-place mean over the data-parallel group: RCCL all-reduce(sum) over xGMI (backend "nccl" on ROCm) or gloo in the
+    CPU tests, then 1/world on the same buffer (one library kernel).  `DataParallelStep` does not need that kernel: it folds
+    the shard weight into the gradient gather and the 1/world into the Adam update."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
         return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.mul_(1.0 / world)
+    _lib.call("cg_scale", ops._ptr(flat), flat.numel(), 1.0 / world, ops._stream(flat))
     return flat
 
 
 def shard_weights(local_batch, group=None):
-    """Weight of this replica's gradient when per-GPU batches differ (BASELINE config 5): B_r / sum B."""
+    """Weight of this replica's gradient when per-GPU batches differ (BASELINE config 5): B_r * world / sum B, so that
+    the plain mean of the weighted replica gradients is the gradient of the global mean loss."""
     import torch.distributed as dist
     t = torch.tensor([float(local_batch)])
     if dist.get_backend(group) == "nccl":
@@ -170,24 +244,69 @@ def _drop_graph_attributes(model):
                 del m.__dict__[k]
 
 
-class GraphedStep:
+def _buffers_snapshot(model, device):
+    """BatchNorm running statistics / counters and the dropout seed: warm-up and probe passes must not move them."""
+    bufs = [b for b in model.buffers()]
+    return [b.clone() for b in bufs], ops.seed_state(device).clone()
+
+
+def _buffers_restore(model, device, snap):
+    with torch.no_grad():
+        for b, v in zip(model.buffers(), snap[0]):
+            b.copy_(v)
+        ops.seed_state(device).copy_(snap[1])
+
+
+class _StepBase:
+    """Shared by the step objects: private zero pool (installed only around their own passes), static inputs, guard that
+    the parameters still live where the captured launches read them."""
+
+    def _init_common(self, model, x, target, flat):
+        self.model, self.flat = model, flat
+        self.x, self.target = x, target
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._pool = ops.new_step_pool(x.device)
+        self._one = torch.ones((), dtype=torch.float32, device=x.device)
+        self._param_ptrs = None
+
+    def _pass(self):
+        """forward + MPJPE + backward of the static batch"""
+        for p in self.params:
+            p.grad = None
+        pred, = self.model(self.x)
+        loss = ops.mpjpe(pred, self.target)
+        loss.backward(self._one)            # explicit root gradient: autograd would fill a fresh ones tensor with a stock kernel
+        return loss
+
+    def _freeze_param_pointers(self):
+        self._param_ptrs = [p.data_ptr() for p in self.params]
+
+    def _check_param_pointers(self):
+        if self._param_ptrs is not None and any(p.data_ptr() != q for p, q in zip(self.params, self._param_ptrs)):
+            raise RuntimeError("the parameters moved after this step was captured (FlatAdam / model.to() / load with assign): "
+                               "the HIP graph still reads the old buffers. Build FlatAdam BEFORE the step object.")
+
+
+class GraphedStep(_StepBase):
     """forward + MPJPE + backward of one batch, captured once in a HIP graph and replayed: the ~2 k
     kernel launches of a step collapse into one graph launch, which is what makes the B=16
     configuration viable.  Inputs live in static device buffers (`x`, `target`).  With `flat`, the
     gradients (static buffers under replay) are gathered into the flat all-reduce buffer by one
-    kernel launched right after the graph."""
+    kernel launched right after the graph.
+
+    Order matters and is enforced: anything that re-homes the parameters (`FlatAdam(model)`, `model.to()`) must happen
+    BEFORE the capture; `replay()` raises if a parameter has moved since.  Construction leaves the model state untouched:
+    BatchNorm running statistics, `num_batches_tracked` and the dropout seed are restored after warm-up and probing."""
 
     def __init__(self, model, x, target, warmup=3, flat=None, branches=False, tries=1):
         """tries > 1: capture that many graphs (each lands in different memory), time a few replays of each and keep the
-        fastest.  Measured on MI355X: the same step replays in 5.27 .. 5.46 ms depending on where the capture's buffers
-        were placed, stable for the life of a capture (tools/diag_bimodal.py)."""
-        self.model, self.flat = model, flat
+        median one (the same step replays in 5.27 .. 5.46 ms depending on where the capture's buffers were placed, stable
+        for the life of a capture: tools/diag_bimodal.py); `capture_ms` lists all probes."""
+        self._init_common(model, x.clone(), target.clone(), flat)
         # Optional: the context branch on a forked stream (one fork / join per step, CISTGCN._parallel) -> a parallel graph
         # branch.  Captures and replays correctly on ROCm 7.2 but measured no faster (5.44 vs 5.43 ms at B=16), so it is off.
         model.branch_streams = bool(branches)
-        ops.step_scratch(x.device, True)       # one fwd+bwd per begin_step, gradients consumed before the next: pool is safe
-        self.x, self.target = x.clone(), target.clone()
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        snap = _buffers_snapshot(model, x.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -196,7 +315,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _drop_graph_attributes(model)      # Adj / w1 / ... of the warm-up pass keep its autograd graph (and streams) alive
-        best, losers = None, []
+        cands = []
         for _ in range(max(1, int(tries))):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -208,17 +327,15 @@ class GraphedStep:
             if tries > 1:
                 cand[0] = self._probe(graph)
             _drop_graph_attributes(model)
-            if best is None or cand[0] < best[0]:
-                if best is not None:
-                    losers.append(best)
-                best = cand
-            else:
-                losers.append(cand)            # kept alive until the end so that the next capture lands elsewhere
-        self.capture_ms = [round(c[0], 4) for c in [best] + losers] if tries > 1 else None
-        del losers
+            cands.append(cand)                 # all kept alive until the end so that the next capture lands elsewhere
+        self.capture_ms = [round(c[0], 4) for c in cands] if tries > 1 else None
+        best = sorted(cands, key=lambda c: c[0])[len(cands) // 2]      # the median capture: a representative, not the best
+        del cands
         self.graph, self.loss = best[1], best[2]
         for p, g in zip(self.params, best[3]):     # the parameters' .grad must be the buffers THIS graph writes
             p.grad = g
+        _buffers_restore(model, x.device, snap)
+        self._freeze_param_pointers()
 
     @staticmethod
     def _probe(graph, n=20):
@@ -233,14 +350,11 @@ class GraphedStep:
         return (time.perf_counter() - t0) / n * 1e3
 
     def _step(self):
-        for p in self.params:
-            p.grad = None
-        pred, = self.model(self.x)
-        loss = ops.mpjpe(pred, self.target)
-        loss.backward()
-        return loss
+        with ops.step_pool(self._pool):
+            return self._pass()
 
     def replay(self):
+        self._check_param_pointers()
         self.graph.replay()
         if self.flat is not None:
             self.flat.gather()
@@ -271,20 +385,137 @@ class GraphedForward:
         return self.pred
 
 
-class EagerStep:
+class EagerStep(_StepBase):
     """Same step without graph capture (debugging / first-iteration reference)."""
 
     def __init__(self, model, x, target, flat=None):
-        self.model, self.flat, self.x, self.target = model, flat, x, target
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        ops.step_scratch(x.device, True)
+        self._init_common(model, x, target, flat)
 
     def replay(self):
-        for p in self.params:
-            p.grad = None
-        pred, = self.model(self.x)
-        self.loss = ops.mpjpe(pred, self.target)
-        self.loss.backward()
+        with ops.step_pool(self._pool):
+            self.loss = self._pass()
         if self.flat is not None:
             self.flat.gather()
+        return self.loss
+
+
+class DataParallelStep(_StepBase):
+    """One data-parallel training step of this replica (BASELINE configs[3] and [4]): forward + MPJPE +
+    backward on the local shard, gradient mean over the group, optional FlatAdam update.
+
+    * Unequal per-GPU batches: each replica's gradient is weighted B_r * world / sum B (`shard_weights`) inside the gather
+      kernel, the 1/world goes into the Adam kernel's `grad_scale` (or one `cg_scale` without optimizer): the result is the
+      gradient of the global mean loss, with per-replica BatchNorm statistics as in the (single-GPU) reference.
+    * Overlap: the autograd graph is cut behind input block `cut_block`.  Phase 1 = forward + backward down to the cut
+      (output block, context branch, time extrapolator, upper input blocks: their gradients are the tail of the flat
+      buffer); its bucket is gathered and all-reduced on a side stream while phase 2 (the remaining input blocks) runs.
+      With `graph=True` the two phases are two HIP graphs that share one memory pool.
+    The only collective is the all-reduce (RCCL over xGMI under backend "nccl"; gloo in the CPU tests)."""
+
+    def __init__(self, model, x, target, optimizer=None, group=None, cut_block=None, graph=True, warmup=3, flat=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.optimizer = optimizer
+        flat = optimizer.grads if optimizer is not None else (flat if flat is not None else FlatGrads(model.parameters(), x.device))
+        self._init_common(model, x.clone() if graph else x, target.clone() if graph else target, flat)
+        self.weight = shard_weights(x.shape[0], group) if self.world > 1 else 1.0
+        nblk = len(model.st_gcnns)
+        self.cut_block = (nblk // 2 - 1 if cut_block is None else int(cut_block))
+        self.two_phase = 0 <= self.cut_block < nblk - 1
+        if self.two_phase:
+            first_late = {id(p) for b in list(model.st_gcnns)[:self.cut_block + 1] for p in b.parameters()}
+            k = sum(1 for p in flat.params if id(p) in first_late)
+            if [id(p) in first_late for p in flat.params] != [True] * k + [False] * (len(flat.params) - k):
+                raise RuntimeError("DataParallelStep: the late-bucket parameters are not a prefix of the flat buffer")
+            flat.set_buckets([k])                # bucket 0 = blocks [0, cut] (gradients land last), bucket 1 = the rest
+        self._cut_in = self._cut_leaf = None
+        self.graphs = None
+        self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
+        if graph:
+            self._capture(warmup)
+        self._freeze_param_pointers()
+
+    # ---- the two phases ---------------------------------------------------------------------------------------
+    def _cut(self, h):
+        t, st = h if isinstance(h, tuple) else (h, None)
+        self._cut_in = t
+        self._cut_leaf = t.detach().requires_grad_(True)
+        return (self._cut_leaf, st) if st is not None else self._cut_leaf
+
+    def _phase1(self):
+        self.model.backward_cut = (self.cut_block, self._cut) if self.two_phase else None
+        try:
+            return self._pass()
+        finally:
+            self.model.backward_cut = None
+
+    def _phase2(self):
+        if self.two_phase:
+            self._cut_in.backward(self._cut_leaf.grad)
+
+    def _capture(self, warmup):
+        snap = _buffers_snapshot(self.model, self.x.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), ops.step_pool(self._pool):
+            for _ in range(warmup):
+                self._phase1(); self._phase2()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        _drop_graph_attributes(self.model)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with ops.step_pool(self._pool):
+            with torch.cuda.graph(g1):
+                loss = self._phase1()
+            if self.two_phase:
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._phase2()
+        self.loss = loss.detach()
+        self._cut_in = self._cut_leaf = None
+        _drop_graph_attributes(self.model)
+        self.graphs = (g1, g2 if self.two_phase else None)
+        _buffers_restore(self.model, self.x.device, snap)
+
+    # ---- one step ---------------------------------------------------------------------------------------------
+    def _reduce(self, bucket, async_op):
+        import torch.distributed as dist
+        buf = self.flat.gather(bucket, scale=self.weight)
+        if self.world > 1:
+            return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        return None
+
+    def replay(self):
+        self._check_param_pointers()
+        cuda = self.x.is_cuda
+        if self.graphs is not None:
+            self.graphs[0].replay()
+        else:
+            with ops.step_pool(self._pool):
+                self.loss = self._phase1()
+        work = None
+        if self.two_phase:
+            if cuda:                                   # early bucket: gather + all-reduce beside phase 2
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    work = self._reduce(1, True)
+            else:
+                work = self._reduce(1, True)
+            if self.graphs is not None:
+                self.graphs[1].replay()
+            else:
+                with ops.step_pool(self._pool):
+                    self._phase2()
+                self._cut_in = self._cut_leaf = None
+            self._reduce(0, False)
+            if work is not None:
+                work.wait()
+            if cuda:
+                torch.cuda.current_stream().wait_stream(self._side)
+        else:
+            self._reduce(None, False)
+        if self.optimizer is not None:
+            self.optimizer.step(grad_scale=1.0 / self.world, gathered=True)
+        elif self.world > 1:
+            _lib.call("cg_scale", ops._ptr(self.flat.flat), self.flat.flat.numel(), 1.0 / self.world, ops._stream(self.flat.flat))
         return self.loss

@@ -206,7 +206,11 @@ int cg_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg
  * flat fp32 buffer that RCCL all-reduces: ptrs[t] <-> flat + flat_off[t], work pre-chunked
  * on the host (chunk i = chunk_len[i] elements of tensor chunk_tensor[i] from element chunk_begin[i]). */
 int cg_multi_copy(void* ptrs, const long long* flat_off, const int32_t* chunk_tensor, const int32_t* chunk_begin,
-                  const int32_t* chunk_len, int n_chunks, float* flat, int direction, void* stream);
+                  const int32_t* chunk_len, int n_chunks, float* flat, int direction, float scale, void* stream);
+/* `scale` multiplies the gathered gradients (direction 0): the replica weight B_r * world / sum B of a data-parallel step
+ * with unequal per-GPU batches (BASELINE configs[4]); passing a sub-range of the chunk arrays gathers one bucket.
+ * p[i] *= s: the 1/world of the gradient mean when no optimizer kernel follows to absorb it (cg_adam_flat's grad_scale). */
+int cg_scale(float* p, long long n, float s, void* stream);
 
 #ifdef __cplusplus
 }

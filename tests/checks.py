@@ -678,6 +678,64 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
             assert_close(sd[k].float(), so[k].float(), k)
 
 
+def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=350.0, grad_floor=1.0, max_flip_frac=2e-5,
+                              x=None, tgt=None, net=None, ora=None, **cfg_kw):
+    """Flip-aware parity of EVERY parameter gradient (north_star tolerance 1e-4): the HIP model runs first and records
+    the branch each PReLU element took (`net.act_trace`); the oracle then differentiates the same piecewise-linear
+    function (helpers.BranchReplay), so no kink allowance is needed: pred, loss, dL/dx and all parameter gradients are
+    held to max|a-b| <= 1e-4 * max(floor, max|ref|).  The branches the oracle would have taken on its own are compared
+    too: they may differ from the HIP ones only on a vanishing fraction of elements whose pre-activation is rounding-sized."""
+    from helpers import BranchReplay, assert_grads_strict
+    g = _gen(2000 + seed)
+    To = cfg_kw.get("To", 25)
+    if net is None:
+        net, ora = build_pair(C, T, V, device, seed=seed, **cfg_kw)
+        with torch.no_grad():                      # move off the init so Adj / gates are numerically alive
+            for p in ora.parameters():
+                p.add_(0.3 * torch.randn(p.shape, generator=g) / max(1.0, float(p[0].numel()) ** 0.5 if p.dim() > 1 else 3.0))
+            for m in ora.modules():
+                if isinstance(m, nn.PReLU):
+                    m.weight.abs_().clamp_(min=0.05)   # branch replay reads the branch off the sign of the output
+        net.load_state_dict(ora.state_dict())
+    if x is None:
+        x = 50 + scale * torch.randn(B, T, V, 3, generator=g)
+        tgt = x[:, -1:] + 20 * torch.randn(B, To, V, 3, generator=g)
+        ora.train(); net.train()
+        with torch.no_grad():                      # settle running statistics on both sides identically
+            ora(x)
+        net.load_state_dict(ora.state_dict())
+    ora.train(mode == "train"); net.train(mode == "train")
+    xd = x.clone().to(device).requires_grad_(True)
+    net.act_trace = {}
+    try:
+        pd, = net(xd)
+        ld = ops.mpjpe(pd, tgt.to(device))
+        ld.backward()
+        trace = net.act_trace
+    finally:
+        net.act_trace = None
+    xo = x.clone().requires_grad_(True)
+    with BranchReplay(net, ora, trace) as rep:
+        po, = ora(xo)
+        lo = O.mpjpe(po, tgt)
+        lo.backward()
+    assert rep.sites == sum(1 for m in ora.modules() if isinstance(m, nn.PReLU)), "a PReLU was not replayed (%d sites)" % rep.sites
+    frac = rep.flips / max(1, rep.elements)
+    assert frac <= max_flip_frac, "HIP and oracle disagree on %d of %d PReLU branches" % (rep.flips, rep.elements)
+    assert rep.worst <= 1e-2, "a flipped pre-activation is not rounding-sized: |x| = %.2e of the mean magnitude" % rep.worst
+    assert_close(pd, po, "pred")
+    assert_close(ld, lo, "loss")
+    assert_close(xd.grad, xo.grad, "dL/dx", floor=1e-1)
+    gd = dict(net.named_parameters())
+    worst = assert_grads_strict({k: gd[k].grad for k, _ in ora.named_parameters()}, {k: p.grad for k, p in ora.named_parameters()},
+                                "branch replay", floor=grad_floor)
+    sd, so = net.state_dict(), ora.state_dict()
+    for k in so:
+        if "running" in k or "num_batches" in k:
+            assert_close(sd[k].float(), so[k].float(), k)
+    return {"flips": rep.flips, "elements": rep.elements, "worst_flip": rep.worst, "worst_grad": worst}
+
+
 def check_flat_adam(device):
     """cg_adam_flat + FlatGrads against torch.optim.Adam with the reference's settings (weight decay, no amsgrad)."""
     from cistgcn_amd.runtime import FlatAdam

@@ -1,13 +1,18 @@
-"""Data-parallel path on the CPU: two gloo ranks run the runtime's flat-gradient
-gather (the HIP multi-copy kernel through the test shim), the all-reduce-mean and the scatter, and
-the result must equal the mean of the per-rank gradients.  Per-replica BatchNorm is the reference
-semantics, so this is all the communication the path has."""
+"""Data-parallel path on the CPU: two gloo ranks run `runtime.DataParallelStep` on the MODEL (the shipped
+kernels through the test shim, tests/hipemu) with UNEQUAL shards, and the all-reduced flat buffer must equal what the
+parity check of §8e prescribes: the oracle run on each shard separately (train mode, dropout 0, per-replica BatchNorm)
+and the gradients averaged with weights B_r / sum B.  Also: the two-phase (bucketed, overlapped) step gives the same
+buffer as the one-phase step, and FlatAdam driven by it applies the same update on both ranks."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
+
+SHARDS = (3, 5)            # per-rank batch sizes (BASELINE configs[4]: mixed batch sizes)
+CFG = dict(C=4, T=4, V=5, To=8, hidden=8)
 
 
 def _free_port():
@@ -19,35 +24,78 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException as e:              # report instead of leaving the parent waiting on the queue
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    torch.set_num_threads(2)
     import torch.distributed as dist
     import emu
     emu.install()
-    from cistgcn_amd.runtime import FlatGrads, allreduce_mean_, shard_weights
+    import checks
+    from helpers import BranchReplay
+    from oracle import cistgcn_ref as O
+    from cistgcn_amd.runtime import DataParallelStep, FlatAdam, FlatGrads
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(37, 11), torch.nn.BatchNorm1d(11), torch.nn.Linear(11, 5000), torch.nn.PReLU())
-    g = torch.Generator().manual_seed(100 + rank)
-    for p in net.parameters():
-        p.grad = torch.randn(p.shape, generator=g)
-    mine = [p.grad.clone() for p in net.parameters()]
-    flat = FlatGrads(net.parameters(), "cpu")
-    buf = flat.gather()
-    assert buf.numel() == sum(p.numel() for p in net.parameters())
-    assert torch.equal(buf, torch.cat([m.flatten() for m in mine]))
-    allreduce_mean_(buf)
-    flat.scatter()
-    w = shard_weights(16 if rank == 0 else 48)      # unequal per-GPU batches (BASELINE config 5)
-    # by value (numpy): tensors sent through a Queue travel as shared-memory handles that die with this process
-    q.put((rank, [p.grad.numpy().copy() for p in net.parameters()], [m.numpy().copy() for m in mine], w))
+    C, T, V = CFG["C"], CFG["T"], CFG["V"]
+    kw = dict(To=CFG["To"], hidden=CFG["hidden"])
+    net, ora = checks.build_pair(C, T, V, "cpu", seed=0, **kw)          # same seed -> same replica weights on every rank
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for p in ora.parameters():
+            p.add_(0.3 * torch.randn(p.shape, generator=g) / max(1.0, float(p[0].numel()) ** 0.5 if p.dim() > 1 else 3.0))
+        for m in ora.modules():
+            if isinstance(m, torch.nn.PReLU):
+                m.weight.abs_().clamp_(min=0.05)
+    net.load_state_dict(ora.state_dict())
+    net.train(); ora.train()
+    xs = 50 + 350 * torch.randn(sum(SHARDS), T, V, 3, generator=g)
+    ts = xs[:, -1:] + 20 * torch.randn(sum(SHARDS), CFG["To"], V, 3, generator=g)
+    lo = sum(SHARDS[:rank])
+    x, tgt = xs[lo:lo + SHARDS[rank]], ts[lo:lo + SHARDS[rank]]
+    state0 = {k: v.clone() for k, v in net.state_dict().items()}
+
+    # (a) two-phase step, no optimizer: flat buffer = weighted gradient mean
+    net.act_trace = {}
+    step = DataParallelStep(net, x, tgt, graph=False, cut_block=1)
+    assert step.two_phase and len(step.flat.buckets) == 2
+    step.replay()
+    trace, net.act_trace = net.act_trace, None
+    two_phase = step.flat.flat.clone()
+    # the oracle on this shard, on the branches the kernels took
+    with BranchReplay(net, ora, trace):
+        po, = ora(x.clone())
+        O.mpjpe(po, tgt).backward()
+    mine = [p.grad.numpy().copy() for p in ora.parameters()]
+    # (b) one-phase step on the same weights / running statistics
+    net.load_state_dict(state0)
+    one = DataParallelStep(net, x, tgt, graph=False, cut_block=-1)
+    assert not one.two_phase
+    one.replay()
+    one_phase = one.flat.flat.clone()
+    offs = [int(o) for o in step.flat.offsets[:-1]]
+    # (c) FlatAdam driven by the step: every rank must end with the same parameters
+    net.load_state_dict(state0)
+    opt = FlatAdam(net, lr=1e-2, weight_decay=1e-4)
+    st2 = DataParallelStep(net, x, tgt, optimizer=opt, graph=False, cut_block=1)
+    st2.replay()
+    after = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).numpy().copy()
+    q.put((rank, two_phase.numpy().copy(), one_phase.numpy().copy(), mine, offs, step.weight, after))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gradient_mean():
+@pytest.mark.timeout(1500)
+def test_two_rank_model_step_matches_oracle_per_shard():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
     import build_emu
@@ -60,14 +108,25 @@ def test_two_rank_gradient_mean():
         p.start()
     res = {}
     for _ in range(world):
-        rank, reduced, mine, w = q.get(timeout=240)
-        res[rank] = (reduced, mine, w)
+        item = q.get(timeout=1400)
+        assert not (isinstance(item[1], str) and item[1] == "error"), item[2]
+        res[item[0]] = item[1:]
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    import numpy as np
-    mean = [(a + b) / 2 for a, b in zip(res[0][1], res[1][1])]
+    tot = float(sum(SHARDS))
     for r in range(world):
-        for got, ref in zip(res[r][0], mean):
-            assert np.allclose(got, ref, rtol=0, atol=1e-6)
-    assert abs(res[0][2] - 0.5) < 1e-6 and abs(res[1][2] - 1.5) < 1e-6
+        assert abs(res[r][4] - SHARDS[r] * world / tot) < 1e-6          # shard_weights
+    offs = res[0][3]
+    # both ranks hold the same reduced buffer; bucketed == unbucketed
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.allclose(res[0][0], res[0][1], rtol=0, atol=1e-6 * max(1.0, float(np.abs(res[0][1]).max())))
+    # SURVEY 8e parity check: oracle per shard -> weighted mean -> compare with the all-reduced buffer
+    n = len(res[0][2])
+    for i in range(n):
+        ref = sum(SHARDS[r] / tot * res[r][2][i] for r in range(world))
+        got = res[0][0][offs[i]:offs[i] + ref.size].reshape(ref.shape)
+        err = float(np.abs(got - ref).max())
+        bound = 1e-4 * max(0.1, float(np.abs(ref).max()))
+        assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
+    assert np.array_equal(res[0][5], res[1][5]), "replicas diverged after the optimizer step"

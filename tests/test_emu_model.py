@@ -19,3 +19,9 @@ def _emulated_kernels():
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_tiny_model_matches_oracle(mode):
     checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8)
+
+
+@pytest.mark.timeout(900)
+def test_tiny_model_every_gradient_strict():
+    """all parameter gradients within 1e-4 * max(0.1, max|ref|) with the oracle on the branches the kernels took"""
+    checks.check_model_branch_replay("cpu", 4, 4, 5, 2, "train", To=8, hidden=8, grad_floor=0.1)

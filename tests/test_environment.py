@@ -1,0 +1,107 @@
+"""Callers either side of the hot path on the CPU box: checkpoint files in the reference's
+layout and naming, resume in both directions between `torch.optim.Adam` (the reference's optimizer) and `FlatAdam`,
+interpretation capture, the per-horizon MPJPE line.  FlatAdam's kernel runs through the test-only HIP shim."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import emu
+from helpers import GOLDEN_DIR
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _emulated_kernels():
+    emu.install()
+    yield
+    emu.uninstall()
+
+
+class CISTGCN(nn.Sequential):          # the loader dispatches on the class name (model_loader.py:18-20)
+    pass
+
+
+def _net(seed=3):
+    torch.manual_seed(seed)
+    return CISTGCN(nn.Linear(13, 7), nn.BatchNorm1d(7), nn.Linear(7, 33), nn.PReLU())
+
+
+def _fake_grads(net, g):
+    for p in net.parameters():
+        p.grad = torch.randn(p.shape, generator=g)
+
+
+def test_checkpoint_files_and_resume_from_a_reference_optimizer(tmp_path):
+    from cistgcn_amd.environment import load_params_from_model_path, make_checkpoint, save_ckpt
+    from cistgcn_amd.runtime import FlatAdam
+    g = torch.Generator().manual_seed(5)
+    ref = _net()
+    opt_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, weight_decay=1e-4)       # environment/utils.py:53-57
+    for _ in range(3):
+        _fake_grads(ref, g); opt_ref.step()
+    name = os.path.join(tmp_path, "CISTGCN_0-20240101.pth.tar")
+    state = make_checkpoint(7, ref, opt_ref, {"mpjpe": 41.5, "mpjpe_seq": [1.0, 2.0]}, "mpjpe")
+    assert set(state) == {"epoch", "lr", "err", "metric_used_to_save", "state_dict", "optimizer"}
+    written = save_ckpt(state, is_best=True, save_all=True, file_name=name)
+    assert [os.path.basename(w) for w in written] == ["CISTGCN_0-20240101_last.pth.tar", "CISTGCN_0-20240101_best.pth.tar",
+                                                      "CISTGCN_0-20240101_epoch_00007.pth.tar"]
+    assert all(os.path.isfile(w) for w in written)
+    assert len(save_ckpt(state, is_best=False, file_name=name)) == 1
+    # resume into the flat-buffer optimizer
+    dev = _net(seed=99)
+    opt_dev = FlatAdam(dev, lr=1.0)
+    upd = load_params_from_model_path(written[1], dev, opt_dev)
+    assert upd["epoch"] == 7 and upd["err"]["mpjpe"] == 41.5 and upd["lr"] is None and upd["optimizer"] is opt_dev
+    assert opt_dev.step_count == 3 and abs(opt_dev.lr - 1e-2) < 1e-12 and opt_dev.param_groups[0]["weight_decay"] == 1e-4
+    assert all(p.data_ptr() == opt_dev.flat_param[int(o):].data_ptr() for p, o in zip(dev.parameters(), opt_dev.grads.offsets[:-1]))
+    g2 = torch.Generator().manual_seed(6)
+    grads = [torch.randn(p.shape, generator=g2) for p in ref.parameters()]
+    for p, q, gr in zip(ref.parameters(), dev.parameters(), grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    opt_ref.step(); opt_dev.step()
+    for (k, p), q in zip(ref.named_parameters(), dev.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), k
+    # ... and back: a checkpoint written here resumes in the reference's optimizer (model_loader.py:23)
+    back = _net(seed=98)
+    opt_back = torch.optim.Adam(back.parameters(), lr=1.0)
+    back.load_state_dict(dev.state_dict())
+    opt_back.load_state_dict(make_checkpoint(8, dev, opt_dev, {"mpjpe": 40.0})["optimizer"])
+    grads = [torch.randn(p.shape, generator=g2) for p in ref.parameters()]
+    for p, q, gr in zip(back.parameters(), dev.parameters(), grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    opt_back.step(); opt_dev.step()
+    for (k, p), q in zip(back.named_parameters(), dev.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), k
+    # without an optimizer the learning rate comes back; a missing file is reported, not raised
+    upd = load_params_from_model_path(written[0], _net(seed=97))
+    assert upd["lr"] == 1e-2 and upd["optimizer"] is None
+    assert load_params_from_model_path(os.path.join(tmp_path, "nope.pth.tar"), dev) is None
+
+
+def test_interpretation_capture_and_npy(tmp_path, capsys):
+    from cistgcn_amd.environment import capture_interpretation, save_interpretation
+    from types import SimpleNamespace as NS
+    model = NS(st_gcnns=nn.ModuleList([nn.Identity()]), context_layer=NS(joints=torch.arange(6.).view(1, 6)))
+    model.st_gcnns[0].w1 = torch.ones(2, 1, 3)
+    keys = ["context_layer.joints", "st_gcnns.0.w1", "st_gcnns.4.w1"]
+    store = capture_interpretation(model, keys)
+    store = capture_interpretation(model, keys, store)
+    out = capsys.readouterr().out
+    assert out.count("st_gcnns.4.w1 is not available on model") == 2
+    assert sorted(store) == ["context_layer.joints", "st_gcnns.0.w1"] and len(store["st_gcnns.0.w1"]) == 2
+    assert store["context_layer.joints"][0].shape == (6,) and store["st_gcnns.0.w1"][0].shape == (2, 3)     # squeeze()
+    path = save_interpretation(os.path.join(tmp_path, "run_best.npy"), store, action="walking")
+    back = np.load(path, allow_pickle=True).item()                       # figures_temp.py:54 reads it back (`.all()` on old numpy)
+    assert np.array_equal(np.array(back["walking"]["interpretation"]["st_gcnns.0.w1"]), np.ones((2, 2, 3)))
+
+
+def test_mpjpe_ms_table_on_the_reference_vector():
+    from cistgcn_amd.environment import mpjpe_ms_table
+    z = np.load(os.path.join(GOLDEN_DIR, "eval_h36m.npz"))
+    frames = z["mpjpe_frames"]                                           # losses.mpjpe(reduce_axis=(0, 2)) of the reference
+    table, line = mpjpe_ms_table(frames)
+    assert list(table) == [80, 200, 400, 560, 720, 1000]
+    assert line == "mpjpe: " + " ".join("%d:%.2f," % (ms, frames[ms // 40 - 1]) for ms in table)
+    assert list(mpjpe_ms_table(frames[:10])[0]) == [80, 200, 400]
