@@ -2,7 +2,7 @@
 """Headline benchmark: sequences/sec of forward + MPJPE + backward of CIST-GCN on synthetic
 H3.6M-shaped poses (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 60 --warmup 10
+    python bench.py --gpus 1 --steps 80 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -367,7 +367,7 @@ def main():
         return cpu_baseline_worker(C, B, T, V, float(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60, help="timed steps of the headline workload (60 x ~30 ms > 2 s)")
+    ap.add_argument("--steps", type=int, default=80, help="timed steps of the headline workload (80 x ~30 ms > 2 s)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
     ap.add_argument("--dropout", type=float, default=0.1)

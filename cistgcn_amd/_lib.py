@@ -70,6 +70,29 @@ class CopyItem(ctypes.Structure):
     _fields_ = [("y", c_void_p), ("yv", View4), ("a", c_void_p), ("av", View4)]
 
 
+class TailBN(ctypes.Structure):
+    _fields_ = [("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("num_batches_tracked", c_void_p), ("momentum", c_float), ("eps", c_float), ("save", c_void_p)]
+
+
+class DstdTail(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("T", c_int), ("V", c_int), ("train", c_int), ("pad0", c_int),
+                ("y", c_void_p * 2), ("r", c_void_p * 2), ("w", c_void_p * 2),
+                ("bn_t", TailBN * 2), ("alpha_d", c_void_p * 2),
+                ("bn_p", TailBN * 2), ("alpha_p", c_void_p * 2),
+                ("Wc", c_void_p), ("bn_c", TailBN), ("alpha_c", c_void_p),
+                ("gate", c_void_p), ("bres", c_void_p),
+                ("drop_p", c_float), ("salt", c_uint * 2), ("pad1", c_int), ("seed", c_void_p),
+                ("h0", c_void_p), ("pooled", c_void_p), ("out", c_void_p), ("ostats", c_void_p),
+                ("tap_x", c_void_p * 2), ("tap_a", c_void_p * 2), ("tap_h", c_void_p),
+                ("dout", c_void_p), ("dpooled", c_void_p), ("dgate", c_void_p), ("red_c", c_void_p),
+                ("gp", c_void_p * 2), ("red_p", c_void_p * 2), ("dWc_ws", c_void_p), ("dWc", c_void_p),
+                ("dr", c_void_p * 2), ("dw", c_void_p * 2), ("red_t", c_void_p * 2), ("dy", c_void_p * 2),
+                ("dgamma_t", c_void_p * 2), ("dbeta_t", c_void_p * 2), ("dalpha_d", c_void_p * 2),
+                ("dgamma_p", c_void_p * 2), ("dbeta_p", c_void_p * 2), ("dalpha_p", c_void_p * 2),
+                ("dgamma_c", c_void_p), ("dbeta_c", c_void_p), ("dalpha_c", c_void_p)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -108,6 +131,10 @@ _SIGNATURES = {
     "cg_stgcn_domain_bwd_ws_floats": [c_int, c_int],
     "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, c_float, P],
     "cg_scale": [P, LL, c_float, P],
+    "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
+    "cg_dstd_tail_bwd": [POINTER(DstdTail), c_int, P],
+    "cg_dstd_tail_ws_floats": [c_int],
+    "cg_augment_sequences": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -1,0 +1,635 @@
+// Tail of a DSTD_GC block as phase kernels (reference: CISTGCN.py:266-269 `tcn` BatchNorm + Dropout + residual + PReLU of both
+// Domain_GCNN layers, :388 `PReLU(BN(w * x))` of both branches + cat, :305-309 compressor 1x1 conv + BN + PReLU + SELayer2d,
+// :390 block residual).  In train mode every BatchNorm needs the batch statistics of its input before the next operation
+// can run, so the chain is cut exactly at those barriers and nowhere else; nothing but the compressor's pre-activation `h0`
+// and the tensors autograd has to hand on (gradients at the barriers) touches HBM.
+//
+//   forward   F1  sums of z_i = w_i * PReLU_d(Dropout(BN_t(y_i)) + r_i)                    (reads y_i, r_i)
+//             F2  a_i = PReLU_p(BN_p(z_i)) recomputed per tile -> h0 = Wc [a_1; a_2] on the matrix cores + sums of h0
+//             F3  pooled[b,c] = mean_{t,v} PReLU_c(BN_c(h0))                                  (reads h0)
+//             --  SELayer excitation (cg_se_gate_fwd)
+//             F4  out = PReLU_c(BN_c(h0)) * gate + block residual, + sums of out for the next block's BatchNorm
+//   backward  K1  dgate[b,c] = sum_{t,v} dout * h                                              (reads dout, h0)
+//             --  SELayer excitation backward (cg_se_gate_bwd) -> dpooled
+//             K2  sums of g_c = (dout * gate + dpooled / P) * PReLU_c'  (and g_c * h0_hat, d alpha_c)
+//             K3  dh0 = BN_c'(g_c) per tile; d[a] = Wc^T dh0 and dWc += dh0 a^T on the matrix cores; g_p = d a * PReLU_p'
+//                 -> HBM, + its BatchNorm sums
+//             K4  dz = BN_p'(g_p); dw = sum dz * x; g_d = w * dz * PReLU_d' -> HBM (= gradient of the residual addend),
+//                 + sums of the `tcn` BatchNorm
+//             K5  dy_i = BN_t'(g_d * keep)
+// Statistics are f64 sums in replicated slots (cg_common.h), reductions of the backward in f64 as in rowops.hip; the
+// element arithmetic is f32 with the mean subtracted first, exactly as cg_norm_act does it, so the two paths agree to
+// rounding.  Dropout draws are those of cg_norm_act (same counter-based hash of seed, site and element index).
+#include "cg_common.h"
+#include "dstd_tail.h"
+
+HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
+
+typedef float cg_f32x4 __attribute__((vector_size(16)));
+
+// ---- per-channel constants -------------------------------------------------------------------------------------------
+struct CgAff { float mean, rstd, gamma, beta; };
+
+// train: batch statistics from the replicated f64 sums (and, by the block that owns channel bookkeeping, save + running
+// statistics exactly like nn.BatchNorm); eval: running statistics.  backward: the saved pair.
+__device__ __forceinline__ CgAff cg_tail_aff(const CgTailBN& bn, int c, int C, double cnt, int train, bool backward, bool owner) {
+  CgAff a;
+  a.gamma = bn.gamma[c]; a.beta = bn.beta[c];
+  if (backward) { a.mean = bn.save[c]; a.rstd = bn.save[C + c]; return a; }
+  if (train) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < CG_STAT_REPLICAS; ++r) { s1 += bn.stats[((long long)r * C + c) * 2]; s2 += bn.stats[((long long)r * C + c) * 2 + 1]; }
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    a.mean = (float)mean;
+    a.rstd = (float)(1.0 / sqrt(var + (double)bn.eps));
+    if (owner) {
+      bn.save[c] = a.mean; bn.save[C + c] = a.rstd;
+      if (bn.running_mean) {
+        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
+        bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
+        if (c == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
+      }
+    }
+  } else {
+    a.mean = bn.running_mean[c];
+    a.rstd = 1.0f / sqrtf(bn.running_var[c] + bn.eps);
+    if (owner) { bn.save[c] = a.mean; bn.save[C + c] = a.rstd; }
+  }
+  return a;
+}
+
+__device__ __forceinline__ float cg_bn(const CgAff& a, float v) { return (v - a.mean) * (a.gamma * a.rstd) + a.beta; }
+__device__ __forceinline__ float cg_prelu(float u, float alpha) { return u > 0.f ? u : alpha * u; }
+
+// rows of one channel per workgroup, as rowops.hip
+static int cg_tail_rows(long long B, long long C, long long P) {
+  long long target = (B * C * P) / 2048;
+  target = target < 4096 ? 4096 : (target > 32768 ? 32768 : target);
+  long long rb = target / (P > 0 ? P : 1);
+  if (rb < 1) rb = 1;
+  if (rb > B) rb = B;
+  while (rb > 1 && C * ((B + rb - 1) / rb) < 512) rb = (rb + 1) / 2;
+  return (int)rb;
+}
+
+// x_i = PReLU_d(Dropout(BN_t(y)) + r) for one element; also returns the pre-activation u and the keep factor
+__device__ __forceinline__ float cg_tail_x(const CgAff& at, float alpha_d, float y, float r, float keep, float& u) {
+  u = cg_bn(at, y) * keep + r;
+  return cg_prelu(u, alpha_d);
+}
+
+__device__ __forceinline__ float cg_tail_keep(const CgDstdTail& t, int i, unsigned long long seed, int b, int c, int p) {
+  if (!(t.train && t.drop_p > 0.f)) return 1.f;
+  const long long P = (long long)t.T * t.V;
+  return cg_drop_scale(t.drop_p, seed, t.salt[i], ((unsigned long long)b * t.C + c) * P + p);
+}
+
+// ======================================================================================================================
+// F1: channel sums of z_i = w_i * x_i     grid (C, batch chunks, 2)
+// ======================================================================================================================
+__global__ void cg_tail_f1_kernel(CgDstdTail t, int rb) {
+  __shared__ double red[32];
+  const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (b0 >= t.B) return;
+  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const double cnt = (double)t.B * P;
+  const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, cnt, t.train, false, blockIdx.y == 0 && threadIdx.x == 0);
+  const float ad = t.alpha_d[i][0];
+  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const float* __restrict__ y = t.y[i]; const float* __restrict__ r = t.r[i];
+  double s = 0.0, q = 0.0;
+  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
+    const int br = e / P, p = e - br * P, b = b0 + br;
+    const long long off = ((long long)b * t.C + c) * P + p;
+    float u;
+    const float x = cg_tail_x(at, ad, y[off], r[off], cg_tail_keep(t, i, seed, b, c, p), u);
+    const float z = t.w[i][(long long)b * t.C + c] * x;
+    if (t.tap_x[i]) t.tap_x[i][off] = x;
+    s += (double)z; q += (double)z * (double)z;
+  }
+  s = cg_block_sum(s, red);
+  q = cg_block_sum(q, red + 16);
+  if (threadIdx.x == 0) {
+    double* rep = t.bn_p[i].stats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * t.C;
+    atomicAdd(&rep[2 * c], s); atomicAdd(&rep[2 * c + 1], q);
+  }
+}
+
+// ======================================================================================================================
+// matrix-core helpers (same fragment scheme as stgcn_domain_mfma.hip: inside a 16-wide k chunk step s takes k = 4*slot + s)
+// ======================================================================================================================
+template <int KIND>
+__device__ __forceinline__ void cg_tfrag(const float* __restrict__ p, int rs, int k0, float v[4]) {
+  if (KIND == 0) {
+    const float4 t = *reinterpret_cast<const float4*>(p + k0);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    const float* q = p + k0 * rs;
+    v[0] = q[0]; v[1] = q[rs]; v[2] = q[2 * rs]; v[3] = q[3 * rs];
+  }
+}
+template <int KIND>
+__device__ __forceinline__ const float* cg_tfrag_ptr(const float* base, int rs, int l15, int slot) {
+  return KIND == 0 ? base + l15 * rs + 4 * slot : base + l15 + 4 * slot * rs;
+}
+
+#define CG_TAIL_PT 64                 // positions per tile
+#define CG_TAIL_PS (CG_TAIL_PT + 4)   // row stride of the [channel][position] images (== 4 mod 8)
+#define CG_TAIL_THREADS 256
+
+// per-channel constants of the forward chain of branch i, channel c, staged in LDS: [2C][8]
+//   0 mean_t  1 scale_t  2 beta_t  3 alpha_d  4 mean_p  5 rstd_p  6 gamma_p  7 beta_p
+__device__ __forceinline__ void cg_tail_consts(const CgDstdTail& t, float* sK, bool backward, bool owner) {
+  const int C = t.C;
+  const double cnt = (double)t.B * t.T * t.V;
+  for (int e = threadIdx.x; e < 2 * C; e += blockDim.x) {
+    const int i = e / C, c = e - i * C;
+    // train: F1 saved the tcn statistics; eval: F1 does not run, the running statistics are taken (and saved) here
+    const CgAff at = cg_tail_aff(t.bn_t[i], c, C, cnt, t.train, backward || t.train != 0, owner);
+    const CgAff ap = cg_tail_aff(t.bn_p[i], c, C, cnt, t.train, backward, owner);
+    float* k = sK + 8 * e;
+    k[0] = at.mean; k[1] = at.gamma * at.rstd; k[2] = at.beta; k[3] = t.alpha_d[i][0];
+    k[4] = ap.mean; k[5] = ap.rstd; k[6] = ap.gamma; k[7] = ap.beta;
+  }
+}
+
+// stage the activations of a tile: image[c2][p] for c2 in [0, 2C), p in [0, PT): what = 0: a = PReLU_p(BN_p(z)), 1: zhat
+__device__ __forceinline__ void cg_tail_stage_act(const CgDstdTail& t, const float* sK, unsigned long long seed, int b, int p0, int np,
+                                                  float* img, int what) {
+  const int C = t.C, P = t.T * t.V;
+  for (int e = threadIdx.x; e < 2 * C * CG_TAIL_PT; e += CG_TAIL_THREADS) {
+    const int c2 = e / CG_TAIL_PT, pp = e - c2 * CG_TAIL_PT;
+    float val = 0.f;
+    if (pp < np) {
+      const int i = c2 / C, c = c2 - i * C, p = p0 + pp;
+      const float* k = sK + 8 * c2;
+      const long long off = ((long long)b * C + c) * P + p;
+      const float keep = cg_tail_keep(t, i, seed, b, c, p);
+      const float u = ((t.y[i][off] - k[0]) * k[1] + k[2]) * keep + t.r[i][off];
+      const float z = t.w[i][(long long)b * C + c] * cg_prelu(u, k[3]);
+      if (what == 0) {
+        val = cg_prelu((z - k[4]) * (k[6] * k[5]) + k[7], t.alpha_p[i][0]);
+        if (t.tap_a[i]) t.tap_a[i][off] = val;
+        if (!t.train && t.tap_x[i]) t.tap_x[i][off] = cg_prelu(u, k[3]);       // eval: F1 does not run
+      }
+      else val = (z - k[4]) * k[5];                                    // zhat = (z - mean) * rstd
+    }
+    img[c2 * CG_TAIL_PS + pp] = val;
+  }
+}
+
+// ======================================================================================================================
+// F2: h0[b][co][p] = sum_c2 Wc[co][c2] a[c2][p]  + channel sums of h0.   Persistent workgroups over (sample, 64 positions)
+// ======================================================================================================================
+__global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTail t, int tiles_per_sample, int total, int per) {
+  const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
+  const int WS = C2M + 4;
+  float* sAct = reinterpret_cast<float*>(cg_dyn_lds);            // [C2M][PS]
+  float* sW = sAct + C2M * CG_TAIL_PS;                            // [CM][WS]
+  float* sK = sW + CM * WS;                                       // [2C][8]
+  double* sStat = reinterpret_cast<double*>(sK + 8 * C2M);        // [CM][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int wg = blockIdx.x;
+  if (wg * per >= total) return;
+  for (int e = tid; e < C2M * CG_TAIL_PS + CM * WS; e += CG_TAIL_THREADS) sAct[e] = 0.f;
+  for (int e = tid; e < 2 * CM; e += CG_TAIL_THREADS) sStat[e] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < C * C2; e += CG_TAIL_THREADS) { const int co = e / C2, c2 = e - co * C2; sW[co * WS + c2] = t.Wc[e]; }
+  cg_tail_consts(t, sK, false, wg == 0);
+  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const int MT = CM / 16;
+  for (int it = 0; it < per; ++it) {
+    const int lid = wg * per + it;
+    if (lid >= total) break;
+    const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
+    __syncthreads();
+    cg_tail_stage_act(t, sK, seed, b, p0, np, sAct, 0);
+    __syncthreads();
+    float* hb = t.h0 + (long long)b * C * P + p0;
+    for (int w = wave; w < MT * 2; w += CG_TAIL_THREADS / 64) {          // (co tile, pair of position tiles)
+      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * WS, WS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sAct + n0, CG_TAIL_PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sAct + n1, CG_TAIL_PS, l15, slot);
+      for (int k0 = 0; k0 < C2M; k0 += 16) {                              // rows >= 2C of sAct and columns >= 2C of sW are zero
+        float av[4], b0v[4], b1v[4];
+        cg_tfrag<0>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 16 * mt + 4 * slot + q;
+        const bool cok = co < C, ok0 = cok && n0 + l15 < np, ok1 = cok && n1 + l15 < np;
+        const float v0 = ok0 ? c0[q] : 0.f, v1 = ok1 ? c1[q] : 0.f;
+        if (ok0) hb[(long long)co * P + n0 + l15] = v0;
+        if (ok1) hb[(long long)co * P + n1 + l15] = v1;
+        if (t.train) {
+          float s1 = v0 + v1, s2 = v0 * v0 + v1 * v1;
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+          if (l15 == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
+        }
+      }
+    }
+  }
+  if (t.train) {
+    __syncthreads();
+    double* rep = t.bn_c.stats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * C;
+    for (int e = tid; e < 2 * C; e += CG_TAIL_THREADS) atomicAdd(&rep[e], sStat[e]);
+  }
+}
+
+// ======================================================================================================================
+// F3: pooled[b,c] = mean_p PReLU_c(BN_c(h0))     one workgroup per (c, b) row
+// F4: out = h * gate[b,c] + bres   (+ channel sums of out)
+// ======================================================================================================================
+__global__ void cg_tail_f3_kernel(CgDstdTail t) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, (double)t.B * P, t.train, false, b == 0 && threadIdx.x == 0);
+  const float alpha = t.alpha_c[0];
+  const float* __restrict__ h0 = t.h0 + ((long long)b * t.C + c) * P;
+  double s = 0.0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) s += (double)cg_prelu(cg_bn(ac, h0[p]), alpha);
+  s = cg_block_sum(s, red);
+  if (threadIdx.x == 0) t.pooled[(long long)b * t.C + c] = (float)(s / (double)P);
+}
+
+__global__ void cg_tail_f4_kernel(CgDstdTail t, int rb) {
+  __shared__ double red[32];
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (b0 >= t.B) return;
+  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, (double)t.B * P, t.train, true, false);      // saved by F3
+  const float alpha = t.alpha_c[0];
+  double s = 0.0, q = 0.0;
+  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
+    const int br = e / P, p = e - br * P, b = b0 + br;
+    const long long off = ((long long)b * t.C + c) * P + p;
+    const float h = cg_prelu(cg_bn(ac, t.h0[off]), alpha);
+    if (t.tap_h) t.tap_h[off] = h;
+    const float v = h * t.gate[(long long)b * t.C + c] + t.bres[off];
+    t.out[off] = v;
+    s += (double)v; q += (double)v * (double)v;
+  }
+  if (t.ostats) {
+    s = cg_block_sum(s, red);
+    q = cg_block_sum(q, red + 16);
+    if (threadIdx.x == 0) {
+      double* rep = t.ostats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * t.C;
+      atomicAdd(&rep[2 * c], s); atomicAdd(&rep[2 * c + 1], q);
+    }
+  }
+}
+
+// ======================================================================================================================
+// backward
+// ======================================================================================================================
+// K1: dgate[b,c] = sum_p dout * h
+__global__ void cg_tail_k1_kernel(CgDstdTail t) {
+  __shared__ double red[16];
+  const int c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, 0.0, t.train, true, false);
+  const float alpha = t.alpha_c[0];
+  const long long base = ((long long)b * t.C + c) * P;
+  double s = 0.0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) s += (double)t.dout[base + p] * (double)cg_prelu(cg_bn(ac, t.h0[base + p]), alpha);
+  s = cg_block_sum(s, red);
+  if (threadIdx.x == 0) t.dgate[(long long)b * t.C + c] = (float)s;
+}
+
+// gradient in front of the compressor's PReLU for one element: g_c = (dout * gate + dpooled / P) * PReLU_c'(u); returns g_c, u
+__device__ __forceinline__ float cg_tail_gc(const CgDstdTail& t, const CgAff& ac, float alpha, long long off, int b, int c, float invP, float& u) {
+  u = cg_bn(ac, t.h0[off]);
+  const float dh = t.dout[off] * t.gate[(long long)b * t.C + c] + t.dpooled[(long long)b * t.C + c] * invP;
+  return u > 0.f ? dh : alpha * dh;
+}
+
+// K2: red_c[c] = { sum g_c, sum g_c * h0hat }, red_c[2C] += sum_{u <= 0} dh * u   (d alpha_c)
+__global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
+  __shared__ double red[48];
+  const int c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (b0 >= t.B) return;
+  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, 0.0, t.train, true, false);
+  const float alpha = t.alpha_c[0], invP = 1.f / (float)P;
+  double s1 = 0.0, s2 = 0.0, sa = 0.0;
+  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
+    const int br = e / P, p = e - br * P, b = b0 + br;
+    const long long off = ((long long)b * t.C + c) * P + p;
+    float u;
+    const float g = cg_tail_gc(t, ac, alpha, off, b, c, invP, u);
+    s1 += (double)g;
+    s2 += (double)g * (double)((t.h0[off] - ac.mean) * ac.rstd);
+    if (!(u > 0.f)) sa += (double)(t.dout[off] * t.gate[(long long)b * t.C + c] + t.dpooled[(long long)b * t.C + c] * invP) * (double)u;
+  }
+  s1 = cg_block_sum(s1, red); s2 = cg_block_sum(s2, red + 16); sa = cg_block_sum(sa, red + 32);
+  if (threadIdx.x == 0) {
+    atomicAdd(&t.red_c[2 * c], s1); atomicAdd(&t.red_c[2 * c + 1], s2); atomicAdd(&t.red_c[2 * t.C], sa);
+  }
+}
+
+// K3: per tile: dh0 (BatchNorm backward of g_c), d a = Wc^T dh0, dWc += dh0 a^T, g_p = d a * PReLU_p' -> HBM + its sums
+__global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTail t, int tiles_per_sample, int total, int per, int replicas) {
+  const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
+  const int WS = C2M + 4;
+  float* sZ = reinterpret_cast<float*>(cg_dyn_lds);              // [C2M][PS]  zhat of both branches
+  float* sDH = sZ + C2M * CG_TAIL_PS;                             // [CM][PS]   dh0
+  float* sW = sDH + CM * CG_TAIL_PS;                              // [CM][WS]
+  float* sK = sW + CM * WS;                                       // [2C][8]
+  double* sRed = reinterpret_cast<double*>(sK + 8 * C2M);         // [C2M][2] sums of g_p, g_p * zhat ; then [2] d alpha_p
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_TAIL_THREADS / 64;
+  const int wg = blockIdx.x;
+  if (wg * per >= total) return;
+  for (int e = tid; e < C2M * CG_TAIL_PS + CM * CG_TAIL_PS + CM * WS; e += CG_TAIL_THREADS) sZ[e] = 0.f;
+  for (int e = tid; e < 2 * C2M + 2; e += CG_TAIL_THREADS) sRed[e] = 0.0;
+  __syncthreads();
+  for (int e = tid; e < C * C2; e += CG_TAIL_THREADS) { const int co = e / C2, c2 = e - co * C2; sW[co * WS + c2] = t.Wc[e]; }
+  cg_tail_consts(t, sK, true, false);
+  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const int MT = CM / 16, NT2 = C2M / 16;
+  const double cnt = (double)t.B * P;
+  const float invP = 1.f / (float)P;
+  // dWc accumulators: tile (mt, n2) for id = u * nw + wave, kept in registers across all tiles of this workgroup
+  cg_f32x4 wacc[CG_TAIL_MAXW];
+#pragma unroll
+  for (int u = 0; u < CG_TAIL_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const float alpha_c = t.alpha_c[0];
+
+  for (int it = 0; it < per; ++it) {
+    const int lid = wg * per + it;
+    if (lid >= total) break;
+    const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
+    __syncthreads();
+    cg_tail_stage_act(t, sK, seed, b, p0, np, sZ, 1);
+    for (int e = tid; e < C * CG_TAIL_PT; e += CG_TAIL_THREADS) {       // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat))
+      const int c = e / CG_TAIL_PT, pp = e - c * CG_TAIL_PT;
+      float val = 0.f;
+      if (pp < np) {
+        const CgAff ac = cg_tail_aff(t.bn_c, c, C, 0.0, t.train, true, false);
+        const long long off = ((long long)b * C + c) * P + p0 + pp;
+        float u;
+        const float g = cg_tail_gc(t, ac, alpha_c, off, b, c, invP, u);
+        if (t.train) {
+          const float m1 = (float)(t.red_c[2 * c] / cnt), m2 = (float)(t.red_c[2 * c + 1] / cnt);
+          val = ac.gamma * ac.rstd * (g - m1 - (t.h0[off] - ac.mean) * ac.rstd * m2);
+        } else val = g * ac.gamma * ac.rstd;
+      }
+      sDH[c * CG_TAIL_PS + pp] = val;
+    }
+    __syncthreads();
+    // dWc[co][c2] += sum_p dh0[co][p] a[c2][p],  a = PReLU_p(gamma zhat + beta) rebuilt from zhat in the B fragments
+#pragma unroll
+    for (int u = 0; u < CG_TAIL_MAXW; ++u) {
+      const int id = u * nw + wave;
+      if (id < MT * NT2) {
+        const int mt = id / NT2, n2 = id - mt * NT2, c2 = 16 * n2 + l15;
+        const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
+        const bool cok = c2 < C2;
+        const float gam = cok ? t.bn_p[i].gamma[c] : 0.f, bet = cok ? t.bn_p[i].beta[c] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        const float* ap = cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS, CG_TAIL_PS, l15, slot);
+        const float* bp = cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS, CG_TAIL_PS, l15, slot);
+        for (int k0 = 0; k0 < CG_TAIL_PT; k0 += 16) {
+          float av[4], bv[4];
+          cg_tfrag<0>(ap, CG_TAIL_PS, k0, av); cg_tfrag<0>(bp, CG_TAIL_PS, k0, bv);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            // positions >= np hold zhat = 0 but a = PReLU(beta) != 0 there; dh0 is zero at those positions, so the product vanishes
+            const float a = cg_prelu(gam * bv[s] + bet, alp);
+            wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], a, wacc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat
+    for (int w = wave; w < NT2 * 2; w += nw) {
+      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, WS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sDH + n0, CG_TAIL_PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sDH + n1, CG_TAIL_PS, l15, slot);
+      for (int k0 = 0; k0 < CM; k0 += 16) {
+        float av[4], b0v[4], b1v[4];
+        cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c2 = 16 * mt + 4 * slot + q;
+        const bool cok = c2 < C2;
+        const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
+        const float gam = cok ? t.bn_p[i].gamma[c] : 0.f, bet = cok ? t.bn_p[i].beta[c] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        float s1 = 0.f, s2 = 0.f, sa = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pp = (h ? n1 : n0) + l15;
+          const float da = h ? c1[q] : c0[q];
+          if (cok && pp < np) {
+            const float zh = sZ[c2 * CG_TAIL_PS + pp], v = gam * zh + bet;
+            const float g = v > 0.f ? da : alp * da;
+            t.gp[i][((long long)b * C + c) * P + p0 + pp] = g;
+            s1 += g; s2 += g * zh;
+            if (!(v > 0.f)) sa += da * v;
+          }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); sa += __shfl_xor(sa, off, 64); }
+        if (l15 == 0 && cok) {
+          atomicAdd(&sRed[2 * c2], (double)s1); atomicAdd(&sRed[2 * c2 + 1], (double)s2); atomicAdd(&sRed[2 * C2M + i], (double)sa);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 2 * C2; e += CG_TAIL_THREADS) {
+    const int c2 = e >> 1, i = c2 >= C ? 1 : 0, c = c2 - i * C;
+    atomicAdd(&t.red_p[i][2 * c + (e & 1)], sRed[e]);
+  }
+  if (tid < 2) atomicAdd(&t.red_p[tid][2 * C], sRed[2 * C2M + tid]);
+  float* dW = t.dWc_ws + (long long)(blockIdx.x % replicas) * C * C2;
+#pragma unroll
+  for (int u = 0; u < CG_TAIL_MAXW; ++u) {
+    const int id = u * nw + wave;
+    if (id < MT * NT2) {
+      const int mt = id / NT2, n2 = id - mt * NT2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 16 * mt + 4 * slot + q, c2 = 16 * n2 + l15;
+        if (co < C && c2 < C2) atomicAdd(&dW[co * C2 + c2], wacc[u][q]);
+      }
+    }
+  }
+}
+
+// K4: dz = BN_p'(g_p); dw[b,c] = sum_p dz * x; g_d = w * dz * PReLU_d'(u) -> dr (HBM); sums of g_t = g_d * keep for the tcn BatchNorm
+__global__ void cg_tail_k4_kernel(CgDstdTail t) {
+  __shared__ double red[64];
+  const int i = blockIdx.z, c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
+  const double cnt = (double)t.B * P;
+  const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, 0.0, t.train, true, false);
+  const CgAff ap = cg_tail_aff(t.bn_p[i], c, t.C, 0.0, t.train, true, false);
+  const float ad = t.alpha_d[i][0], wv = t.w[i][(long long)b * t.C + c];
+  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  float m1 = 0.f, m2 = 0.f;
+  if (t.train) { m1 = (float)(t.red_p[i][2 * c] / cnt); m2 = (float)(t.red_p[i][2 * c + 1] / cnt); }
+  const long long base = ((long long)b * t.C + c) * P;
+  double sw = 0.0, s1 = 0.0, s2 = 0.0, sa = 0.0;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    const float keep = cg_tail_keep(t, i, seed, b, c, p);
+    float u;
+    const float yv = t.y[i][base + p];
+    const float x = cg_tail_x(at, ad, yv, t.r[i][base + p], keep, u);
+    const float z = wv * x;
+    const float g = t.gp[i][base + p];
+    const float dz = t.train ? ap.gamma * ap.rstd * (g - m1 - (z - ap.mean) * ap.rstd * m2) : g * ap.gamma * ap.rstd;
+    sw += (double)dz * (double)x;
+    const float dx = wv * dz;
+    const float gd = u > 0.f ? dx : ad * dx;
+    t.dr[i][base + p] = gd;
+    if (!(u > 0.f)) sa += (double)dx * (double)u;
+    const float gt = gd * keep;
+    s1 += (double)gt; s2 += (double)gt * (double)((yv - at.mean) * at.rstd);
+  }
+  sw = cg_block_sum(sw, red); s1 = cg_block_sum(s1, red + 16); s2 = cg_block_sum(s2, red + 32); sa = cg_block_sum(sa, red + 48);
+  if (threadIdx.x == 0) {
+    t.dw[i][(long long)b * t.C + c] = (float)sw;
+    atomicAdd(&t.red_t[i][2 * c], s1); atomicAdd(&t.red_t[i][2 * c + 1], s2); atomicAdd(&t.red_t[i][2 * t.C], sa);
+  }
+}
+
+// K5: dy = BN_t'(g_d * keep); also the per-channel parameter gradients of all three BatchNorm levels and the PReLU slopes
+__global__ void cg_tail_k5_kernel(CgDstdTail t, int rb) {
+  const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb;
+  if (b0 >= t.B) return;
+  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const double cnt = (double)t.B * P;
+  const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, 0.0, t.train, true, false);
+  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  float m1 = 0.f, m2 = 0.f;
+  if (t.train) { m1 = (float)(t.red_t[i][2 * c] / cnt); m2 = (float)(t.red_t[i][2 * c + 1] / cnt); }
+  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
+    const int br = e / P, p = e - br * P, b = b0 + br;
+    const long long off = ((long long)b * t.C + c) * P + p;
+    const float gt = t.dr[i][off] * cg_tail_keep(t, i, seed, b, c, p);
+    t.dy[i][off] = t.train ? at.gamma * at.rstd * (gt - m1 - (t.y[i][off] - at.mean) * at.rstd * m2) : gt * at.gamma * at.rstd;
+  }
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    t.dgamma_t[i][c] = (float)t.red_t[i][2 * c + 1]; t.dbeta_t[i][c] = (float)t.red_t[i][2 * c];
+    t.dgamma_p[i][c] = (float)t.red_p[i][2 * c + 1]; t.dbeta_p[i][c] = (float)t.red_p[i][2 * c];
+    if (i == 0) { t.dgamma_c[c] = (float)t.red_c[2 * c + 1]; t.dbeta_c[c] = (float)t.red_c[2 * c]; }
+    if (c == 0) {
+      t.dalpha_d[i][0] = (float)t.red_t[i][2 * t.C]; t.dalpha_p[i][0] = (float)t.red_p[i][2 * t.C];
+      if (i == 0) t.dalpha_c[0] = (float)t.red_c[2 * t.C];
+    }
+  }
+}
+
+__global__ void cg_tail_fold_kernel(const float* __restrict__ ws, int replicas, int n, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < replicas; ++r) s += ws[(long long)r * n + i];
+  dW[i] = s;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+#define CG_TAIL_REPLICAS 16
+
+static int cg_tail_check(const CgDstdTail* t) {
+  if (!t) return CG_EARG;
+  if (t->B <= 0 || t->C <= 0 || t->T <= 0 || t->V <= 0 || t->C > 64) return CG_ESHAPE;
+  for (int i = 0; i < 2; ++i)
+    if (!t->y[i] || !t->r[i] || !t->w[i] || !t->alpha_d[i] || !t->alpha_p[i] || !t->bn_t[i].gamma || !t->bn_p[i].gamma || !t->bn_t[i].save ||
+        !t->bn_p[i].save) return CG_EARG;
+  if (!t->Wc || !t->bn_c.gamma || !t->bn_c.save || !t->alpha_c || !t->h0) return CG_EARG;
+  if (t->train && t->drop_p > 0.f && !t->seed) return CG_EARG;
+  if (t->B > 65535) return CG_ESHAPE;
+  return CG_OK;
+}
+
+extern "C" long long cg_dstd_tail_ws_floats(int C) { return (long long)CG_TAIL_REPLICAS * C * 2 * C; }
+
+static size_t cg_tail_gemm_lds(int C, bool bwd) {
+  const int CM = (C + 15) & ~15, C2M = (2 * C + 15) & ~15, WS = C2M + 4;
+  size_t f = (size_t)C2M * CG_TAIL_PS + (size_t)CM * WS + (size_t)8 * C2M;
+  if (bwd) f += (size_t)CM * CG_TAIL_PS;
+  return f * sizeof(float) + (bwd ? (size_t)(2 * C2M + 2) : (size_t)2 * CM) * sizeof(double) + 16;
+}
+
+// include/cistgcn_hip.h : cg_dstd_tail_fwd (phases 1..4) / cg_dstd_tail_bwd (phases 1..5)
+extern "C" int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream_) {
+  int st = cg_tail_check(t);
+  if (st != CG_OK) return st;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int P = t->T * t->V;
+  const int rb = cg_tail_rows(t->B, t->C, P);
+  const dim3 rows((unsigned)t->C, (unsigned)((t->B + rb - 1) / rb), 1);
+  if (phase == 1) {
+    if (!t->train) return CG_OK;                      // eval: running statistics, nothing to reduce
+    if (!t->bn_t[0].stats || !t->bn_t[1].stats || !t->bn_p[0].stats || !t->bn_p[1].stats) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_f1_kernel, dim3(rows.x, rows.y, 2), dim3(256), 0, stream, *t, rb);
+  } else if (phase == 2) {
+    if (t->train && (!t->bn_p[0].stats || !t->bn_p[1].stats || !t->bn_c.stats)) return CG_EARG;
+    const int tps = (P + CG_TAIL_PT - 1) / CG_TAIL_PT, total = t->B * tps;
+    const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
+    const size_t lds = cg_tail_gemm_lds(t->C, false);
+    hipError_t e = hipFuncSetAttribute((const void*)cg_tail_f2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cg_tail_f2_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per);
+  } else if (phase == 3) {
+    if (!t->pooled || (t->train && !t->bn_c.stats)) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_f3_kernel, dim3((unsigned)t->C, (unsigned)t->B), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+  } else if (phase == 4) {
+    if (!t->gate || !t->bres || !t->out) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_f4_kernel, rows, dim3(256), 0, stream, *t, rb);
+  } else return CG_EARG;
+  return cg_launch_status();
+}
+
+extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
+  int st = cg_tail_check(t);
+  if (st != CG_OK) return st;
+  if (!t->dout || !t->gate) return CG_EARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int P = t->T * t->V, C = t->C;
+  const int rb = cg_tail_rows(t->B, C, P);
+  const dim3 rows((unsigned)C, (unsigned)((t->B + rb - 1) / rb), 1);
+  if (phase == 1) {
+    if (!t->dgate) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_k1_kernel, dim3((unsigned)C, (unsigned)t->B), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+  } else if (phase == 2) {
+    if (!t->dpooled || !t->red_c) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_k2_kernel, rows, dim3(256), 0, stream, *t, rb);
+  } else if (phase == 3) {
+    if (!t->dpooled || !t->red_c || !t->gp[0] || !t->gp[1] || !t->red_p[0] || !t->red_p[1] || !t->dWc_ws || !t->dWc) return CG_EARG;
+    const int tps = (P + CG_TAIL_PT - 1) / CG_TAIL_PT, total = t->B * tps;
+    const int per = (total + 255) / 256, nwg = (total + per - 1) / per;
+    const size_t lds = cg_tail_gemm_lds(C, true);
+    hipError_t e = hipFuncSetAttribute((const void*)cg_tail_k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cg_tail_k3_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per, CG_TAIL_REPLICAS);
+    st = cg_launch_status();
+    if (st != CG_OK) return st;
+    const int n = C * 2 * C;
+    hipLaunchKernelGGL(cg_tail_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t->dWc_ws, CG_TAIL_REPLICAS, n, t->dWc);
+  } else if (phase == 4) {
+    if (!t->gp[0] || !t->gp[1] || !t->dr[0] || !t->dr[1] || !t->dw[0] || !t->dw[1] || !t->red_t[0] || !t->red_t[1] || !t->red_p[0]) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_k4_kernel, dim3((unsigned)C, (unsigned)t->B, 2), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+  } else if (phase == 5) {
+    if (!t->dy[0] || !t->dy[1] || !t->dr[0] || !t->dr[1] || !t->red_t[0] || !t->red_t[1] || !t->dgamma_t[0] || !t->dgamma_p[0] || !t->dgamma_c) return CG_EARG;
+    hipLaunchKernelGGL(cg_tail_k5_kernel, dim3(rows.x, rows.y, 2), dim3(256), 0, stream, *t, rb);
+  } else return CG_EARG;
+  return cg_launch_status();
+}

@@ -12,10 +12,13 @@ struct CgDomM {
   int Js, RS;                // column stride of a group inside a row of the [channel][position] images, row stride (== 4 mod 8)
   int Jr, Jsa;               // adjacency slab: rows per group (J up to 16), row stride (Jr + 4)
   int CiM, CoM, WS;          // channels up to 16, row stride of the weight image
-  unsigned magicJ, magicGT;  // ceil(2^32 / d) for the index divisions by J and GT
+  int dbg, w_global;         // (unused) | 1: the backward's dG product reads W from HBM/L2 instead of an LDS image
+  unsigned magicJ, magicGT, magicJs, magicRun, magicNP, magicMTi, magicNT, magicNPp;  // ceil(2^32 / d) for the index divisions by J, GT and Js (0: d = 1)
 };
 
-int cg_domm_geom(CgDomM& g, int B, int Cin, int Cout, int T, int V, int domain);
-size_t cg_domm_lds_bytes(const CgDomM& g);
+int cg_domm_geom(CgDomM& g, int B, int Cin, int Cout, int T, int V, int domain, bool bwd);
+size_t cg_domm_lds_bytes(const CgDomM& g, bool bwd);
 int cg_domm_bwd_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
                        int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);
+int cg_domm_fwd_launch(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
+                       int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);

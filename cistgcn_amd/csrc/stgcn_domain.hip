@@ -592,6 +592,14 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
+  // wide layers: both products on the matrix cores with the shared staging of stgcn_domain_mfma.hip (CG_DOM_FWD_OLD=1: the
+  // first-generation kernels below, kept for A/B runs)
+  // (measured at 64->64, B=256, T=50, V=22: time domain 146 vs 173 us; in the space domain both generations sit at ~280 us,
+  // bound by the 4-byte-column accesses of x and y - DESIGN.md section 4 - so the first-generation kernel stays there)
+  if ((Cin >= 16 || Cout >= 16) && domain == 1 && V <= 64 && getenv("CG_DOM_FWD_OLD") == nullptr) {
+    st = cg_domm_fwd_launch(x, adj, W, bias, y, ystats, B, Cin, Cout, T, V, domain, (hipStream_t)stream_);
+    if (st != CG_ESHAPE) return st;
+  }
   // matrix cores pay off in the time domain (164 vs 243 us at C=64, B=256); in the space domain the kernel is bound by
   // its 4-byte-column accesses, the MFMA variant is no faster there and measured 1.7x the HBM write traffic (PMC)
   const bool mfma = Cin >= 16 && Cout >= 16 && domain == 1 && getenv("CG_DOM_NO_MFMA") == nullptr;

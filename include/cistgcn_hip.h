@@ -185,6 +185,48 @@ int cg_stgcn_domain_bwd(const float* x, const float* adj, const float* W, const 
                         float* dW, float* dbias, float* ws, int B, int Cin, int Cout, int T, int V, int domain,
                         int ws_prezeroed, void* stream);
 
+/* ---- tail of a DSTD_GC block as phase kernels (SURVEY 8b `dstd_combine`) ------------------------------------------------
+ * CISTGCN.py:266-269 (`tcn` BatchNorm + Dropout + residual + PReLU of both Domain_GCNN layers), :388 (PReLU(BN(w * x)) of both
+ * branches + cat), :305-309 (compressor 1x1 conv + BN + PReLU + SELayer2d), :390 (block residual).  In train mode every
+ * BatchNorm needs the batch statistics of its input first, so the chain is cut at those barriers and nowhere else:
+ *   forward  phase 1: sums of z_i = w_i * PReLU(Dropout(BN(y_i)) + r_i) | 2: h0 = Wc [a_1; a_2] on the matrix cores, a_i =
+ *            PReLU(BN(z_i)) rebuilt per tile, + sums of h0 | 3: pooled = mean PReLU(BN(h0)) | (cg_se_gate_fwd) | 4: out = h * gate
+ *            + block residual (+ sums of out for the next block's BatchNorm);
+ *   backward phase 1: dgate | (cg_se_gate_bwd) | 2: sums at the compressor BatchNorm | 3: dh0, d a = Wc^T dh0, dWc on the matrix
+ *            cores, gradient in front of prelu1/2 + its sums | 4: gate gradients dw, gradient of the residual addends, sums of
+ *            the tcn BatchNorm | 5: dy_i and every per-channel parameter gradient.
+ * All tensors contiguous (B,C,T,V) / (B,C); C <= 64.  `stats` / `red_*` / `dWc_ws` are zeroed by the caller (slices of the
+ * per-step arenas); BatchNorm bookkeeping (save mean / rstd, running statistics) as cg_norm_act. */
+typedef struct CgTailBN {
+  double* stats;                 /* [CG_STAT_REPLICAS][C][2] sums of this BatchNorm's input (train mode) */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float momentum, eps;
+  float* save;                   /* [2][C] mean, rstd used by the forward */
+} CgTailBN;
+typedef struct CgDstdTail {
+  int B, C, T, V, train, pad0;
+  const float* y[2]; const float* r[2]; const float* w[2];
+  CgTailBN bn_t[2]; const float* alpha_d[2];
+  CgTailBN bn_p[2]; const float* alpha_p[2];
+  const float* Wc; CgTailBN bn_c; const float* alpha_c;
+  const float* gate; const float* bres;
+  float drop_p; unsigned int salt[2]; int pad1; const unsigned long long* seed;
+  float* h0; float* pooled; float* out; double* ostats;
+  float* tap_x[2]; float* tap_a[2]; float* tap_h;      /* optional: outputs of the five PReLUs (diagnostics) */
+  const float* dout; const float* dpooled; float* dgate;
+  double* red_c;
+  float* gp[2]; double* red_p[2];
+  float* dWc_ws; float* dWc;
+  float* dr[2]; float* dw[2]; double* red_t[2]; float* dy[2];
+  float* dgamma_t[2]; float* dbeta_t[2]; float* dalpha_d[2];
+  float* dgamma_p[2]; float* dbeta_p[2]; float* dalpha_p[2];
+  float* dgamma_c; float* dbeta_c; float* dalpha_c;
+} CgDstdTail;
+int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream);
+int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream);
+long long cg_dstd_tail_ws_floats(int C);
+
 /* ---- evaluation harness counterpart, environment/test.py:97-132 ----------------------
  * y[r,k,:] = x[r,idx[k],:] : `inputs[:, :, dim_used]` (32 -> 22 joints); x (rows,Jin,3), y (rows,Jout,3) contiguous */
 int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long rows, int Jin, int Jout, void* stream);
@@ -193,6 +235,16 @@ int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long row
  * pred (B,To,J22,3), target/out (B,To,J32,3); src[j] = prediction joint taken by skeleton joint j, or -1 (ground truth kept) */
 int cg_eval_scatter_mpjpe(const float* pred, const float* target, float* out, float* frame_err, const int32_t* src,
                           int B, int To, int J32, int J22, void* stream);
+
+/* ---- on-device input pipeline -----------------------------------------------------------------
+ * The training augmentations of environment/custom_transforms.py (RandomFlip :243-298, RandomRotation :10-84, RandomScale
+ * :87-161, RandomTranslation :164-240; order of loaders/loader.py:42-130) and the per-item tensors of
+ * loaders/h36m_motion_3d.py:94-108 for a whole batch in one launch.  raw (B,L,J,3); params (B,20) = per sequence
+ * [flip x,y,z | rotate? | R 3x3 row-major (p' = (p-c) R + c) | scale x,y,z | translation rate x,y,z | pad], drawn on the host
+ * in the reference's order; outputs sample (B,input_n,J,3), target (B,L-input_n,J,3), target_vel (same shape, cumulative
+ * frame differences from frame input_n-1 on), target_gvel (B,L-input_n,J,1) cumulative speeds, processed (B,L,J,3) or NULL. */
+int cg_augment_sequences(const float* raw, const float* params, float* sample, float* target, float* target_vel,
+                         float* target_gvel, float* processed, int B, int L, int J, int input_n, void* stream);
 
 /* ---- optimizer on the flat parameter buffer -----------------------------------
  * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,

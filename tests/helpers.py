@@ -8,7 +8,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # model fixtures (tools/gen_golden.py); eval_*.npz belong to the evaluation-harness counterpart (tools/gen_golden_eval.py)
-CASES = sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith("eval_"))
+CASES = sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("eval_", "aug_")))
 
 
 def make_cfg(C, T, V, dropout=0.0, To=25, hidden=64, interp=(True,) * 5, interp_o=(True,)):

@@ -34,7 +34,7 @@ struct State {
   Barrier block_barrier;
   Barrier wave_barrier[kMaxThreads / 64];
   std::mutex m;
-  std::condition_variable cv_start, cv_done;
+  std::condition_variable cv_start[kMaxThreads / 64], cv_done;      // one start signal per wave: a 64-thread block wakes 64 workers
   std::vector<std::thread> pool;
   std::mutex launch_mutex;
 };
@@ -56,9 +56,8 @@ void worker(int id) {
   for (;;) {
     {
       std::unique_lock<std::mutex> lk(g_m);
-      g_cv_start.wait(lk, [&] { return g_job != seen; });
+      g_cv_start[id / 64].wait(lk, [&] { return g_job != seen && id < g_active; });
       seen = g_job;
-      if (id >= g_active) continue;
     }
     threadIdx = dim3((unsigned)id, 0, 0);
     (*g_body)();
@@ -88,7 +87,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
         blockIdx = dim3(bx, by, bz);
         std::unique_lock<std::mutex> lk(g_m);
         g_body = &body; g_active = n; g_done = 0; ++g_job;
-        g_cv_start.notify_all();
+        for (int w = 0; w * 64 < n; ++w) g_cv_start[w].notify_all();
         g_cv_done.wait(lk, [&] { return g_done == n; });
       }
 }

@@ -62,9 +62,11 @@ def test_gradients_as_accurate_as_cpu_fp32(cfg, mode):
 def test_every_gradient_within_1e4_on_the_same_branches(cfg, mode):
     """north_star tolerance (1e-4) on all 698 parameter gradients with the real PReLU slopes: the oracle replays the
     branches the HIP run took, so a rounding-sized pre-activation landing on the other side of 0 cannot hide (or fake)
-    an error.  floor 0.25: four times tighter than `1e-4 * max(1, max|ref|)`."""
+    an error.  Bound: `1e-4 * max(floor, max|ref|)` per tensor with floor 0.25 in eval mode and 1 (the north_star form) in train
+    mode: batch-statistic BatchNorm over 4..16 samples amplifies fp32 rounding, the reference's own fp32 CPU path differs from
+    its fp64 self by 1.4e-4 * max(0.25, max|ref|) on the (32, 50, 25, 4) case with the branches pinned."""
     C, T, V, B = cfg
-    r = checks.check_model_branch_replay("cuda", C, T, V, B, mode, grad_floor=0.25)
+    r = checks.check_model_branch_replay("cuda", C, T, V, B, mode, grad_floor=0.25 if mode == "eval" else 1.0)
     print("branch replay %s %s: %s" % (cfg, mode, r))
 
 
@@ -73,7 +75,7 @@ def test_non_interpretable_layers_at_model_level(mode):
     """`interpretable: false` (CISTGCN.py:104-120, never selected by the shipped YAMLs): batch-shared adjacency parameter
     `gcn.A`, no Map2Adj; mixed with interpretable blocks as the per-layer flag list allows."""
     interp, interp_o = (False, True, False, True, False), (False,)
-    r = checks.check_model_branch_replay("cuda", 8, 10, 22, 6, mode, grad_floor=0.25, interp=interp, interp_o=interp_o)
+    r = checks.check_model_branch_replay("cuda", 8, 10, 22, 6, mode, grad_floor=0.25 if mode == "eval" else 1.0, interp=interp, interp_o=interp_o)
     net, _ = checks.build_pair(8, 10, 22, "cpu", interp=interp, interp_o=interp_o)
     assert "st_gcnns.0.dsgn.gcn.A" in dict(net.named_parameters()) and "st_gcnns.1.dsgn.gcn.A" not in dict(net.named_parameters())
     print("non-interpretable %s: %s" % (mode, r))
@@ -353,23 +355,47 @@ def test_rccl_single_rank_allreduce_runs():
         dist.destroy_process_group()
 
 
-def test_every_kernel_of_a_replayed_step_is_ours():
-    """One replay of the captured training step (plus the flat gradient gather) under the profiler: every device kernel comes
-    from libcistgcn_hip.so (names cg_*) - no stock aten / rocclr kernels in the step."""
+def test_every_kernel_of_a_step_is_ours():
+    """One training step (forward + MPJPE + backward: the launches the HIP graph captures) under the profiler: every device
+    kernel comes from libcistgcn_hip.so (names cg_*) - no stock aten / rocclr kernels, no device memcpy / memset.  (A graph
+    replay shows up as one opaque event, so the same launches are traced eagerly; the flat gradient gather that follows the
+    graph is cg_multi_copy, its pointer table is uploaded once per capture.)"""
     from torch.profiler import ProfilerActivity, profile
-    from cistgcn_amd.runtime import FlatGrads, GraphedStep
+    from cistgcn_amd.runtime import EagerStep, FlatGrads
     net, _ = checks.build_pair(8, 10, 22, "cuda")
     net.train()
     g = torch.Generator().manual_seed(5)
     x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
     tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
-    step = GraphedStep(net, x, tgt, warmup=2, flat=FlatGrads(net.parameters(), "cuda"))
-    step.replay()
+    step = EagerStep(net, x, tgt)
+    for _ in range(2):
+        step.replay()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
         step.replay()
         torch.cuda.synchronize()
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-    foreign = sorted({n[:80] for n in names if "cg_" not in n[:48] and "Memcpy" not in n and "Memset" not in n})
-    assert len(names) > 50, "the profiler saw only %d kernels" % len(names)
-    assert not foreign, "kernels from outside the library in the captured step: %s" % foreign
+    foreign = sorted({n[:80] for n in names if "cg_" not in n[:48]})
+    assert len(names) > 200, "the profiler saw only %d kernels" % len(names)
+    assert not foreign, "device work from outside the library in the training step: %s" % foreign
+
+
+def test_device_input_pipeline_matches_reference():
+    """SURVEY 8f rank 4 on the MI355X: the augmentation kernel against the vectors of the reference's own transform classes
+    (recorded draws), against the oracle at the 50->25 / 25-joint size, and the prefetcher (pinned staging + side stream)."""
+    import numpy as np
+    import test_environment as te
+    from cistgcn_amd.environment import DeviceAugmentation, DevicePrefetcher
+    te.check_augmentation_golden("cuda")
+    te.check_augmentation_vs_oracle("cuda", B=64, L=75, J=25, input_n=50)
+    te.check_augmentation_vs_oracle("cuda", B=5, L=35, J=18, input_n=10, seed=12)
+    aug = DeviceAugmentation(te._aug_cfg())
+    g = np.random.RandomState(3)
+    batches = [(50 + 350 * g.randn(16, 35, 22, 3)).astype(np.float32) for _ in range(5)]
+    np.random.seed(77)
+    got = [{k: v.clone() for k, v in b.items()} for b in DevicePrefetcher(batches, aug, input_n=10, device="cuda")]
+    torch.cuda.synchronize()
+    np.random.seed(77)
+    for raw, out in zip(batches, got):                       # same draws, no overlap: must be identical
+        ref = aug(torch.from_numpy(raw).cuda(), 10)
+        assert all(torch.equal(out[k], ref[k]) for k in ref)
