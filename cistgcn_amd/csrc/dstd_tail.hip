@@ -139,6 +139,8 @@ __device__ __forceinline__ const float* cg_tfrag_ptr(const float* base, int rs, 
 #define CG_TAIL_PT 64                 // positions per tile
 #define CG_TAIL_PS (CG_TAIL_PT + 4)   // row stride of the [channel][position] images (== 4 mod 8)
 #define CG_TAIL_THREADS 256
+#define CG_TAIL_PT3 32                // positions per tile of the backward GEMM phase (two workgroups per CU)
+#define CG_TAIL_PS3 (CG_TAIL_PT3 + 4)
 
 // per-channel constants of the forward chain of branch i, channel c, staged in LDS: [2C][8]
 //   0 mean_t  1 scale_t  2 beta_t  3 alpha_d  4 mean_p  5 rstd_p  6 gamma_p  7 beta_p
@@ -156,12 +158,109 @@ __device__ __forceinline__ void cg_tail_consts(const CgDstdTail& t, float* sK, b
   }
 }
 
-// stage the activations of a tile: image[c2][p] for c2 in [0, 2C), p in [0, PT): what = 0: a = PReLU_p(BN_p(z)), 1: zhat
+// keep factors of the four consecutive elements idx0 .. idx0 + 3 (idx0 % 4 == 0): one hash, as cg_norm_act's float4 path
+__device__ __forceinline__ void cg_tail_keep4(const CgDstdTail& t, int i, unsigned long long seed, unsigned long long idx0, float keep[4]) {
+  if (!(t.train && t.drop_p > 0.f)) { keep[0] = keep[1] = keep[2] = keep[3] = 1.f; return; }
+  const unsigned long long bits = cg_drop_bits(seed, t.salt[i], idx0 >> 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) keep[j] = cg_drop_pick(bits, j, t.drop_p);
+}
+
+// stage the activations of a tile: image[c2][p] for c2 in [0, 2C), p in [0, PT): what = 0: a = PReLU_p(BN_p(z)), 1: zhat.
+// Four positions per work item (one 16-byte load of y and of r, one dropout hash) when the rows allow it (P % 4 == 0).
+// Software-pipelined form of the staging below for rows of whole quads (P % 4 == 0): `load` issues every 16-byte read of a
+// tile (PT / 8 quads of y and of r per thread at C <= 64) before anything waits, `finish` turns them into the LDS image.  The
+// GEMM phases call `load` for tile k+1 right before the matrix-core work of tile k, so the reads travel while the MFMAs run.
+template <int PT>
+__device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int p0, int np, float4 yq[PT / 8], float4 rq[PT / 8]) {
+  const int C = t.C, P = t.T * t.V;
+#pragma unroll
+  for (int q = 0; q < PT / 8; ++q) {
+    const int e = threadIdx.x + q * CG_TAIL_THREADS;
+    const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
+    yq[q] = make_float4(0.f, 0.f, 0.f, 0.f); rq[q] = yq[q];
+    if (c2 < 2 * C && pp < np) {
+      const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
+      const long long off = ((long long)b * C + c) * P + p0 + pp;
+      yq[q] = *reinterpret_cast<const float4*>(t.y[i] + off); rq[q] = *reinterpret_cast<const float4*>(t.r[i] + off);
+    }
+  }
+}
+
+template <int PT>
+__device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const float* sK, unsigned long long seed, int b, int p0, int np,
+                                                   const float4 yq[PT / 8], const float4 rq[PT / 8], float* img, int what) {
+  constexpr int PS = PT + 4;
+  const int C = t.C, P = t.T * t.V;
+#pragma unroll
+  for (int q = 0; q < PT / 8; ++q) {
+    const int e = threadIdx.x + q * CG_TAIL_THREADS;
+    const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
+    if (c2 >= 2 * C) continue;
+    float val[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pp < np) {
+      const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
+      const float4 k0 = *reinterpret_cast<const float4*>(sK + 8 * c2), k1 = *reinterpret_cast<const float4*>(sK + 8 * c2 + 4);
+      const long long off = ((long long)b * C + c) * P + p0 + pp;
+      const float yv[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w}, rv[4] = {rq[q].x, rq[q].y, rq[q].z, rq[q].w};
+      float keep[4];
+      cg_tail_keep4(t, i, seed, (unsigned long long)off, keep);
+      const float wv = t.w[i][(long long)b * C + c], ap = t.alpha_p[i][0], scale_p = k1.z * k1.y;
+      float xv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = ((yv[j] - k0.x) * k0.y + k0.z) * keep[j] + rv[j];
+        xv[j] = cg_prelu(u, k0.w);
+        const float z = wv * xv[j];
+        val[j] = what == 0 ? cg_prelu((z - k1.x) * scale_p + k1.w, ap) : (z - k1.x) * k1.y;
+      }
+      if (what == 0) {
+        if (t.tap_a[i]) *reinterpret_cast<float4*>(t.tap_a[i] + off) = make_float4(val[0], val[1], val[2], val[3]);
+        if (!t.train && t.tap_x[i]) *reinterpret_cast<float4*>(t.tap_x[i] + off) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+      }
+    }
+    *reinterpret_cast<float4*>(img + c2 * PS + pp) = make_float4(val[0], val[1], val[2], val[3]);
+  }
+}
+
+template <int PT>
 __device__ __forceinline__ void cg_tail_stage_act(const CgDstdTail& t, const float* sK, unsigned long long seed, int b, int p0, int np,
                                                   float* img, int what) {
+  constexpr int PS = PT + 4;
   const int C = t.C, P = t.T * t.V;
-  for (int e = threadIdx.x; e < 2 * C * CG_TAIL_PT; e += CG_TAIL_THREADS) {
-    const int c2 = e / CG_TAIL_PT, pp = e - c2 * CG_TAIL_PT;
+  if ((P & 3) == 0) {
+#pragma unroll 4
+    for (int e = threadIdx.x; e < 2 * C * (PT / 4); e += CG_TAIL_THREADS) {
+      const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
+      float val[4] = {0.f, 0.f, 0.f, 0.f};
+      if (pp < np) {                                       // np % 4 == 0 here: a quad is inside the tile or outside
+        const int i = c2 >= C ? 1 : 0, c = c2 - i * C, p = p0 + pp;
+        const float4 k0 = *reinterpret_cast<const float4*>(sK + 8 * c2), k1 = *reinterpret_cast<const float4*>(sK + 8 * c2 + 4);
+        const long long off = ((long long)b * C + c) * P + p;
+        const float4 y4 = *reinterpret_cast<const float4*>(t.y[i] + off), r4 = *reinterpret_cast<const float4*>(t.r[i] + off);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+        float keep[4];
+        cg_tail_keep4(t, i, seed, (unsigned long long)off, keep);
+        const float wv = t.w[i][(long long)b * C + c], ap = t.alpha_p[i][0], scale_p = k1.z * k1.y;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = ((yv[j] - k0.x) * k0.y + k0.z) * keep[j] + rv[j];
+          xv[j] = cg_prelu(u, k0.w);
+          const float z = wv * xv[j];
+          val[j] = what == 0 ? cg_prelu((z - k1.x) * scale_p + k1.w, ap) : (z - k1.x) * k1.y;
+        }
+        if (what == 0) {
+          if (t.tap_a[i]) *reinterpret_cast<float4*>(t.tap_a[i] + off) = make_float4(val[0], val[1], val[2], val[3]);
+          if (!t.train && t.tap_x[i]) *reinterpret_cast<float4*>(t.tap_x[i] + off) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(img + c2 * PS + pp) = make_float4(val[0], val[1], val[2], val[3]);
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < 2 * C * PT; e += CG_TAIL_THREADS) {
+    const int c2 = e / PT, pp = e - c2 * PT;
     float val = 0.f;
     if (pp < np) {
       const int i = c2 / C, c = c2 - i * C, p = p0 + pp;
@@ -177,7 +276,7 @@ __device__ __forceinline__ void cg_tail_stage_act(const CgDstdTail& t, const flo
       }
       else val = (z - k[4]) * k[5];                                    // zhat = (z - mean) * rstd
     }
-    img[c2 * CG_TAIL_PS + pp] = val;
+    img[c2 * PS + pp] = val;
   }
 }
 
@@ -201,13 +300,24 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
   cg_tail_consts(t, sK, false, wg == 0);
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
   const int MT = CM / 16;
+  const bool vec = (P & 3) == 0;
+  float4 yq[CG_TAIL_PT / 8], rq[CG_TAIL_PT / 8];
+  if (vec) {
+    const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT;
+    cg_tail_act_load<CG_TAIL_PT>(t, b, p0, min(CG_TAIL_PT, P - p0), yq, rq);
+  }
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
     if (lid >= total) break;
     const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
     __syncthreads();
-    cg_tail_stage_act(t, sK, seed, b, p0, np, sAct, 0);
+    if (vec) cg_tail_act_finish<CG_TAIL_PT>(t, sK, seed, b, p0, np, yq, rq, sAct, 0);
+    else cg_tail_stage_act<CG_TAIL_PT>(t, sK, seed, b, p0, np, sAct, 0);
     __syncthreads();
+    if (vec && it + 1 < per && lid + 1 < total) {          // the next tile's reads travel while the matrix cores work
+      const int l2 = lid + 1, b2 = l2 / tiles_per_sample, q0 = (l2 - b2 * tiles_per_sample) * CG_TAIL_PT;
+      cg_tail_act_load<CG_TAIL_PT>(t, b2, q0, min(CG_TAIL_PT, P - q0), yq, rq);
+    }
     float* hb = t.h0 + (long long)b * C * P + p0;
     for (int w = wave; w < MT * 2; w += CG_TAIL_THREADS / 64) {          // (co tile, pair of position tiles)
       const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
@@ -338,52 +448,81 @@ __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
 }
 
 // K3: per tile: dh0 (BatchNorm backward of g_c), d a = Wc^T dh0, dWc += dh0 a^T, g_p = d a * PReLU_p' -> HBM + its sums
-__global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTail t, int tiles_per_sample, int total, int per, int replicas) {
+__global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTail t, int tiles_per_sample, int total, int per, int replicas) {
   const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
   const int WS = C2M + 4;
   float* sZ = reinterpret_cast<float*>(cg_dyn_lds);              // [C2M][PS]  zhat of both branches
-  float* sDH = sZ + C2M * CG_TAIL_PS;                             // [CM][PS]   dh0
-  float* sW = sDH + CM * CG_TAIL_PS;                              // [CM][WS]
+  float* sDH = sZ + C2M * CG_TAIL_PS3;                             // [CM][PS]   dh0
+  float* sW = sDH + CM * CG_TAIL_PS3;                              // [CM][WS]
   float* sK = sW + CM * WS;                                       // [2C][8]
-  double* sRed = reinterpret_cast<double*>(sK + 8 * C2M);         // [C2M][2] sums of g_p, g_p * zhat ; then [2] d alpha_p
+  float* sKc = sK + 8 * C2M;                                      // [CM][8] compressor BatchNorm backward constants
+  double* sRed = reinterpret_cast<double*>(sKc + 8 * CM);         // [C2M][2] sums of g_p, g_p * zhat ; then [2] d alpha_p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_TAIL_THREADS / 64;
   const int wg = blockIdx.x;
   if (wg * per >= total) return;
-  for (int e = tid; e < C2M * CG_TAIL_PS + CM * CG_TAIL_PS + CM * WS; e += CG_TAIL_THREADS) sZ[e] = 0.f;
+  for (int e = tid; e < C2M * CG_TAIL_PS3 + CM * CG_TAIL_PS3 + CM * WS; e += CG_TAIL_THREADS) sZ[e] = 0.f;
   for (int e = tid; e < 2 * C2M + 2; e += CG_TAIL_THREADS) sRed[e] = 0.0;
   __syncthreads();
   for (int e = tid; e < C * C2; e += CG_TAIL_THREADS) { const int co = e / C2, c2 = e - co * C2; sW[co * WS + c2] = t.Wc[e]; }
   cg_tail_consts(t, sK, true, false);
+  const double cnt = (double)t.B * P;
+  for (int c = tid; c < C; c += CG_TAIL_THREADS) {
+    const CgAff ac = cg_tail_aff(t.bn_c, c, C, 0.0, t.train, true, false);
+    float* kc = sKc + 8 * c;
+    kc[0] = ac.mean; kc[1] = ac.rstd; kc[2] = ac.gamma * ac.rstd; kc[3] = ac.beta;
+    kc[4] = t.train ? (float)(t.red_c[2 * c] / cnt) : 0.f; kc[5] = t.train ? (float)(t.red_c[2 * c + 1] / cnt) : 0.f;
+  }
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
   const int MT = CM / 16, NT2 = C2M / 16;
-  const double cnt = (double)t.B * P;
   const float invP = 1.f / (float)P;
   // dWc accumulators: tile (mt, n2) for id = u * nw + wave, kept in registers across all tiles of this workgroup
   cg_f32x4 wacc[CG_TAIL_MAXW];
 #pragma unroll
   for (int u = 0; u < CG_TAIL_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float alpha_c = t.alpha_c[0];
-
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
     if (lid >= total) break;
-    const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
+    const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT3, np = min(CG_TAIL_PT3, P - p0);
     __syncthreads();
-    cg_tail_stage_act(t, sK, seed, b, p0, np, sZ, 1);
-    for (int e = tid; e < C * CG_TAIL_PT; e += CG_TAIL_THREADS) {       // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat))
-      const int c = e / CG_TAIL_PT, pp = e - c * CG_TAIL_PT;
-      float val = 0.f;
-      if (pp < np) {
-        const CgAff ac = cg_tail_aff(t.bn_c, c, C, 0.0, t.train, true, false);
-        const long long off = ((long long)b * C + c) * P + p0 + pp;
-        float u;
-        const float g = cg_tail_gc(t, ac, alpha_c, off, b, c, invP, u);
-        if (t.train) {
-          const float m1 = (float)(t.red_c[2 * c] / cnt), m2 = (float)(t.red_c[2 * c + 1] / cnt);
-          val = ac.gamma * ac.rstd * (g - m1 - (t.h0[off] - ac.mean) * ac.rstd * m2);
-        } else val = g * ac.gamma * ac.rstd;
+    cg_tail_stage_act<CG_TAIL_PT3>(t, sK, seed, b, p0, np, sZ, 1);
+    // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
+    if ((P & 3) == 0) {
+#pragma unroll 2
+      for (int e = tid; e < C * (CG_TAIL_PT3 / 4); e += CG_TAIL_THREADS) {
+        const int c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
+        float val[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pp < np) {
+          const float* kc = sKc + 8 * c;                  // mean, rstd, scale = gamma * rstd, beta, m1, m2
+          const long long off = ((long long)b * C + c) * P + p0 + pp;
+          const float4 h4 = *reinterpret_cast<const float4*>(t.h0 + off), d4 = *reinterpret_cast<const float4*>(t.dout + off);
+          const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+          const float gt = t.gate[(long long)b * C + c], dp = t.dpooled[(long long)b * C + c] * invP;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float u = (hv[j] - kc[0]) * kc[2] + kc[3];
+            const float dh = dv[j] * gt + dp;
+            const float g = u > 0.f ? dh : alpha_c * dh;
+            val[j] = t.train ? kc[2] * (g - kc[4] - (hv[j] - kc[0]) * kc[1] * kc[5]) : g * kc[2];
+          }
+        }
+        *reinterpret_cast<float4*>(sDH + c * CG_TAIL_PS3 + pp) = make_float4(val[0], val[1], val[2], val[3]);
       }
-      sDH[c * CG_TAIL_PS + pp] = val;
+    } else {
+      for (int e = tid; e < C * CG_TAIL_PT3; e += CG_TAIL_THREADS) {
+        const int c = e / CG_TAIL_PT3, pp = e - c * CG_TAIL_PT3;
+        float val = 0.f;
+        if (pp < np) {
+          const float* kc = sKc + 8 * c;
+          const long long off = ((long long)b * C + c) * P + p0 + pp;
+          const float hv = t.h0[off];
+          const float u = (hv - kc[0]) * kc[2] + kc[3];
+          const float dh = t.dout[off] * t.gate[(long long)b * C + c] + t.dpooled[(long long)b * C + c] * invP;
+          const float g = u > 0.f ? dh : alpha_c * dh;
+          val = t.train ? kc[2] * (g - kc[4] - (hv - kc[0]) * kc[1] * kc[5]) : g * kc[2];
+        }
+        sDH[c * CG_TAIL_PS3 + pp] = val;
+      }
     }
     __syncthreads();
     // dWc[co][c2] += sum_p dh0[co][p] a[c2][p],  a = PReLU_p(gamma zhat + beta) rebuilt from zhat in the B fragments
@@ -395,11 +534,11 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTa
         const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
         const bool cok = c2 < C2;
         const float gam = cok ? t.bn_p[i].gamma[c] : 0.f, bet = cok ? t.bn_p[i].beta[c] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
-        const float* ap = cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS, CG_TAIL_PS, l15, slot);
-        const float* bp = cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS, CG_TAIL_PS, l15, slot);
-        for (int k0 = 0; k0 < CG_TAIL_PT; k0 += 16) {
+        const float* ap = cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
+        const float* bp = cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
+        for (int k0 = 0; k0 < CG_TAIL_PT3; k0 += 16) {
           float av[4], bv[4];
-          cg_tfrag<0>(ap, CG_TAIL_PS, k0, av); cg_tfrag<0>(bp, CG_TAIL_PS, k0, bv);
+          cg_tfrag<0>(ap, CG_TAIL_PS3, k0, av); cg_tfrag<0>(bp, CG_TAIL_PS3, k0, bv);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             // positions >= np hold zhat = 0 but a = PReLU(beta) != 0 there; dh0 is zero at those positions, so the product vanishes
@@ -410,15 +549,15 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTa
       }
     }
     // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat
-    for (int w = wave; w < NT2 * 2; w += nw) {
-      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+    for (int w = wave; w < NT2 * (CG_TAIL_PT3 / 32); w += nw) {
+      const int mt = w / (CG_TAIL_PT3 / 32), n0 = 32 * (w % (CG_TAIL_PT3 / 32)), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
       const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sDH + n0, CG_TAIL_PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sDH + n1, CG_TAIL_PS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sDH + n0, CG_TAIL_PS3, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sDH + n1, CG_TAIL_PS3, l15, slot);
       for (int k0 = 0; k0 < CM; k0 += 16) {
         float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
+        cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS3, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS3, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
@@ -437,7 +576,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTa
           const int pp = (h ? n1 : n0) + l15;
           const float da = h ? c1[q] : c0[q];
           if (cok && pp < np) {
-            const float zh = sZ[c2 * CG_TAIL_PS + pp], v = gam * zh + bet;
+            const float zh = sZ[c2 * CG_TAIL_PS3 + pp], v = gam * zh + bet;
             const float g = v > 0.f ? da : alp * da;
             t.gp[i][((long long)b * C + c) * P + p0 + pp] = g;
             s1 += g; s2 += g * zh;
@@ -473,40 +612,73 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 1) void cg_tail_k3_kernel(CgDstdTa
   }
 }
 
-// K4: dz = BN_p'(g_p); dw[b,c] = sum_p dz * x; g_d = w * dz * PReLU_d'(u) -> dr (HBM); sums of g_t = g_d * keep for the tcn BatchNorm
-__global__ void cg_tail_k4_kernel(CgDstdTail t) {
-  __shared__ double red[64];
-  const int i = blockIdx.z, c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
+// K4: dz = BN_p'(g_p); dw = sum dz * x; g_d = w * dz * PReLU_d'(u) -> dr (HBM); sums of g_t = g_d * keep for the tcn BatchNorm.
+// One WAVE per (b, c) row (the gate gradient is a row sum: shuffles, no workgroup barrier); a workgroup = four waves walking
+// the batch rows of one channel, channel sums kept in registers and added once per wave.
+__global__ void cg_tail_k4_kernel(CgDstdTail t, int rb) {
+  const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb, P = t.T * t.V;
+  if (b0 >= t.B) return;
+  const int nb = min(rb, t.B - b0), lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const double cnt = (double)t.B * P;
   const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, 0.0, t.train, true, false);
   const CgAff ap = cg_tail_aff(t.bn_p[i], c, t.C, 0.0, t.train, true, false);
-  const float ad = t.alpha_d[i][0], wv = t.w[i][(long long)b * t.C + c];
+  const float ad = t.alpha_d[i][0], scale_p = ap.gamma * ap.rstd;
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
   float m1 = 0.f, m2 = 0.f;
   if (t.train) { m1 = (float)(t.red_p[i][2 * c] / cnt); m2 = (float)(t.red_p[i][2 * c + 1] / cnt); }
-  const long long base = ((long long)b * t.C + c) * P;
-  double sw = 0.0, s1 = 0.0, s2 = 0.0, sa = 0.0;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    const float keep = cg_tail_keep(t, i, seed, b, c, p);
-    float u;
-    const float yv = t.y[i][base + p];
-    const float x = cg_tail_x(at, ad, yv, t.r[i][base + p], keep, u);
-    const float z = wv * x;
-    const float g = t.gp[i][base + p];
-    const float dz = t.train ? ap.gamma * ap.rstd * (g - m1 - (z - ap.mean) * ap.rstd * m2) : g * ap.gamma * ap.rstd;
-    sw += (double)dz * (double)x;
-    const float dx = wv * dz;
-    const float gd = u > 0.f ? dx : ad * dx;
-    t.dr[i][base + p] = gd;
-    if (!(u > 0.f)) sa += (double)dx * (double)u;
-    const float gt = gd * keep;
-    s1 += (double)gt; s2 += (double)gt * (double)((yv - at.mean) * at.rstd);
+  double s1 = 0.0, s2 = 0.0, sa = 0.0;
+  for (int br = wave; br < nb; br += nw) {
+    const int b = b0 + br;
+    const float wv = t.w[i][(long long)b * t.C + c];
+    const long long base = ((long long)b * t.C + c) * P;
+    float sw = 0.f;
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        float keep[4];
+        cg_tail_keep4(t, i, seed, (unsigned long long)(base + p), keep);
+        const float4 y4 = *reinterpret_cast<const float4*>(t.y[i] + base + p), r4 = *reinterpret_cast<const float4*>(t.r[i] + base + p);
+        const float4 g4 = *reinterpret_cast<const float4*>(t.gp[i] + base + p);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float gd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u;
+          const float x = cg_tail_x(at, ad, yv[j], rv[j], keep[j], u);
+          const float z = wv * x;
+          const float dz = t.train ? scale_p * (gv[j] - m1 - (z - ap.mean) * ap.rstd * m2) : gv[j] * scale_p;
+          sw += dz * x;
+          const float dx = wv * dz;
+          gd[j] = u > 0.f ? dx : ad * dx;
+          if (!(u > 0.f)) sa += (double)dx * (double)u;
+          const float gt = gd[j] * keep[j];
+          s1 += (double)gt; s2 += (double)gt * (double)((yv[j] - at.mean) * at.rstd);
+        }
+        *reinterpret_cast<float4*>(t.dr[i] + base + p) = make_float4(gd[0], gd[1], gd[2], gd[3]);
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) {
+        const float keep = cg_tail_keep(t, i, seed, b, c, p);
+        float u;
+        const float yv = t.y[i][base + p];
+        const float x = cg_tail_x(at, ad, yv, t.r[i][base + p], keep, u);
+        const float z = wv * x;
+        const float g = t.gp[i][base + p];
+        const float dz = t.train ? scale_p * (g - m1 - (z - ap.mean) * ap.rstd * m2) : g * scale_p;
+        sw += dz * x;
+        const float dx = wv * dz;
+        const float gd = u > 0.f ? dx : ad * dx;
+        t.dr[i][base + p] = gd;
+        if (!(u > 0.f)) sa += (double)dx * (double)u;
+        const float gt = gd * keep;
+        s1 += (double)gt; s2 += (double)gt * (double)((yv - at.mean) * at.rstd);
+      }
+    }
+    double swd = (double)sw;
+    swd = cg_wave_sum(swd);
+    if (lane == 0) t.dw[i][(long long)b * t.C + c] = (float)swd;
   }
-  sw = cg_block_sum(sw, red); s1 = cg_block_sum(s1, red + 16); s2 = cg_block_sum(s2, red + 32); sa = cg_block_sum(sa, red + 48);
-  if (threadIdx.x == 0) {
-    t.dw[i][(long long)b * t.C + c] = (float)sw;
-    atomicAdd(&t.red_t[i][2 * c], s1); atomicAdd(&t.red_t[i][2 * c + 1], s2); atomicAdd(&t.red_t[i][2 * t.C], sa);
-  }
+  s1 = cg_wave_sum(s1); s2 = cg_wave_sum(s2); sa = cg_wave_sum(sa);
+  if (lane == 0) { atomicAdd(&t.red_t[i][2 * c], s1); atomicAdd(&t.red_t[i][2 * c + 1], s2); atomicAdd(&t.red_t[i][2 * t.C], sa); }
 }
 
 // K5: dy = BN_t'(g_d * keep); also the per-channel parameter gradients of all three BatchNorm levels and the PReLU slopes
@@ -563,8 +735,8 @@ extern "C" long long cg_dstd_tail_ws_floats(int C) { return (long long)CG_TAIL_R
 
 static size_t cg_tail_gemm_lds(int C, bool bwd) {
   const int CM = (C + 15) & ~15, C2M = (2 * C + 15) & ~15, WS = C2M + 4;
-  size_t f = (size_t)C2M * CG_TAIL_PS + (size_t)CM * WS + (size_t)8 * C2M;
-  if (bwd) f += (size_t)CM * CG_TAIL_PS;
+  size_t f = (size_t)C2M * (bwd ? CG_TAIL_PS3 : CG_TAIL_PS) + (size_t)CM * WS + (size_t)8 * C2M;
+  if (bwd) f += (size_t)CM * CG_TAIL_PS3 + (size_t)8 * CM;
   return f * sizeof(float) + (bwd ? (size_t)(2 * C2M + 2) : (size_t)2 * CM) * sizeof(double) + 16;
 }
 
@@ -614,8 +786,8 @@ extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
     hipLaunchKernelGGL(cg_tail_k2_kernel, rows, dim3(256), 0, stream, *t, rb);
   } else if (phase == 3) {
     if (!t->dpooled || !t->red_c || !t->gp[0] || !t->gp[1] || !t->red_p[0] || !t->red_p[1] || !t->dWc_ws || !t->dWc) return CG_EARG;
-    const int tps = (P + CG_TAIL_PT - 1) / CG_TAIL_PT, total = t->B * tps;
-    const int per = (total + 255) / 256, nwg = (total + per - 1) / per;
+    const int tps = (P + CG_TAIL_PT3 - 1) / CG_TAIL_PT3, total = t->B * tps;
+    const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
     const size_t lds = cg_tail_gemm_lds(C, true);
     hipError_t e = hipFuncSetAttribute((const void*)cg_tail_k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -626,7 +798,7 @@ extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
     hipLaunchKernelGGL(cg_tail_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t->dWc_ws, CG_TAIL_REPLICAS, n, t->dWc);
   } else if (phase == 4) {
     if (!t->gp[0] || !t->gp[1] || !t->dr[0] || !t->dr[1] || !t->dw[0] || !t->dw[1] || !t->red_t[0] || !t->red_t[1] || !t->red_p[0]) return CG_EARG;
-    hipLaunchKernelGGL(cg_tail_k4_kernel, dim3((unsigned)C, (unsigned)t->B, 2), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+    hipLaunchKernelGGL(cg_tail_k4_kernel, dim3(rows.x, rows.y, 2), dim3(256), 0, stream, *t, rb);
   } else if (phase == 5) {
     if (!t->dy[0] || !t->dy[1] || !t->dr[0] || !t->dr[1] || !t->red_t[0] || !t->red_t[1] || !t->dgamma_t[0] || !t->dgamma_p[0] || !t->dgamma_c) return CG_EARG;
     hipLaunchKernelGGL(cg_tail_k5_kernel, dim3(rows.x, rows.y, 2), dim3(256), 0, stream, *t, rb);

@@ -222,6 +222,8 @@ class CISTGCN(nn.Module):
         self.in_ch = 10
         self.fused_domain = True     # False: graph product and channel mix as two generic contractions
         self.staged = True           # True: same-depth ops of a block's parallel branches share one launch
+        # True: everything behind the tcn convolutions of a block as phase kernels (ops.dstd_tail); CISTGCN_FUSED_TAIL=0 is a tuning aid
+        self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
@@ -460,10 +462,22 @@ class CISTGCN(nn.Module):
             else:
                 spec = "bctv,bvtq->bcqv" if d.domain == "space" else "bctv,btvw->bctw"
                 ys.append(self._lin(_pointwise, ops.contract(spec, x_dom[i], d.Adj), conv))
+        c = m.compressor
+        if self.fused_tail and c[0].out_channels <= 64 and all(isinstance(y, tuple) and (y[1] is not None or not tr) for y in ys):
+            # everything behind the two tcn convolutions in five phase launches (csrc/dstd_tail.hip)
+            self._site += 2
+            taps = [] if self.act_trace is not None else None
+            out, ost = ops.dstd_tail([y[0] for y in ys], [y[1] for y in ys], res, (m.w1, m.w2),
+                                     (doms[0].tcn[1], doms[1].tcn[1], m.prelu1[0], m.prelu2[0], c[1]),
+                                     (doms[0].prelu, doms[1].prelu, m.prelu1[1], m.prelu2[1], c[2]), c[0].weight, c[3], bres, tr,
+                                     drop_p=self.dropout, salts=(self._site - 1, self._site), emit_stats=tr, taps=taps)
+            if taps is not None:
+                for mod, tap in zip((doms[0].prelu, doms[1].prelu, m.prelu1[1], m.prelu2[1], c[2]), taps):
+                    self.act_trace[mod] = (tap, None)
+            return (out, ost) if tr else out
         x12 = self._na_many([dict(x=ys[i], bn=d.tcn[1], drop=True, add=res[i], prelu=d.prelu) for i, d in enumerate(doms)])
         ab = self._na_many([dict(x=x12[0], pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1]),
                             dict(x=x12[1], pre=m.w2, bn=m.prelu2[0], prelu=m.prelu2[1])])
-        c = m.compressor
         h = self._na(self._lin(_pointwise, ops.cat_channels(ab), c[0]), bn=c[1], prelu=c[2])
         h_pool, h = ops.fanout(h, 2)                                     # squeeze | excite
         gate = ops.se_gate(ops.mean_bc(h_pool), c[3].w1, c[3].w2)

@@ -1345,3 +1345,148 @@ def stgcn_domain(x, adj, w, bias, domain, want_stats=False):
     """Fused graph product + channel mix (CISTGCN.py:265-266).  domain 0 = "space" (Adj (B,V,T,T)),
     1 = "time" (Adj (B,T,V,V)).  Returns (y, f64 channel sums of y or None)."""
     return _StgcnDomain.apply(x, adj, w, bias, domain, want_stats)
+
+
+# ----------------------------------------------------------------------------------------------
+# tail of a DSTD_GC block as phase kernels (csrc/dstd_tail.hip)
+# ----------------------------------------------------------------------------------------------
+def _tail_bn(dst, bn, stats, save, train):
+    dst.stats = stats.data_ptr() if stats is not None else None
+    dst.gamma, dst.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+    dst.running_mean, dst.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+    dst.num_batches_tracked = bn.num_batches_tracked.data_ptr() if train else None
+    dst.momentum, dst.eps = bn.momentum, bn.eps
+    dst.save = save.data_ptr()
+
+
+class _DstdTail(torch.autograd.Function):
+    """y_i (tcn outputs) -> block output, CISTGCN.py:266-269, :388, :305-309, :390 (see csrc/dstd_tail.hip).
+    Tensor inputs: y1 y2 r1 r2 w1 w2 | g_t1 b_t1 a_d1 g_t2 b_t2 a_d2 | g_p1 b_p1 a_p1 g_p2 b_p2 a_p2 | Wc g_c b_c a_c |
+    se_w1 se_w2 | bres."""
+
+    @staticmethod
+    def forward(ctx, cfg, *ts):
+        ctx.set_materialize_grads(False)
+        (y1, y2, r1, r2, w1, w2, gt1, bt1, ad1, gt2, bt2, ad2, gp1, bp1, ap1, gp2, bp2, ap2, wc, gc, bc, ac, sw1, sw2, bres) = ts
+        for t in (y1, y2, r1, r2, w1, w2, bres):
+            _chk(t)
+            if not t.is_contiguous():
+                raise ValueError("dstd_tail expects contiguous tensors")
+        B, C, T, V = y1.shape
+        dev, train = y1.device, bool(cfg["train"])
+        f32 = torch.float32
+        t = _lib.DstdTail()
+        t.B, t.C, t.T, t.V, t.train = B, C, T, V, 1 if train else 0
+        saves = torch.empty(5, 2, C, dtype=f32, device=dev)           # tcn x2, prelu1/2, compressor: mean / rstd
+        t.y[0], t.y[1], t.r[0], t.r[1], t.w[0], t.w[1] = (v.data_ptr() for v in (y1, y2, r1, r2, w1, w2))
+        arena = _arena(dev)
+        zst = [arena.take(2 * C * _lib.STAT_REPLICAS) for _ in range(2)] if train else [None, None]
+        hst = arena.take(2 * C * _lib.STAT_REPLICAS) if train else None
+        bns = cfg["bn"]                                                # (tcn1, tcn2, prelu1, prelu2, compressor) parameter holders
+        _tail_bn(t.bn_t[0], bns[0], cfg["ystats"][0], saves[0], train); _tail_bn(t.bn_t[1], bns[1], cfg["ystats"][1], saves[1], train)
+        _tail_bn(t.bn_p[0], bns[2], zst[0], saves[2], train); _tail_bn(t.bn_p[1], bns[3], zst[1], saves[3], train)
+        _tail_bn(t.bn_c, bns[4], hst, saves[4], train)
+        t.alpha_d[0], t.alpha_d[1], t.alpha_p[0], t.alpha_p[1] = ad1.data_ptr(), ad2.data_ptr(), ap1.data_ptr(), ap2.data_ptr()
+        t.Wc, t.alpha_c, t.bres = wc.data_ptr(), ac.data_ptr(), bres.data_ptr()
+        p = float(cfg.get("drop_p", 0.0)) if train else 0.0
+        t.drop_p = p
+        if p > 0.0:
+            t.seed = seed_state(dev).data_ptr()
+        t.salt[0], t.salt[1] = cfg["salts"]
+        h0 = torch.empty(B, C, T, V, dtype=f32, device=dev)
+        pooled = torch.empty(B, C, dtype=f32, device=dev)
+        out = torch.empty(B, C, T, V, dtype=f32, device=dev)
+        ostats = arena.take(2 * C * _lib.STAT_REPLICAS) if cfg.get("emit_stats") else None
+        t.h0, t.pooled, t.out, t.ostats = h0.data_ptr(), pooled.data_ptr(), out.data_ptr(), _ptr(ostats)
+        taps = cfg.get("taps")
+        if taps is not None:                                           # branch records (diagnostics): five PReLU outputs
+            for k in range(5):
+                taps.append(torch.empty(B, C, T, V, dtype=f32, device=dev))
+            t.tap_x[0], t.tap_x[1], t.tap_a[0], t.tap_a[1], t.tap_h = (v.data_ptr() for v in taps[-5:])
+        stream = _stream(y1)
+        for phase in (1, 2, 3):
+            _lib.call("cg_dstd_tail_fwd", ctypes.byref(t), phase, stream)
+        gate = torch.empty(B, C, dtype=f32, device=dev)
+        H = sw1.shape[0]
+        _lib.call("cg_se_gate_fwd", _ptr(pooled), _ptr(sw1), _ptr(sw2), _ptr(gate), B, C, H, stream)
+        t.gate = gate.data_ptr()
+        _lib.call("cg_dstd_tail_fwd", ctypes.byref(t), 4, stream)
+        ctx.cfg, ctx.p = cfg, p
+        ctx.save_for_backward(*ts, h0, pooled, gate, saves)
+        if ostats is not None:
+            ctx.mark_non_differentiable(ostats)
+        return out, ostats
+
+    @staticmethod
+    def backward(ctx, dout, _=None):
+        sv = ctx.saved_tensors
+        (y1, y2, r1, r2, w1, w2, gt1, bt1, ad1, gt2, bt2, ad2, gp1, bp1, ap1, gp2, bp2, ap2, wc, gc, bc, ac, sw1, sw2, bres) = sv[:25]
+        h0, pooled, gate, saves = sv[25:]
+        cfg = ctx.cfg
+        B, C, T, V = y1.shape
+        dev, train, f32 = y1.device, bool(cfg["train"]), torch.float32
+        dout = dout if dout.is_contiguous() else _copy(dout)
+        t = _lib.DstdTail()
+        t.B, t.C, t.T, t.V, t.train = B, C, T, V, 1 if train else 0
+        t.y[0], t.y[1], t.r[0], t.r[1], t.w[0], t.w[1] = (v.data_ptr() for v in (y1, y2, r1, r2, w1, w2))
+        bns = cfg["bn"]
+        for dst, bn, k in ((t.bn_t[0], bns[0], 0), (t.bn_t[1], bns[1], 1), (t.bn_p[0], bns[2], 2), (t.bn_p[1], bns[3], 3), (t.bn_c, bns[4], 4)):
+            _tail_bn(dst, bn, None, saves[k], False)
+        t.alpha_d[0], t.alpha_d[1], t.alpha_p[0], t.alpha_p[1] = ad1.data_ptr(), ad2.data_ptr(), ap1.data_ptr(), ap2.data_ptr()
+        t.Wc, t.alpha_c, t.bres, t.gate, t.h0 = wc.data_ptr(), ac.data_ptr(), bres.data_ptr(), gate.data_ptr(), h0.data_ptr()
+        t.drop_p = ctx.p
+        if ctx.p > 0.0:
+            t.seed = seed_state(dev).data_ptr()
+        t.salt[0], t.salt[1] = cfg["salts"]
+        t.dout = dout.data_ptr()
+        stream = _stream(y1)
+        dgate = torch.empty(B, C, dtype=f32, device=dev)
+        t.dgate = dgate.data_ptr()
+        _lib.call("cg_dstd_tail_bwd", ctypes.byref(t), 1, stream)
+        H = sw1.shape[0]
+        dpooled = torch.empty(B, C, dtype=f32, device=dev)
+        ws_floats = int(_lib.lib().cg_dstd_tail_ws_floats(C))
+        zb, _ = _zeros(2 * C * H + ws_floats, dev)
+        dsw1, dsw2 = zb[:C * H].view(sw1.shape), zb[C * H:2 * C * H].view(sw2.shape)
+        _lib.call("cg_se_gate_bwd", _ptr(pooled), _ptr(sw1), _ptr(sw2), _ptr(gate), _ptr(dgate), _ptr(dpooled), _ptr(dsw1), _ptr(dsw2),
+                  B, C, H, 1, stream)
+        arena = _arena(dev)
+        red_c = arena.take(2 * C + 1)
+        red_p = [arena.take(2 * C + 1) for _ in range(2)]
+        red_t = [arena.take(2 * C + 1) for _ in range(2)]
+        big = [torch.empty(B, C, T, V, dtype=f32, device=dev) for _ in range(6)]            # gp x2, dr x2, dy x2
+        dws = [torch.empty(B, C, dtype=f32, device=dev) for _ in range(2)]
+        small = torch.empty(15, C, dtype=f32, device=dev)   # dgamma/dbeta of tcn1,2 prelu1,2 compressor (10 rows) + 5 slope gradients
+        dwc = torch.empty(C, 2 * C, dtype=f32, device=dev)
+        t.dpooled, t.red_c = dpooled.data_ptr(), red_c.data_ptr()
+        for i in range(2):
+            t.gp[i], t.red_p[i], t.dr[i], t.dw[i], t.red_t[i], t.dy[i] = (big[i].data_ptr(), red_p[i].data_ptr(), big[2 + i].data_ptr(),
+                                                                          dws[i].data_ptr(), red_t[i].data_ptr(), big[4 + i].data_ptr())
+            t.dgamma_t[i], t.dbeta_t[i], t.dgamma_p[i], t.dbeta_p[i] = (small[2 * i].data_ptr(), small[2 * i + 1].data_ptr(),
+                                                                        small[4 + 2 * i].data_ptr(), small[5 + 2 * i].data_ptr())
+            t.dalpha_d[i], t.dalpha_p[i] = small[10 + i].data_ptr(), small[12 + i].data_ptr()
+        t.dgamma_c, t.dbeta_c, t.dalpha_c = small[8].data_ptr(), small[9].data_ptr(), small[14].data_ptr()
+        t.dWc_ws, t.dWc = zb[2 * C * H:].data_ptr(), dwc.data_ptr()
+        for phase in (2, 3, 4, 5):
+            _lib.call("cg_dstd_tail_bwd", ctypes.byref(t), phase, stream)
+        al = lambda k: small[k, :1].reshape(1)
+        grads = (big[4], big[5], big[2], big[3], dws[0], dws[1],
+                 small[0], small[1], al(10), small[2], small[3], al(11),
+                 small[4], small[5], al(12), small[6], small[7], al(13),
+                 dwc.view(wc.shape), small[8], small[9], al(14), dsw1, dsw2, dout)
+        return (None,) + tuple(g if ctx.needs_input_grad[1 + k] else None for k, g in enumerate(grads))
+
+
+def dstd_tail(ys, ystats, rs, ws, bns, alphas, wc, se, bres, train, drop_p=0.0, salts=(0, 0), emit_stats=False, taps=None):
+    """Fused tail of a DSTD_GC block.  ys / ystats: tcn outputs of the two Domain_GCNN layers and their f64 channel sums;
+    rs: their residual addends; ws: gates (B,C); bns: (tcn1.1, tcn2.1, prelu1.0, prelu2.0, compressor.1) BatchNorm holders;
+    alphas: (layer1.prelu, layer2.prelu, prelu1.1, prelu2.1, compressor.2) PReLU holders; wc: compressor conv weight
+    (C,2C,1,1); se: SELayer2d holder; bres: block residual.  Returns (out, f64 channel sums of out or None)."""
+    C = ys[0].shape[1]
+    cfg = {"train": bool(train), "drop_p": float(drop_p), "salts": tuple(int(s) for s in salts), "ystats": tuple(ystats), "bn": tuple(bns),
+           "emit_stats": bool(emit_stats), "taps": taps}
+    ts = (ys[0], ys[1], rs[0], rs[1], ws[0], ws[1],
+          bns[0].weight, bns[0].bias, alphas[0].weight, bns[1].weight, bns[1].bias, alphas[1].weight,
+          bns[2].weight, bns[2].bias, alphas[2].weight, bns[3].weight, bns[3].bias, alphas[3].weight,
+          wc.view(C, 2 * C), bns[4].weight, bns[4].bias, alphas[4].weight, se.w1, se.w2, bres)
+    return _DstdTail.apply(cfg, *ts)

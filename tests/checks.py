@@ -736,6 +736,73 @@ def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=35
     return {"flips": rep.flips, "elements": rep.elements, "worst_flip": rep.worst, "worst_grad": worst}
 
 
+def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11))):
+    """ops.dstd_tail (phase kernels of csrc/dstd_tail.hip) against the same chain built from the row kernels and the generic
+    contraction (pinned to the oracle by the model tests): identical dropout draws (same seed word and site ids), train and
+    eval mode, output, emitted channel sums, every input / parameter gradient, running statistics."""
+    from cistgcn_amd.models.layers.SE import SELayer2d
+    g = _gen(31)
+    for (B, C, T, V) in shapes:
+        for train in (True, False):
+            def make():
+                gg = _gen(100 + B + C)
+                bns = [nn.BatchNorm2d(C) for _ in range(5)]
+                for bn in bns:
+                    with torch.no_grad():
+                        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=gg)); bn.bias.copy_(0.3 * torch.randn(C, generator=gg))
+                        bn.running_mean.copy_(0.2 * torch.randn(C, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(C, generator=gg))
+                al = [nn.PReLU() for _ in range(5)]
+                for i, a in enumerate(al):
+                    with torch.no_grad():
+                        a.weight.fill_(0.1 + 0.07 * i)
+                conv = nn.Conv2d(2 * C, C, 1, bias=False)
+                se = SELayer2d(C, reduction=8)
+                with torch.no_grad():
+                    conv.weight.copy_(0.3 * torch.randn(conv.weight.shape, generator=gg))
+                    se.w1.copy_(0.5 * torch.randn(se.w1.shape, generator=gg)); se.w2.copy_(0.5 * torch.randn(se.w2.shape, generator=gg))
+                mods = nn.ModuleList(bns + al + [conv, se]).to(device)
+                return list(mods[:5]), list(mods[5:10]), mods[10], mods[11], mods
+            data = [_rand(g, B, C, T, V), _rand(g, B, C, T, V), _rand(g, B, C, T, V), _rand(g, B, C, T, V), _rand(g, B, C), _rand(g, B, C),
+                    _rand(g, B, C, T, V)]
+            gout = _rand(g, B, C, T, V).to(device)
+            results = []
+            for fused in (True, False):
+                bns, al, conv, se, mods = make()
+                mods.train(train)
+                y1, y2, r1, r2, w1, w2, bres = [_leaf(t, device) for t in data]
+                ops.manual_seed(1234, device)
+                ops.begin_step(device)
+                def sums(y):
+                    st = ops._arena(torch.device(device)).take(2 * C * 16)
+                    yc = y.detach().double()
+                    st.view(16, C, 2)[0].copy_(torch.stack((yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3))), 1))
+                    return st
+                p = 0.25
+                if fused:
+                    out, ost = ops.dstd_tail([y1, y2], [sums(y1), sums(y2)] if train else [None, None], [r1, r2], (w1, w2), bns, al, conv.weight, se,
+                                             bres, train, drop_p=p, salts=(7, 9), emit_stats=train)
+                else:
+                    x12 = ops.norm_act_many([dict(x=y1, bn=bns[0], train=train, drop_p=p, salt=7, add=r1, prelu=al[0], stats=sums(y1) if train else None),
+                                             dict(x=y2, bn=bns[1], train=train, drop_p=p, salt=9, add=r2, prelu=al[1], stats=sums(y2) if train else None)])
+                    ab = ops.norm_act_many([dict(x=x12[0], pre=w1, bn=bns[2], train=train, prelu=al[2]),
+                                            dict(x=x12[1], pre=w2, bn=bns[3], train=train, prelu=al[3])])
+                    h0 = ops.contract("oc,bchw->bohw", conv.weight.view(C, 2 * C), ops.cat_channels(ab))
+                    h = ops.norm_act(h0, bn=bns[4], train=train, prelu=al[4])
+                    gate = ops.se_gate(ops.mean_bc(h), se.w1, se.w2)
+                    out, ost = ops.norm_act(h, pre=gate, add=bres, add_post=True, emit_stats=True)
+                out.backward(gout)
+                grads = [t.grad for t in (y1, y2, r1, r2, w1, w2, bres)] + [p_.grad for p_ in mods.parameters()]
+                results.append((out.detach(), _chan_sums(ost) if (train or not fused) else None, grads, [b.clone() for b in mods.buffers()]))
+            what = "dstd_tail B%d C%d T%d V%d %s" % (B, C, T, V, "train" if train else "eval")
+            assert_close(results[0][0], results[1][0], what + " out", rel=2e-5)
+            if train:
+                assert_close(results[0][1], results[1][1], what + " sums", rel=1e-6)
+            for k, (a, b) in enumerate(zip(results[0][2], results[1][2])):
+                assert_close(a, b, "%s grad[%d]" % (what, k), rel=5e-5, floor=max(1e-3, float(b.abs().max())))
+            for k, (a, b) in enumerate(zip(results[0][3], results[1][3])):
+                assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
+
+
 def check_flat_adam(device):
     """cg_adam_flat + FlatGrads against torch.optim.Adam with the reference's settings (weight decay, no amsgrad)."""
     from cistgcn_amd.runtime import FlatAdam

@@ -1,0 +1,5 @@
+python -m cistgcn_amd.build >/dev/null 2>&1
+for v in 1 0 1 0; do
+  CISTGCN_FUSED_TAIL=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-roofline --no-eval --steps 40 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('fused_tail=$v headline %.2f ms  secondary %.3f ms' % (d['ms_per_step'], d['secondary']['ms_per_step']))"
+done

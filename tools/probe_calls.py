@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: HIP-event time of every C-ABI call of one eager training step, grouped by entry point and shape
 (contractions: (mode, G, M, N, K) of each problem of the launch).  Usage: probe_calls.py [workload] [top]"""
-import collections, os, sys
+import collections, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -32,6 +32,9 @@ def describe(name, args):
         arr, n = args[0], (args[1] if name.endswith("fwd_many") else args[2])
         return " ".join("[%dx%dx%d%s%s%s]" % (arr[i].xv.n[0], arr[i].xv.n[1], arr[i].xv.n[2] * arr[i].xv.n[3], " bn" if arr[i].bn_mode else "",
                                               " pre" if arr[i].pre else "", " add" if arr[i].add else "") for i in range(n))
+    if name.startswith("cg_dstd_tail"):
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.DstdTail)).contents
+        return "phase %d  B%d C%d T%d V%d" % (args[1], t.B, t.C, t.T, t.V)
     if name.startswith("cg_stgcn_domain"):
         return str(args[-7:-1] if name.endswith("fwd") else args[-8:-2])
     return ""
