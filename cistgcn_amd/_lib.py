@@ -93,6 +93,16 @@ class DstdTail(ctypes.Structure):
                 ("dgamma_c", c_void_p), ("dbeta_c", c_void_p), ("dalpha_c", c_void_p)]
 
 
+class AdjTail(ctypes.Structure):
+    _fields_ = [("B", c_int), ("Kc", c_int), ("J", c_int), ("domain", c_int), ("train", c_int), ("pad0", c_int),
+                ("s", c_void_p), ("q", c_void_p), ("W0", c_void_p), ("bn", TailBN), ("alpha", c_void_p), ("W4", c_void_p),
+                ("drop_p", c_float), ("salt", c_uint), ("seed", c_void_p),
+                ("e", c_void_p), ("adj", c_void_p), ("tap", c_void_p),
+                ("dadj", c_void_p), ("g", c_void_p), ("red", c_void_p), ("ds", c_void_p), ("dq", c_void_p),
+                ("dW0_ws", c_void_p), ("dW4_ws", c_void_p),
+                ("dW0", c_void_p), ("dW4", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("dalpha", c_void_p)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -134,6 +144,9 @@ _SIGNATURES = {
     "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_bwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_ws_floats": [c_int],
+    "cg_map2adj_tail_fwd": [POINTER(AdjTail), c_int, c_int, P],
+    "cg_map2adj_tail_bwd": [POINTER(AdjTail), c_int, c_int, P],
+    "cg_map2adj_tail_ws_floats": [c_int],
     "cg_augment_sequences": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }

@@ -22,47 +22,9 @@
 // rounding.  Dropout draws are those of cg_norm_act (same counter-based hash of seed, site and element index).
 #include "cg_common.h"
 #include "dstd_tail.h"
+#include "cg_phase.h"
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
-
-typedef float cg_f32x4 __attribute__((vector_size(16)));
-
-// ---- per-channel constants -------------------------------------------------------------------------------------------
-struct CgAff { float mean, rstd, gamma, beta; };
-
-// train: batch statistics from the replicated f64 sums (and, by the block that owns channel bookkeeping, save + running
-// statistics exactly like nn.BatchNorm); eval: running statistics.  backward: the saved pair.
-__device__ __forceinline__ CgAff cg_tail_aff(const CgTailBN& bn, int c, int C, double cnt, int train, bool backward, bool owner) {
-  CgAff a;
-  a.gamma = bn.gamma[c]; a.beta = bn.beta[c];
-  if (backward) { a.mean = bn.save[c]; a.rstd = bn.save[C + c]; return a; }
-  if (train) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < CG_STAT_REPLICAS; ++r) { s1 += bn.stats[((long long)r * C + c) * 2]; s2 += bn.stats[((long long)r * C + c) * 2 + 1]; }
-    const double mean = s1 / cnt;
-    double var = s2 / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    a.mean = (float)mean;
-    a.rstd = (float)(1.0 / sqrt(var + (double)bn.eps));
-    if (owner) {
-      bn.save[c] = a.mean; bn.save[C + c] = a.rstd;
-      if (bn.running_mean) {
-        const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-        bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
-        bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
-        if (c == 0 && bn.num_batches_tracked) *bn.num_batches_tracked += 1;
-      }
-    }
-  } else {
-    a.mean = bn.running_mean[c];
-    a.rstd = 1.0f / sqrtf(bn.running_var[c] + bn.eps);
-    if (owner) { bn.save[c] = a.mean; bn.save[C + c] = a.rstd; }
-  }
-  return a;
-}
-
-__device__ __forceinline__ float cg_bn(const CgAff& a, float v) { return (v - a.mean) * (a.gamma * a.rstd) + a.beta; }
-__device__ __forceinline__ float cg_prelu(float u, float alpha) { return u > 0.f ? u : alpha * u; }
 
 // rows of one channel per workgroup, as rowops.hip
 static int cg_tail_rows(long long B, long long C, long long P) {
@@ -116,24 +78,6 @@ __global__ void cg_tail_f1_kernel(CgDstdTail t, int rb) {
     double* rep = t.bn_p[i].stats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * t.C;
     atomicAdd(&rep[2 * c], s); atomicAdd(&rep[2 * c + 1], q);
   }
-}
-
-// ======================================================================================================================
-// matrix-core helpers (same fragment scheme as stgcn_domain_mfma.hip: inside a 16-wide k chunk step s takes k = 4*slot + s)
-// ======================================================================================================================
-template <int KIND>
-__device__ __forceinline__ void cg_tfrag(const float* __restrict__ p, int rs, int k0, float v[4]) {
-  if (KIND == 0) {
-    const float4 t = *reinterpret_cast<const float4*>(p + k0);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else {
-    const float* q = p + k0 * rs;
-    v[0] = q[0]; v[1] = q[rs]; v[2] = q[2 * rs]; v[3] = q[3 * rs];
-  }
-}
-template <int KIND>
-__device__ __forceinline__ const float* cg_tfrag_ptr(const float* base, int rs, int l15, int slot) {
-  return KIND == 0 ? base + l15 * rs + 4 * slot : base + l15 + 4 * slot * rs;
 }
 
 #define CG_TAIL_PT 64                 // positions per tile

@@ -224,6 +224,7 @@ class CISTGCN(nn.Module):
         self.staged = True           # True: same-depth ops of a block's parallel branches share one launch
         # True: everything behind the tcn convolutions of a block as phase kernels (ops.dstd_tail); CISTGCN_FUSED_TAIL=0 is a tuning aid
         self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
+        self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
@@ -439,18 +440,30 @@ class CISTGCN(nn.Module):
         for i, d in enumerate(doms):
             q, s = o[2 + 2 * i][0].view(B, T, V), o[3 + 2 * i][0].view(B, V, T)
             seeds.append((0 if d.domain == "space" else 1, s, q))
-        if T <= 64 and V <= 64:
-            oo = ops.rank1_adj(seeds)                        # both towers in one launch; backward reads each d o once
+        if self.fused_adj and T <= 64 and V <= 64:
+            # seed, expansor and adjacency of both towers in two phase launches (csrc/map2adj_tail.hip); the seed is never stored
+            o = _run_items([_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)])
+            m.w1, m.w2 = o[0][0], o[1][0]
+            self._site += 2
+            taps = [] if self.act_trace is not None else None
+            adj = ops.map2adj_tail(seeds, [a.expansor for a in maps], tr, drop_p=self.dropout, salts=(self._site - 1, self._site), taps=taps)
+            adj = [(a, None) for a in adj]
+            if taps is not None:
+                for a, tap in zip(maps, taps):
+                    self.act_trace[a.expansor[3]] = (tap, None)
         else:
-            oo = [y for y, _ in ops.contract_many([("bvt,bxv->bvtx" if dom == 0 else "bvt,btw->btvw", s, q, None, None, None)
-                                                   for dom, s, q in seeds])]
-        # 7. gate output Linear + expansor first map
-        items = [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
-        items += [_pw_item(oo[i], a.expansor[0], tr) for i, a in enumerate(maps)]
-        o = _run_items(items)
-        m.w1, m.w2 = o[0][0], o[1][0]
-        e = self._na_many([dict(x=o[2 + i], bn=a.expansor[1], drop=True, prelu=a.expansor[3]) for i, a in enumerate(maps)])
-        adj = _run_items([_pw_item(e[i], a.expansor[4], False) for i, a in enumerate(maps)])
+            if T <= 64 and V <= 64:
+                oo = ops.rank1_adj(seeds)                        # both towers in one launch; backward reads each d o once
+            else:
+                oo = [y for y, _ in ops.contract_many([("bvt,bxv->bvtx" if dom == 0 else "bvt,btw->btvw", s, q, None, None, None)
+                                                       for dom, s, q in seeds])]
+            # 7. gate output Linear + expansor first map
+            items = [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
+            items += [_pw_item(oo[i], a.expansor[0], tr) for i, a in enumerate(maps)]
+            o = _run_items(items)
+            m.w1, m.w2 = o[0][0], o[1][0]
+            e = self._na_many([dict(x=o[2 + i], bn=a.expansor[1], drop=True, prelu=a.expansor[3]) for i, a in enumerate(maps)])
+            adj = _run_items([_pw_item(e[i], a.expansor[4], False) for i, a in enumerate(maps)])
         # 8. graph product + channel mix, then BN + residual + PReLU
         ys = []
         for i, d in enumerate(doms):
@@ -524,7 +537,31 @@ class CISTGCN(nn.Module):
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != self.n_input or x.shape[2] != self.n_joints or x.shape[3] != 3:
             raise ValueError("expected input of shape (B, %d, %d, 3), got %s" % (self.n_input, self.n_joints, tuple(x.shape)))
-        ops.begin_step(x.device, bump_seed=self.training and self.dropout > 0.0)
+        if torch.jit.is_tracing():
+            # `SummaryWriter.add_graph(model, batch)` (train.py:137) traces the model.  The kernels are reached through ctypes and
+            # exchange statistics buffers the tracer cannot follow, so the hot path is shown to it as ONE opaque node.
+            net = self
+
+            class HotPath(torch.autograd.Function):
+                @staticmethod
+                def forward(ctx, inp):
+                    state = torch._C._get_tracing_state()
+                    torch._C._set_tracing_state(None)          # nothing inside is recorded
+                    try:
+                        with torch.no_grad():
+                            return net._forward(inp.detach(), bump_seed=False)[0]
+                    finally:
+                        torch._C._set_tracing_state(state)
+
+                @staticmethod
+                def backward(ctx, g):
+                    raise RuntimeError("the traced CISTGCN graph is for display only")
+
+            return HotPath.apply(x),
+        return self._forward(x, bump_seed=self.training and self.dropout > 0.0)
+
+    def _forward(self, x, bump_seed):
+        ops.begin_step(x.device, bump_seed=bump_seed)
         self._site, self._next_stream = 0, 0
         h = ops.feature_lift(x)                                         # (B,10,T,V)
         block = self._block_staged if self.staged else self._block

@@ -1490,3 +1490,107 @@ def dstd_tail(ys, ystats, rs, ws, bns, alphas, wc, se, bres, train, drop_p=0.0, 
           bns[2].weight, bns[2].bias, alphas[2].weight, bns[3].weight, bns[3].bias, alphas[3].weight,
           wc.view(C, 2 * C), bns[4].weight, bns[4].bias, alphas[4].weight, se.w1, se.w2, bres)
     return _DstdTail.apply(cfg, *ts)
+
+
+class _Map2AdjTail(torch.autograd.Function):
+    """(s, q) of each tower pair -> Adj, CISTGCN.py:183-189 with the expansor of :165-170 (see csrc/map2adj_tail.hip).
+    Tensor inputs per tower: s q W0 gamma beta alpha W4."""
+
+    @staticmethod
+    def _items(cfg, ts, train, saves, stats, e, dev, p):
+        n = len(ts) // 7
+        items = (_lib.AdjTail * n)()
+        for i in range(n):
+            s, q, w0, gamma, beta, alpha, w4 = ts[7 * i:7 * i + 7]
+            B, V, T = s.shape
+            t = items[i]
+            dom = cfg["domains"][i]
+            t.B, t.domain, t.train = B, dom, 1 if train else 0
+            t.Kc, t.J = (V, T) if dom == 0 else (T, V)
+            t.s, t.q, t.W0, t.alpha, t.W4 = s.data_ptr(), q.data_ptr(), w0.data_ptr(), alpha.data_ptr(), w4.data_ptr()
+            _tail_bn(t.bn, cfg["bn"][i], stats[i] if stats is not None else None, saves[i], train and stats is not None)
+            t.drop_p, t.salt = p, cfg["salts"][i]
+            if p > 0.0:
+                t.seed = seed_state(dev).data_ptr()
+            t.e = e[i].data_ptr()
+        return items
+
+    @staticmethod
+    def forward(ctx, cfg, *ts):
+        ctx.set_materialize_grads(False)
+        n = len(ts) // 7
+        for i in range(n):
+            for t in ts[7 * i:7 * i + 2]:
+                _chk(t)
+                if not t.is_contiguous():
+                    raise ValueError("map2adj_tail expects contiguous tower outputs")
+        dev, train, f32 = ts[0].device, bool(cfg["train"]), torch.float32
+        p = float(cfg.get("drop_p", 0.0)) if train else 0.0
+        arena = _arena(dev)
+        shapes = []
+        for i in range(n):
+            B, V, T = ts[7 * i].shape
+            Kc, J = (V, T) if cfg["domains"][i] == 0 else (T, V)
+            shapes.append((B, Kc, J, J))
+        saves = [torch.empty(2, sh[1], dtype=f32, device=dev) for sh in shapes]
+        stats = [arena.take(2 * sh[1] * _lib.STAT_REPLICAS) for sh in shapes] if train else None
+        e = [torch.empty(sh, dtype=f32, device=dev) for sh in shapes]
+        adj = [torch.empty(sh, dtype=f32, device=dev) for sh in shapes]
+        items = _Map2AdjTail._items(cfg, ts, train, saves, stats, e, dev, p)
+        taps = cfg.get("taps")
+        for i in range(n):
+            items[i].adj = adj[i].data_ptr()
+            if taps is not None:
+                taps.append(torch.empty(shapes[i], dtype=f32, device=dev))
+                items[i].tap = taps[-1].data_ptr()
+        stream = _stream(ts[0])
+        for phase in (1, 2):
+            _lib.call("cg_map2adj_tail_fwd", items, n, phase, stream)
+        ctx.cfg, ctx.p, ctx.n = cfg, p, n
+        ctx.save_for_backward(*ts, *e, *saves)
+        return tuple(adj)
+
+    @staticmethod
+    def backward(ctx, *dadj):
+        n, cfg = ctx.n, ctx.cfg
+        sv = ctx.saved_tensors
+        ts, e, saves = sv[:7 * n], sv[7 * n:8 * n], sv[8 * n:9 * n]
+        dev, train, f32 = ts[0].device, bool(cfg["train"]), torch.float32
+        if any(d is None for d in dadj):
+            raise RuntimeError("map2adj_tail: every adjacency needs a gradient")
+        dadj = [d if d.is_contiguous() else _copy(d) for d in dadj]
+        items = _Map2AdjTail._items(cfg, ts, train, saves, None, e, dev, ctx.p)
+        arena = _arena(dev)
+        grads, keep = [], []
+        stream = _stream(ts[0])
+        for i in range(n):
+            t = items[i]
+            Kc = t.Kc
+            ws = int(_lib.lib().cg_map2adj_tail_ws_floats(Kc))
+            zb, _ = _zeros(ws, dev)
+            red = arena.take(2 * Kc + 1)
+            g = torch.empty_like(e[i])
+            keep += [g, zb]
+            ds, dq = torch.empty_like(ts[7 * i]), torch.empty_like(ts[7 * i + 1])
+            dw = torch.empty(2, Kc, Kc, dtype=f32, device=dev)
+            small = torch.empty(3, Kc, dtype=f32, device=dev)
+            t.dadj, t.g, t.red, t.ds, t.dq = dadj[i].data_ptr(), g.data_ptr(), red.data_ptr(), ds.data_ptr(), dq.data_ptr()
+            t.dW0_ws, t.dW4_ws = zb[:ws // 2].data_ptr(), zb[ws // 2:].data_ptr()
+            t.dW0, t.dW4, t.dgamma, t.dbeta, t.dalpha = dw[0].data_ptr(), dw[1].data_ptr(), small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
+            grads += [ds, dq, dw[0].view(ts[7 * i + 2].shape), small[0], small[1], small[2, :1].reshape(1), dw[1].view(ts[7 * i + 6].shape)]
+        for phase in (1, 2):
+            _lib.call("cg_map2adj_tail_bwd", items, n, phase, stream)
+        del keep
+        return (None,) + tuple(g if ctx.needs_input_grad[1 + k] else None for k, g in enumerate(grads))
+
+
+def map2adj_tail(seeds, expansors, train, drop_p=0.0, salts=(0, 0), taps=None):
+    """Adjacency maps of a block's towers.  seeds: (domain 0|1, s (B,V,T), q (B,T,V)) per tower; expansors: their `expansor`
+    holders (0: conv, 1: BatchNorm, 3: PReLU, 4: conv).  One launch per phase for all towers."""
+    cfg = {"train": bool(train), "drop_p": float(drop_p), "salts": tuple(int(s) for s in salts), "domains": tuple(int(d) for d, _, _ in seeds),
+           "bn": tuple(e[1] for e in expansors), "taps": taps}
+    ts = []
+    for (dom, s, q), e in zip(seeds, expansors):
+        kc = e[0].out_channels
+        ts += [s, q, e[0].weight.view(kc, kc), e[1].weight, e[1].bias, e[3].weight, e[4].weight.view(kc, kc)]
+    return _Map2AdjTail.apply(cfg, *ts)

@@ -227,6 +227,29 @@ int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream);
 int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream);
 long long cg_dstd_tail_ws_floats(int C);
 
+/* ---- tail of the interpretability map, Map2Adj.forward CISTGCN.py:183-189 (expansor :165-170) ------------------------
+ * s (B,V,T), q (B,T,V): outputs of the joint / time towers.  Seed o = s (x) q (space: o[b,v,t,u] = s[b,v,t] q[b,u,v];
+ * time: o[b,t,v,w] = s[b,v,t] q[b,t,w]) -> conv W0 over the slab axis -> BatchNorm -> Dropout -> PReLU -> conv W4 = Adj.
+ * The seed is generated inside the kernels, never stored.  `items`: the towers of a block sharing a launch (n <= 2, same B).
+ *   forward phase 1: e = W0 o + f64 channel sums | 2: Adj = W4 PReLU(Dropout(BN(e)))
+ *   backward phase 1: g = gradient in front of the BatchNorm, its sums, d alpha, dW4 | 2: d e, ds, dq, dW0, d gamma / d beta
+ * domain 0 (space): Kc = V, J = T; domain 1 (time): Kc = T, J = V; Kc, J <= 64.  `bn.stats`, `red`, `dW*_ws` zeroed by the caller. */
+typedef struct CgAdjTail {
+  int B, Kc, J, domain, train, pad0;
+  const float* s; const float* q;
+  const float* W0; CgTailBN bn; const float* alpha; const float* W4;
+  float drop_p; unsigned int salt; const unsigned long long* seed;
+  float* e; float* adj;          /* (B,Kc,J,J) */
+  float* tap;                    /* optional (B,Kc,J,J): PReLU output (diagnostics) */
+  const float* dadj; float* g; double* red;       /* g (B,Kc,J,J) scratch; red [2 Kc + 1] */
+  float* ds; float* dq;
+  float* dW0_ws; float* dW4_ws;  /* cg_map2adj_tail_ws_floats(Kc) / 2 floats each */
+  float* dW0; float* dW4; float* dgamma; float* dbeta; float* dalpha;
+} CgAdjTail;
+int cg_map2adj_tail_fwd(const CgAdjTail* items, int n, int phase, void* stream);
+int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, void* stream);
+long long cg_map2adj_tail_ws_floats(int Kc);
+
 /* ---- evaluation harness counterpart, environment/test.py:97-132 ----------------------
  * y[r,k,:] = x[r,idx[k],:] : `inputs[:, :, dim_used]` (32 -> 22 joints); x (rows,Jin,3), y (rows,Jout,3) contiguous */
 int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long rows, int Jin, int Jout, void* stream);

@@ -803,6 +803,59 @@ def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
+def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6))):
+    """ops.map2adj_tail (phase kernels of csrc/map2adj_tail.hip) against the same chain built from the rank-1 kernel, the
+    generic contraction and the row kernels (pinned to the oracle by the model tests): identical dropout draws, train and eval
+    mode, both adjacencies, the PReLU taps, every input / parameter gradient, running statistics.  shapes: (B, T, V)."""
+    from cistgcn_amd.models.CISTGCN.CISTGCN import Stage, _conv
+    g = _gen(47)
+    for (B, T, V) in shapes:
+        for train in (True, False):
+            def make():
+                gg = _gen(200 + B + T)
+                exps = []
+                for ch in (V, T):
+                    e = Stage(s0=_conv(ch, ch), s1=nn.BatchNorm2d(ch), s3=nn.PReLU(), s4=_conv(ch, ch))
+                    with torch.no_grad():
+                        e[0].weight.copy_(0.4 * torch.randn(e[0].weight.shape, generator=gg)); e[4].weight.copy_(0.4 * torch.randn(e[4].weight.shape, generator=gg))
+                        e[1].weight.copy_(1 + 0.3 * torch.randn(ch, generator=gg)); e[1].bias.copy_(0.3 * torch.randn(ch, generator=gg))
+                        e[1].running_mean.copy_(0.2 * torch.randn(ch, generator=gg)); e[1].running_var.copy_(0.5 + torch.rand(ch, generator=gg))
+                        e[3].weight.fill_(0.2 + 0.1 * len(exps))
+                    exps.append(e)
+                mods = nn.ModuleList(exps).to(device)
+                return list(mods), mods
+            data = [_rand(g, B, V, T), _rand(g, B, T, V), _rand(g, B, V, T), _rand(g, B, T, V)]
+            gouts = [_rand(g, B, V, T, T).to(device), _rand(g, B, T, V, V).to(device)]
+            results = []
+            for fused in (True, False):
+                exps, mods = make()
+                mods.train(train)
+                s0, q0, s1, q1 = [_leaf(t, device) for t in data]
+                seeds = [(0, s0, q0), (1, s1, q1)]
+                ops.manual_seed(4321, device)
+                ops.begin_step(device)
+                p = 0.25
+                if fused:
+                    taps = []
+                    adj = ops.map2adj_tail(seeds, exps, train, drop_p=p, salts=(5, 6), taps=taps)
+                else:
+                    oo = ops.rank1_adj(seeds)
+                    es = [ops.contract("oc,bchw->bohw", e[0].weight.view(e[0].out_channels, -1), o) for e, o in zip(exps, oo)]
+                    taps = ops.norm_act_many([dict(x=es[i], bn=e[1], train=train, drop_p=p, salt=5 + i, prelu=e[3]) for i, e in enumerate(exps)])
+                    adj = [ops.contract("oc,bchw->bohw", e[4].weight.view(e[4].out_channels, -1), h) for e, h in zip(exps, taps)]
+                torch.autograd.backward(list(adj), gouts)
+                grads = [t.grad for t in (s0, q0, s1, q1)] + [p_.grad for p_ in mods.parameters()]
+                results.append(([a.detach() for a in adj], [t.detach() for t in taps], grads, [b.clone() for b in mods.buffers()]))
+            what = "map2adj_tail B%d T%d V%d %s" % (B, T, V, "train" if train else "eval")
+            for k in range(2):
+                assert_close(results[0][0][k], results[1][0][k], "%s adj[%d]" % (what, k), rel=2e-5)
+                assert_close(results[0][1][k], results[1][1][k], "%s tap[%d]" % (what, k), rel=2e-5)
+            for k, (a, b) in enumerate(zip(results[0][2], results[1][2])):
+                assert_close(a, b, "%s grad[%d]" % (what, k), rel=5e-5, floor=max(1e-3, float(b.abs().max())))
+            for k, (a, b) in enumerate(zip(results[0][3], results[1][3])):
+                assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
+
+
 def check_flat_adam(device):
     """cg_adam_flat + FlatGrads against torch.optim.Adam with the reference's settings (weight decay, no amsgrad)."""
     from cistgcn_amd.runtime import FlatAdam

@@ -8,7 +8,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "cistgcn_amd", "csrc")
-OUT = os.path.join(HERE, "_build", "libcistgcn_emu.so")
+# HIPEMU_SANITIZE=1: AddressSanitizer build of the very same sources (run python under LD_PRELOAD=$(g++ -print-file-name=libasan.so)
+# with ASAN_OPTIONS=detect_leaks=0); the GPU pool offers no device sanitizer, this is where out-of-bounds indexing is hunted.
+SANITIZE = os.environ.get("HIPEMU_SANITIZE", "0") == "1"
+OUT = os.path.join(HERE, "_build", "libcistgcn_emu_asan.so" if SANITIZE else "libcistgcn_emu.so")
 
 
 def build(force=False):
@@ -32,15 +35,15 @@ def _build_locked(force):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     objs = []
     for s in srcs + [os.path.join(HERE, "emu_runtime.cpp")]:
-        o = os.path.join(HERE, "_build", os.path.basename(s) + ".o")
+        o = os.path.join(HERE, "_build", os.path.basename(s) + (".asan.o" if SANITIZE else ".o"))
         cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes",
-               "-I", HERE, "-I", CSRC, "-c", s, "-o", o]
+               "-I", HERE, "-I", CSRC, "-c", s, "-o", o] + (["-fsanitize=address", "-fno-omit-frame-pointer"] if SANITIZE else [])
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("g++ failed on %s:\n%s" % (s, res.stderr[-4000:]))
         objs.append(o)
     tmp = OUT + ".tmp.%d" % os.getpid()
-    res = subprocess.run(["g++", "-shared", "-pthread", "-o", tmp] + objs, capture_output=True, text=True)
+    res = subprocess.run(["g++", "-shared", "-pthread", "-o", tmp] + objs + (["-fsanitize=address"] if SANITIZE else []), capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("link failed:\n" + res.stderr[-4000:])
     os.replace(tmp, OUT)

@@ -66,6 +66,19 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
 }
 
 template <typename T>
+static inline T __shfl_up(T v, unsigned delta, int width = 64) {
+  static_assert(sizeof(T) <= 16, "shuffle payload");
+  const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64;
+  *reinterpret_cast<T*>(hipemu::wave_slot(wave, lane)) = v;
+  hipemu::wave_barrier(wave);
+  const int src = lane - (int)delta;
+  T r = v;
+  if (src >= 0 && (src / width) == (lane / width)) r = *reinterpret_cast<T*>(hipemu::wave_slot(wave, src));
+  hipemu::wave_barrier(wave);
+  return r;
+}
+
+template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
   static_assert(sizeof(T) <= 16, "shuffle payload");
   const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64;

@@ -25,3 +25,16 @@ def test_tiny_model_matches_oracle(mode):
 def test_tiny_model_every_gradient_strict():
     """all parameter gradients within 1e-4 * max(0.1, max|ref|) with the oracle on the branches the kernels took"""
     checks.check_model_branch_replay("cpu", 4, 4, 5, 2, "train", To=8, hidden=8, grad_floor=0.1)
+
+
+@pytest.mark.timeout(900)
+def test_model_survives_jit_trace():
+    """`writer.add_graph(model, batch)` (train.py:137) = `torch.jit.trace` with its default self-check, model in train mode
+    with dropout on: the hot path appears as one opaque node, the seed is not advanced while tracing (the tracer's check run
+    draws the same masks) and the traced module replays to the same prediction."""
+    import torch
+    net, _ = checks.build_pair(4, 4, 5, "cpu", To=8, hidden=8, dropout=0.1)
+    net.train()
+    x = 50 + 350 * torch.randn(2, 4, 5, 3, generator=torch.Generator().manual_seed(3))
+    traced = torch.jit.trace(net, x)
+    assert any(n.kind() == "prim::PythonOp" for n in traced.graph.nodes())
