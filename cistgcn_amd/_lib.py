@@ -98,7 +98,7 @@ class AdjTail(ctypes.Structure):
                 ("s", c_void_p), ("q", c_void_p), ("W0", c_void_p), ("bn", TailBN), ("alpha", c_void_p), ("W4", c_void_p),
                 ("drop_p", c_float), ("salt", c_uint), ("seed", c_void_p),
                 ("e", c_void_p), ("adj", c_void_p), ("tap", c_void_p),
-                ("dadj", c_void_p), ("g", c_void_p), ("red", c_void_p), ("ds", c_void_p), ("dq", c_void_p),
+                ("dadj", c_void_p), ("g", c_void_p), ("red", c_void_p), ("ds", c_void_p), ("dq", c_void_p), ("part", c_void_p),
                 ("dW0_ws", c_void_p), ("dW4_ws", c_void_p),
                 ("dW0", c_void_p), ("dW4", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("dalpha", c_void_p)]
 
@@ -147,6 +147,8 @@ _SIGNATURES = {
     "cg_map2adj_tail_fwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_bwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_ws_floats": [c_int],
+    "cg_map2adj_tail_part_floats": [c_int, c_int, c_int],
+    "cg_map2adj_tail_red_doubles": [c_int],
     "cg_augment_sequences": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }
@@ -158,7 +160,7 @@ def declare(handle):
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(handle, name)     # AttributeError if the library does not export it
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name.endswith("_ws_floats") else c_int
+        fn.restype = c_longlong if name.endswith(("_floats", "_doubles")) else c_int
     return handle
 
 

@@ -14,9 +14,11 @@ struct CgAdjTail {
   float* e; float* adj;                  // (B,Kc,J,J): first conv output (kept for the backward), the adjacency
   float* tap;                            // optional (B,Kc,J,J): output of the PReLU (diagnostics / branch records)
   // backward
-  const float* dadj; float* g; double* red;       // g (B,Kc,J,J) scratch; red [2 Kc + 1] f64, zero on entry
-  float* ds; float* dq;
+  const float* dadj; float* g; double* red;       // g (B,Kc,J,J) scratch; red: cg_map2adj_tail_red_doubles(Kc) f64 words, zero on entry
+  float* ds; float* dq; float* part;     // part: cg_map2adj_tail_part_floats(B, Kc, J) scratch
   float* dW0_ws; float* dW4_ws;          // cg_map2adj_tail_ws_floats(Kc) / 2 zeroed floats each
   float* dW0; float* dW4; float* dgamma; float* dbeta; float* dalpha;
 };
-struct CgAdjTailPair { int n, pad; CgAdjTail t[2]; };
+// launch geometry of one tower (internal): padded slab count, LDS strides, tile width (KcM * PT = 4096), chunking, magic divisors
+struct CgAdjGeom { int KcM, WS, JS, Pn, PT, PS, NP, lgq, ntiles, nch; unsigned magicJ, magicKc, magicPad; int tpw; };
+struct CgAdjTailPair { int n, nch_max, dbg, pad; CgAdjGeom g[2]; CgAdjTail t[2]; };   // dbg: tuning aid (CG_ADJ_DBG), phases of the backward kernels skipped

@@ -13,48 +13,72 @@
 #include "cg_common.h"
 #include "cg_phase.h"
 #include "map2adj_tail.h"
+#include <cstdlib>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
-#define CG_ADJ_PT 64
-#define CG_ADJ_PS (CG_ADJ_PT + 4)
+// tile of a workgroup: [KcM channels][PT positions] with KcM * PT = 4096 (16 floats per thread and staged tensor):
+// PT = 64 for 49..64 slabs, 128 for 17..32, 256 up to 16
 #define CG_ADJ_THREADS 256
-#define CG_ADJ_REPLICAS 16
+#define CG_ADJ_REPLICAS 32
 
-struct CgAdjGeom { int KcM, WS, JS, Pn; unsigned magicJ; };
+#define CG_ADJ_TPW_MAX 8                    // 64-position tiles per workgroup
 
-__device__ __forceinline__ CgAdjGeom cg_adj_geom(const CgAdjTail& t) {
-  CgAdjGeom g;
-  g.KcM = (t.Kc + 15) & ~15;
-  g.WS = g.KcM + 4;
-  g.JS = t.J + 1;                      // odd-ish row stride of the S / Q tables
-  g.Pn = t.J * t.J;
-  g.magicJ = t.J > 1 ? (unsigned)((0x100000000ULL + t.J - 1) / t.J) : 0u;
-  return g;
-}
+// geometry of a tower (host side, cg_adj_geometry): handed to the kernels next to the argument block
+__device__ __forceinline__ const CgAdjGeom& cg_adj_geom(const CgAdjTailPair& pr, int i) { return pr.g[i]; }
 __device__ __forceinline__ unsigned cg_adj_div(unsigned n, unsigned magic) { return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n; }
 
+// Staging loops: the global loads of four strides are issued together, then their LDS stores.
 // S[k][a], Q[k][b'] of sample b: [KcM][JS] tables, rows >= Kc zero
 __device__ __forceinline__ void cg_adj_tables(const CgAdjTail& t, const CgAdjGeom& g, int b, float* sS, float* sQ) {
-  const int V = t.domain == 0 ? t.Kc : t.J, T = t.domain == 0 ? t.J : t.Kc;
+  const int V = t.domain == 0 ? t.Kc : t.J, T = t.domain == 0 ? t.J : t.Kc, KJ = t.Kc * t.J;
   const float* sb = t.s + (long long)b * V * T;      // (V, T)
   const float* qb = t.q + (long long)b * T * V;      // (T, V)
-  for (int e = threadIdx.x; e < g.KcM * g.JS; e += CG_ADJ_THREADS) {
-    const int k = e / g.JS, a = e - k * g.JS;
-    float sv = 0.f, qv = 0.f;
-    if (k < t.Kc && a < t.J) {
-      if (t.domain == 0) { sv = sb[k * T + a]; qv = qb[a * V + k]; }       // k = joint: S = s[v][t], Q = q[tau][v]
-      else { sv = sb[a * T + k]; qv = qb[k * V + a]; }                     // k = frame: S = s[v][t], Q = q[t][w]
+  for (int i0 = threadIdx.x; i0 < KJ; i0 += 4 * CG_ADJ_THREADS) {
+    float sv[4], qv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + CG_ADJ_THREADS * j, k = (int)cg_adj_div((unsigned)i, g.magicJ), a = i - k * t.J;
+      sv[j] = qv[j] = 0.f;
+      if (i < KJ) {
+        if (t.domain == 0) { sv[j] = sb[k * T + a]; qv[j] = qb[a * V + k]; }       // k = joint: S = s[v][t], Q = q[tau][v]
+        else { sv[j] = sb[a * T + k]; qv[j] = qb[k * V + a]; }                     // k = frame: S = s[v][t], Q = q[t][w]
+      }
     }
-    sS[e] = sv; sQ[e] = qv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + CG_ADJ_THREADS * j, k = (int)cg_adj_div((unsigned)i, g.magicJ), a = i - k * t.J;
+      if (i < KJ) { sS[k * g.JS + a] = sv[j]; sQ[k * g.JS + a] = qv[j]; }
+    }
   }
+  for (int e = t.Kc * g.JS + threadIdx.x; e < g.KcM * g.JS; e += CG_ADJ_THREADS) { sS[e] = 0.f; sQ[e] = 0.f; }
 }
 
-__device__ __forceinline__ void cg_adj_weight(const float* __restrict__ W, int Kc, int KcM, int WS, float* sW) {
-  for (int e = threadIdx.x; e < KcM * WS; e += CG_ADJ_THREADS) {
-    const int r = e / WS, c = e - r * WS;
-    sW[e] = (r < Kc && c < Kc) ? W[r * Kc + c] : 0.f;
+// W (Kc x Kc) -> sW [KcM][WS], padding zero
+__device__ __forceinline__ void cg_adj_weight(const float* __restrict__ W, const CgAdjTail& t, const CgAdjGeom& g, float* sW) {
+  const int n = t.Kc * t.Kc, padw = g.WS - t.Kc;
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * CG_ADJ_THREADS) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int i = i0 + CG_ADJ_THREADS * j; v[j] = i < n ? W[i] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + CG_ADJ_THREADS * j, r = (int)cg_adj_div((unsigned)i, g.magicKc);
+      if (i < n) sW[r * g.WS + i - r * t.Kc] = v[j];
+    }
   }
+  for (int i = threadIdx.x; i < t.Kc * padw; i += CG_ADJ_THREADS) {            // columns Kc .. WS - 1 of the rows < Kc
+    const int r = (int)cg_adj_div((unsigned)i, g.magicPad);
+    sW[r * g.WS + t.Kc + i - r * padw] = 0.f;
+  }
+  for (int e = t.Kc * g.WS + threadIdx.x; e < g.KcM * g.WS; e += CG_ADJ_THREADS) sW[e] = 0.f;
+}
+
+// rows Kc .. KcM - 1 of `count` consecutive [KcM][PS] tile images: never written by the staging, read by the fragments
+__device__ __forceinline__ void cg_adj_zero_pad_rows(const CgAdjTail& t, const CgAdjGeom& g, float* img, int count) {
+  const int n = (g.KcM - t.Kc) * g.PS;
+  for (int c = 0; c < count; ++c)
+    for (int e = threadIdx.x; e < n; e += CG_ADJ_THREADS) img[(c * g.KcM + t.Kc) * g.PS + e] = 0.f;
 }
 
 // generated fragment of the seed for 16-wide k chunk k0: v[s] = S[k][a] Q[k][b'], k = k0 + 4*slot + s
@@ -71,21 +95,24 @@ __device__ __forceinline__ void cg_adj_seed_frag_k(const float* sS, const float*
 // ======================================================================================================================
 __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair pr) {
   const CgAdjTail& t = pr.t[blockIdx.y];
-  const CgAdjGeom g = cg_adj_geom(t);
-  const int b = blockIdx.x;
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
+  if (ch >= g.nch) return;
+  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
   float* sS = reinterpret_cast<float*>(cg_dyn_lds);
   float* sQ = sS + g.KcM * g.JS;
   float* sW = sQ + g.KcM * g.JS;
   double* sStat = reinterpret_cast<double*>(sW + g.KcM * g.WS + ((g.KcM * g.JS * 2 + g.KcM * g.WS) & 1));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
   cg_adj_tables(t, g, b, sS, sQ);
-  cg_adj_weight(t.W0, t.Kc, g.KcM, g.WS, sW);
+  cg_adj_weight(t.W0, t, g, sW);
   for (int e = tid; e < 2 * g.KcM; e += CG_ADJ_THREADS) sStat[e] = 0.0;
   __syncthreads();
-  const int MT = g.KcM / 16, ntiles = (g.Pn + CG_ADJ_PT - 1) / CG_ADJ_PT;
+  const int MT = g.KcM / 16;
   float* eb = t.e + (long long)b * t.Kc * g.Pn;
-  for (int w = wave; w < ntiles * MT * 2; w += CG_ADJ_THREADS / 64) {       // (tile, u tile, pair of position tiles)
-    const int tile = w / (MT * 2), r = w - tile * (MT * 2), mt = r >> 1, p0 = tile * CG_ADJ_PT + 32 * (r & 1);
+  const int P0 = tile0 * g.PT, ngroups = (min(g.Pn, tile1 * g.PT) - P0 + 31) / 32;
+  for (int w = wave; w < ngroups * MT; w += CG_ADJ_THREADS / 64) {       // (group of 32 positions, u tile)
+    const int grp = w / MT, mt = w - grp * MT, p0 = P0 + 32 * grp;
     const int pa = p0 + l15, pb = p0 + 16 + l15;
     const int aa = (int)cg_adj_div((unsigned)pa, g.magicJ), ab = (int)cg_adj_div((unsigned)pb, g.magicJ);
     const bool oka = pa < g.Pn, okb = pb < g.Pn;
@@ -110,9 +137,7 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
       if (uok && oka) eb[(long long)u * g.Pn + pa] = v0;
       if (uok && okb) eb[(long long)u * g.Pn + pb] = v1;
       if (t.train) {
-        float s1 = v0 + v1, s2 = v0 * v0 + v1 * v1;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        const float s1 = cg_row16_sum(v0 + v1), s2 = cg_row16_sum(v0 * v0 + v1 * v1);
         if (l15 == 0 && uok) { atomicAdd(&sStat[2 * u], (double)s1); atomicAdd(&sStat[2 * u + 1], (double)s2); }
       }
     }
@@ -124,15 +149,23 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
   }
 }
 
-// per-channel constants [KcM][8]: mean, rstd, scale = gamma * rstd, beta, m1, m2 (backward), -, -
+// `red` ([CG_ADJ_REPLICAS][2 Kc + 1] f64: sums of g and g e_hat per channel, d alpha) summed over its replicas
+__device__ __forceinline__ double cg_adj_red(const CgAdjTail& t, int i) {
+  double s = 0.0;
+  for (int r = 0; r < CG_ADJ_REPLICAS; ++r) s += t.red[(long long)r * (2 * t.Kc + 1) + i];
+  return s;
+}
+
+// per-channel constants [KcM][8]: mean, rstd, scale = gamma * rstd, beta, m1, m2 (backward), gamma, -
 __device__ __forceinline__ void cg_adj_consts(const CgAdjTail& t, const CgAdjGeom& g, float* sK, bool backward, bool owner) {
   const double cnt = (double)t.B * g.Pn;
   for (int c = threadIdx.x; c < t.Kc; c += CG_ADJ_THREADS) {
     const CgAff a = cg_tail_aff(t.bn, c, t.Kc, cnt, t.train, backward, owner);
     float* k = sK + 8 * c;
     k[0] = a.mean; k[1] = a.rstd; k[2] = a.gamma * a.rstd; k[3] = a.beta;
-    k[4] = (backward && t.train) ? (float)(t.red[2 * c] / cnt) : 0.f;
-    k[5] = (backward && t.train) ? (float)(t.red[2 * c + 1] / cnt) : 0.f;
+    k[4] = (backward && t.train) ? (float)(cg_adj_red(t, 2 * c) / cnt) : 0.f;
+    k[5] = (backward && t.train) ? (float)(cg_adj_red(t, 2 * c + 1) / cnt) : 0.f;
+    k[6] = a.gamma;
   }
 }
 
@@ -141,82 +174,104 @@ __device__ __forceinline__ float cg_adj_keep(const CgAdjTail& t, unsigned long l
   return cg_drop_scale(t.drop_p, seed, t.salt, (unsigned long long)idx);
 }
 
-// stage one [Kc][64-position] tile of a (B,Kc,J,J) tensor through `fn(value, channel, flat index)` into an LDS image
-template <typename F>
-__device__ __forceinline__ void cg_adj_stage(const CgAdjTail& t, const CgAdjGeom& g, const float* __restrict__ src, int b, int p0, float* img, F fn) {
-  const int np = min(CG_ADJ_PT, g.Pn - p0);
-  if ((g.Pn & 3) == 0) {
-#pragma unroll 2
-    for (int e = threadIdx.x; e < t.Kc * (CG_ADJ_PT / 4); e += CG_ADJ_THREADS) {
-      const int c = e / (CG_ADJ_PT / 4), pp = 4 * (e - c * (CG_ADJ_PT / 4));
-      float val[4] = {0.f, 0.f, 0.f, 0.f};
-      if (pp < np) {
-        const long long off = ((long long)b * t.Kc + c) * g.Pn + p0 + pp;
-        const float4 x4 = *reinterpret_cast<const float4*>(src + off);
-        fn(x4, c, off, val);
-      }
-      *reinterpret_cast<float4*>(img + c * CG_ADJ_PS + pp) = make_float4(val[0], val[1], val[2], val[3]);
+// ---- pipelined staging: a thread's share of one [Kc][64-position] tile travels global -> registers (issued a tile ahead, in flight
+// during the matrix work) -> transform -> LDS.  VEC (J*J % 4 == 0): float4 number r of the thread is element 4 * (tid + 256 r) of the
+// tile image; otherwise scalar number j is element tid + 256 j.
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_fetch(const CgAdjGeom& g, const float* __restrict__ src, int Kc, int Pn, int p0, int np, float buf[16]) {
+  if (VEC) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < Kc && pp < np) v = *reinterpret_cast<const float4*>(src + (long long)c * Pn + p0 + pp);
+      buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
     }
   } else {
-    for (int e = threadIdx.x; e < t.Kc * CG_ADJ_PT; e += CG_ADJ_THREADS) {
-      const int c = e / CG_ADJ_PT, pp = e - c * CG_ADJ_PT;
-      float val[4] = {0.f, 0.f, 0.f, 0.f};
-      if (pp < np) {
-        const long long off = ((long long)b * t.Kc + c) * g.Pn + p0 + pp;
-        fn(make_float4(src[off], 0.f, 0.f, 0.f), c, -off - 1, val);        // negative index: scalar element `-(idx) - 1`
-      }
-      img[c * CG_ADJ_PS + pp] = val[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (g.lgq + 2), pp = e & (g.PT - 1);
+      buf[j] = (c < Kc && pp < np) ? src[(long long)c * Pn + p0 + pp] : 0.f;
     }
   }
+}
+// fn(c, pp, ok, off): channel c < Kc, tile position pp of staging register number `off` (4 consecutive positions with VEC, else 1);
+// ok: inside the tensor
+template <bool VEC, typename F>
+__device__ __forceinline__ void cg_adj_commit(const CgAdjGeom& g, int Kc, int np, F fn) {
+  if (VEC) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+      if (c < Kc) fn(c, pp, pp < np, 4 * r);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (g.lgq + 2), pp = e & (g.PT - 1);
+      if (c < Kc) fn(c, pp, pp < np, j);
+    }
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_keeps(const CgAdjTail& t, bool drop, unsigned long long seed, long long idx, float keep[4]) {
+  if (VEC) cg_keep4(drop, t.drop_p, seed, t.salt, (unsigned long long)idx, keep);
+  else keep[0] = drop ? cg_drop_scale(t.drop_p, seed, t.salt, (unsigned long long)idx) : 1.f;
+}
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_put(const CgAdjGeom& g, float* img, int c, int pp, const float v[4]) {
+  if (VEC) *reinterpret_cast<float4*>(img + c * g.PS + pp) = make_float4(v[0], v[1], v[2], v[3]);
+  else img[c * g.PS + pp] = v[0];
 }
 
 // ======================================================================================================================
 // M2: Adj[u'][p] = sum_u W4[u'][u] h[u][p],  h = PReLU(Dropout(BN(e)))
 // ======================================================================================================================
-__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_m2_kernel(CgAdjTailPair pr) {
-  const CgAdjTail& t = pr.t[blockIdx.y];
-  const CgAdjGeom g = cg_adj_geom(t);
-  const int b = blockIdx.x;
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_m2_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int tile0, int tile1, bool owner) {
   float* sH = reinterpret_cast<float*>(cg_dyn_lds);              // [KcM][PS]
-  float* sW = sH + g.KcM * CG_ADJ_PS;                             // [KcM][WS]
+  float* sW = sH + g.KcM * g.PS;                             // [KcM][WS]
   float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
-  for (int e = tid; e < g.KcM * CG_ADJ_PS; e += CG_ADJ_THREADS) sH[e] = 0.f;
-  cg_adj_weight(t.W4, t.Kc, g.KcM, g.WS, sW);
-  cg_adj_consts(t, g, sK, false, b == 0);
-  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
-  const float alpha = t.alpha[0];
+  constexpr int N = VEC ? 4 : 1;
+  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
+  float ebuf[16];
+  cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, tile0 * g.PT, min(g.PT, g.Pn - tile0 * g.PT), ebuf);
+  cg_adj_zero_pad_rows(t, g, sH, 1);
+  cg_adj_weight(t.W4, t, g, sW);
+  cg_adj_consts(t, g, sK, false, owner);
   const bool drop = t.train && t.drop_p > 0.f;
-  const int MT = g.KcM / 16, ntiles = (g.Pn + CG_ADJ_PT - 1) / CG_ADJ_PT;
+  const unsigned long long seed = drop ? *t.seed : 0ull;
+  const float alpha = t.alpha[0];
+  const int MT = g.KcM / 16;
   float* ab = t.adj + (long long)b * t.Kc * g.Pn;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int p0 = tile * CG_ADJ_PT, np = min(CG_ADJ_PT, g.Pn - p0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
     __syncthreads();
-    cg_adj_stage(t, g, t.e, b, p0, sH, [&](float4 x4, int c, long long idx, float val[4]) {
+    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
       const float* k = sK + 8 * c;
-      if (idx >= 0) {
-        float keep[4];
-        cg_keep4(drop, t.drop_p, seed, t.salt, (unsigned long long)idx, keep);
-        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+      const long long idx = ((long long)b * t.Kc + c) * g.Pn + p0 + pp;
+      float keep[4], v[4];
+      cg_adj_keeps<VEC>(t, drop && ok, seed, idx, keep);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) val[j] = cg_prelu(((xv[j] - k[0]) * k[2] + k[3]) * keep[j], alpha);
-      } else val[0] = cg_prelu(((x4.x - k[0]) * k[2] + k[3]) * cg_adj_keep(t, seed, -idx - 1), alpha);
+      for (int j = 0; j < N; ++j) v[j] = ok ? cg_prelu(((ebuf[off + j] - k[0]) * k[2] + k[3]) * keep[j], alpha) : 0.f;
+      cg_adj_put<VEC>(g, sH, c, pp, v);
+      if (t.tap && ok) {
+        if (VEC) *reinterpret_cast<float4*>(t.tap + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        else t.tap[idx] = v[0];
+      }
     });
     __syncthreads();
-    if (t.tap)
-      for (int e = tid; e < t.Kc * CG_ADJ_PT; e += CG_ADJ_THREADS) {
-        const int c = e / CG_ADJ_PT, pp = e - c * CG_ADJ_PT;
-        if (pp < np) t.tap[((long long)b * t.Kc + c) * g.Pn + p0 + pp] = sH[c * CG_ADJ_PS + pp];
-      }
-    for (int w = wave; w < MT * 2; w += CG_ADJ_THREADS / 64) {
-      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+    if (tile + 1 < tile1) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0 + g.PT, min(g.PT, g.Pn - p0 - g.PT), ebuf);
+    for (int w = wave; w < MT * g.NP; w += CG_ADJ_THREADS / 64) {
+      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
       const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * g.WS, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sH + n0, CG_ADJ_PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sH + n1, CG_ADJ_PS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sH + n0, g.PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sH + n1, g.PS, l15, slot);
       for (int k0 = 0; k0 < g.KcM; k0 += 16) {
         float av[4], b0v[4], b1v[4];
-        cg_tfrag<0>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, CG_ADJ_PS, k0, b0v); cg_tfrag<1>(bp1, CG_ADJ_PS, k0, b1v);
+        cg_tfrag<0>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
@@ -234,80 +289,109 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_m2_kernel(CgAdjTailP
   }
 }
 
+__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_m2_kernel(CgAdjTailPair pr) {
+  const CgAdjTail& t = pr.t[blockIdx.y];
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
+  if (ch >= g.nch) return;
+  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
+  if ((g.Pn & 3) == 0) cg_adj_m2_body<true>(t, g, b, tile0, tile1, blockIdx.x == 0);
+  else cg_adj_m2_body<false>(t, g, b, tile0, tile1, blockIdx.x == 0);
+}
+
 // ======================================================================================================================
 // N1: dh = W4^T dAdj;  g = dh PReLU'(u) keep -> HBM;  red = { sum g, sum g e_hat }, d alpha;  dW4 += dAdj h^T
 // ======================================================================================================================
-__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n1_kernel(CgAdjTailPair pr) {
-  const CgAdjTail& t = pr.t[blockIdx.y];
-  const CgAdjGeom g = cg_adj_geom(t);
-  const int b = blockIdx.x;
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int tile0, int tile1, int dbg) {
   float* sE = reinterpret_cast<float*>(cg_dyn_lds);              // [KcM][PS] e_hat
-  float* sD = sE + g.KcM * CG_ADJ_PS;                             // [KcM][PS] dAdj
-  float* sW = sD + g.KcM * CG_ADJ_PS;                             // [KcM][WS] W4
+  float* sP = sE + g.KcM * g.PS;                             // [KcM][PS] dropout keep factors
+  float* sD = sP + g.KcM * g.PS;                             // [KcM][PS] dAdj
+  float* sW = sD + g.KcM * g.PS;                             // [KcM][WS] W4
   float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
   double* sRed = reinterpret_cast<double*>(sK + 8 * g.KcM);       // [KcM][2] + [1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
-  for (int e = tid; e < 2 * g.KcM * CG_ADJ_PS; e += CG_ADJ_THREADS) sE[e] = 0.f;
+  constexpr int N = VEC ? 4 : 1;
+  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
+  const float* db = t.dadj + (long long)b * t.Kc * g.Pn;
+  float ebuf[16], dbuf[16];
+  {
+    const int p0 = tile0 * g.PT, np = min(g.PT, g.Pn - p0);
+    cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0, np, ebuf);
+    cg_adj_fetch<VEC>(g, db, t.Kc, g.Pn, p0, np, dbuf);
+  }
+  cg_adj_zero_pad_rows(t, g, sE, 3);
   for (int e = tid; e < 2 * g.KcM + 1; e += CG_ADJ_THREADS) sRed[e] = 0.0;
-  cg_adj_weight(t.W4, t.Kc, g.KcM, g.WS, sW);
+  cg_adj_weight(t.W4, t, g, sW);
   cg_adj_consts(t, g, sK, true, false);
-  const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const bool drop = t.train && t.drop_p > 0.f;
+  const unsigned long long seed = drop ? *t.seed : 0ull;
   const float alpha = t.alpha[0];
-  const bool drop = t.train && t.drop_p > 0.f, vec = (g.Pn & 3) == 0;
-  const int MT = g.KcM / 16, ntiles = (g.Pn + CG_ADJ_PT - 1) / CG_ADJ_PT;
+  const int MT = g.KcM / 16;
   cg_f32x4 wacc[CG_ADJ_MAXW];
 #pragma unroll
   for (int u = 0; u < CG_ADJ_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   float* gb = t.g + (long long)b * t.Kc * g.Pn;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int p0 = tile * CG_ADJ_PT, np = min(CG_ADJ_PT, g.Pn - p0);
-    __syncthreads();
-    cg_adj_stage(t, g, t.e, b, p0, sE, [&](float4 x4, int c, long long idx, float val[4]) {
-      const float* k = sK + 8 * c;
-      const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+  float racc[2][4][2], sa = 0.f;                   // per lane: sums of g and g e_hat of the wave's (at most two) dh tasks, d alpha
 #pragma unroll
-      for (int j = 0; j < 4; ++j) val[j] = (xv[j] - k[0]) * k[1];
-    });
-    cg_adj_stage(t, g, t.dadj, b, p0, sD, [&](float4 x4, int c, long long idx, float val[4]) { val[0] = x4.x; val[1] = x4.y; val[2] = x4.z; val[3] = x4.w; });
+  for (int i = 0; i < 16; ++i) (&racc[0][0][0])[i] = 0.f;
+  if (dbg & 64) tile1 = tile0;
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
     __syncthreads();
-    // dW4[u'][u] += sum_p dAdj[u'][p] h[u][p],  h rebuilt from e_hat in the B fragments (lane = channel u)
+    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
+      const float* k = sK + 8 * c;
+      float keep[4], v[4], d[4];
+      cg_adj_keeps<VEC>(t, drop && ok, seed, ((long long)b * t.Kc + c) * g.Pn + p0 + pp, keep);
+#pragma unroll
+      for (int j = 0; j < N; ++j) { v[j] = ok ? (ebuf[off + j] - k[0]) * k[1] : 0.f; keep[j] = ok ? keep[j] : 0.f; d[j] = dbuf[off + j]; }
+      cg_adj_put<VEC>(g, sE, c, pp, v);
+      cg_adj_put<VEC>(g, sP, c, pp, keep);
+      cg_adj_put<VEC>(g, sD, c, pp, d);
+    });
+    __syncthreads();
+    if (tile + 1 < tile1 && !(dbg & 8)) {
+      const int q0 = p0 + g.PT, nq = min(g.PT, g.Pn - q0);
+      cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, q0, nq, ebuf);
+      cg_adj_fetch<VEC>(g, db, t.Kc, g.Pn, q0, nq, dbuf);
+    }
+    // dW4[u'][u] += sum_p dAdj[u'][p] h[u][p],  h rebuilt from e_hat and the keep factors in the B fragments (lane = channel u)
 #pragma unroll
     for (int u = 0; u < CG_ADJ_MAXW; ++u) {
       const int id = u * nw + wave;
-      if (id < MT * MT) {
+      if (id < MT * MT && !(dbg & 1)) {
         const int mt = id / MT, n2 = id - mt * MT, cu = 16 * n2 + l15;
         const bool cok = cu < t.Kc;
-        const float gam = cok ? t.bn.gamma[cu] : 0.f, bet = cok ? t.bn.beta[cu] : 0.f;
-        const float* ap = cg_tfrag_ptr<0>(sD + 16 * mt * CG_ADJ_PS, CG_ADJ_PS, l15, slot);
-        const float* bp = cg_tfrag_ptr<0>(sE + 16 * n2 * CG_ADJ_PS, CG_ADJ_PS, l15, slot);
-        for (int k0 = 0; k0 < CG_ADJ_PT; k0 += 16) {
+        const float gam = cok ? sK[8 * cu + 6] : 0.f, bet = cok ? sK[8 * cu + 3] : 0.f;
+        const float* ap = cg_tfrag_ptr<0>(sD + 16 * mt * g.PS, g.PS, l15, slot);
+        const float* bp = cg_tfrag_ptr<0>(sE + 16 * n2 * g.PS, g.PS, l15, slot);
+        const float* kp = cg_tfrag_ptr<0>(sP + 16 * n2 * g.PS, g.PS, l15, slot);
+#pragma unroll 4
+        for (int k0 = 0; k0 < g.PT; k0 += 16) {
           float av[4], bv[4], keep[4];
-          cg_tfrag<0>(ap, CG_ADJ_PS, k0, av); cg_tfrag<0>(bp, CG_ADJ_PS, k0, bv);
-          const long long idx = ((long long)b * t.Kc + (cok ? cu : 0)) * g.Pn + p0 + k0 + 4 * slot;
-          if (vec) cg_keep4(drop, t.drop_p, seed, t.salt, (unsigned long long)idx, keep);
-          else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) keep[s] = cg_adj_keep(t, seed, idx + s);
-          }
+          cg_tfrag<0>(ap, g.PS, k0, av); cg_tfrag<0>(bp, g.PS, k0, bv); cg_tfrag<0>(kp, g.PS, k0, keep);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            // positions beyond the tile: dAdj is zero there, the product vanishes
-            const float h = cok ? cg_prelu((gam * bv[s] + bet) * keep[s], alpha) : 0.f;
+            // rows of channels >= Kc and positions beyond the tensor hold keep = 0: h = 0
+            const float h = cg_prelu((gam * bv[s] + bet) * keep[s], alpha);
             wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], h, wacc[u], 0, 0, 0);
           }
         }
       }
     }
     // dh[u][p] = sum_u' W4[u'][u] dAdj[u'][p]
-    for (int w = wave; w < MT * 2; w += nw) {
-      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      const int w = wave + nw * ti;
+      if (w >= MT * g.NP || (dbg & 2)) break;
+      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
       const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sD + n0, CG_ADJ_PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sD + n1, CG_ADJ_PS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sD + n0, g.PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sD + n1, g.PS, l15, slot);
       for (int k0 = 0; k0 < g.KcM; k0 += 16) {
         float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, CG_ADJ_PS, k0, b0v); cg_tfrag<1>(bp1, CG_ADJ_PS, k0, b1v);
+        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
@@ -318,31 +402,42 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n1_kernel(CgAdjTailP
       for (int q = 0; q < 4; ++q) {
         const int u = 16 * mt + 4 * slot + q;
         const bool uok = u < t.Kc;
-        const float gam = uok ? t.bn.gamma[u] : 0.f, bet = uok ? t.bn.beta[u] : 0.f;
-        float s1 = 0.f, s2 = 0.f, sa = 0.f;
+        const float gam = uok ? sK[8 * u + 6] : 0.f, bet = uok ? sK[8 * u + 3] : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pp = (h ? n1 : n0) + l15;
           const float dh = h ? c1[q] : c0[q];
           if (uok && pp < np) {
-            const long long idx = ((long long)b * t.Kc + u) * g.Pn + p0 + pp;
-            const float eh = sE[u * CG_ADJ_PS + pp], keep = cg_adj_keep(t, seed, idx);
+            const float eh = sE[u * g.PS + pp], keep = sP[u * g.PS + pp];
             const float upre = (gam * eh + bet) * keep;
             const float gg = (upre > 0.f ? dh : alpha * dh) * keep;
             gb[(long long)u * g.Pn + p0 + pp] = gg;
-            s1 += gg; s2 += gg * eh;
+            racc[ti][q][0] += gg; racc[ti][q][1] += gg * eh;
             if (!(upre > 0.f)) sa += dh * upre;
           }
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); sa += __shfl_xor(sa, off, 64); }
-        if (l15 == 0 && uok) { atomicAdd(&sRed[2 * u], (double)s1); atomicAdd(&sRed[2 * u + 1], (double)s2); atomicAdd(&sRed[2 * g.KcM], (double)sa); }
       }
     }
   }
+  // one cross-lane reduction for all tiles of the workgroup (rows of 16 lanes hold the positions of a channel)
+  sa = cg_row16_sum(sa);
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    const int w = wave + nw * ti;
+    if (w >= MT * g.NP) break;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int u = 16 * (w / g.NP) + 4 * slot + q;
+      const float s1 = cg_row16_sum(racc[ti][q][0]), s2 = cg_row16_sum(racc[ti][q][1]);
+      if (l15 == 0 && u < t.Kc) { atomicAdd(&sRed[2 * u], (double)s1); atomicAdd(&sRed[2 * u + 1], (double)s2); }
+    }
+  }
+  if (l15 == 0) atomicAdd(&sRed[2 * g.KcM], (double)sa);
   __syncthreads();
-  for (int e = tid; e < 2 * t.Kc; e += CG_ADJ_THREADS) atomicAdd(&t.red[e], sRed[e]);
-  if (tid == 0) atomicAdd(&t.red[2 * t.Kc], sRed[2 * g.KcM]);
+  if (dbg & 32) return;
+  double* red = t.red + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * (2 * t.Kc + 1);
+  for (int e = tid; e < 2 * t.Kc; e += CG_ADJ_THREADS) atomicAdd(&red[e], sRed[e]);
+  if (tid == 0) atomicAdd(&red[2 * t.Kc], sRed[2 * g.KcM]);
   float* dW = t.dW4_ws + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * t.Kc * t.Kc;
 #pragma unroll
   for (int u = 0; u < CG_ADJ_MAXW; ++u) {
@@ -358,57 +453,76 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n1_kernel(CgAdjTailP
   }
 }
 
+__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n1_kernel(CgAdjTailPair pr) {
+  const CgAdjTail& t = pr.t[blockIdx.y];
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
+  if (ch >= g.nch) return;
+  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
+  if ((g.Pn & 3) == 0) cg_adj_n1_body<true>(t, g, b, tile0, tile1, pr.dbg);
+  else cg_adj_n1_body<false>(t, g, b, tile0, tile1, pr.dbg);
+}
+
 // ======================================================================================================================
 // N2: de = BN'(g);  do = W0^T de;  dS[k][a] += do Q[k][b'],  dQ[k][b'] += do S[k][a];  dW0 += de (S x Q)^T
 // ======================================================================================================================
-__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailPair pr) {
-  const CgAdjTail& t = pr.t[blockIdx.y];
-  const CgAdjGeom g = cg_adj_geom(t);
-  const int b = blockIdx.x;
+template <bool VEC>
+__device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int ch, int tile0, int tile1, int dbg) {
   float* sS = reinterpret_cast<float*>(cg_dyn_lds);
   float* sQ = sS + g.KcM * g.JS;
-  float* sDS = sQ + g.KcM * g.JS;                                 // accumulators
-  float* sDQ = sDS + g.KcM * g.JS;
-  float* sDE = sDQ + g.KcM * g.JS;                                // [KcM][PS]
-  float* sW = sDE + g.KcM * CG_ADJ_PS;                            // [KcM][WS] W0
+  float* sDS = sQ + g.KcM * g.JS;                                 // dS of this chunk (few LDS atomics: one per run of equal a)
+  float* sDQ = sDS + g.KcM * g.JS;                                // dQ of this chunk: cell (k, b') belongs to one thread, plain updates
+  float* sDE = sDQ + g.KcM * g.JS;                                // [KcM][PS] de
+  float* sDO = sDE + g.KcM * g.PS;                           // [KcM][PS] do
+  float* sW = sDO + g.KcM * g.PS;                            // [KcM][WS] W0
   float* sK = sW + g.KcM * g.WS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
+  constexpr int N = VEC ? 4 : 1;
+  const float* gsrc = t.g + (long long)b * t.Kc * g.Pn;
+  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
+  float gbuf[16], ebuf[16];
+  {
+    const int p0 = tile0 * g.PT, np = min(g.PT, g.Pn - p0);
+    cg_adj_fetch<VEC>(g, gsrc, t.Kc, g.Pn, p0, np, gbuf);
+    if (t.train) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0, np, ebuf);
+  }
   cg_adj_tables(t, g, b, sS, sQ);
-  for (int e = tid; e < 2 * g.KcM * g.JS + g.KcM * CG_ADJ_PS; e += CG_ADJ_THREADS) sDS[e] = 0.f;
-  cg_adj_weight(t.W0, t.Kc, g.KcM, g.WS, sW);
+  for (int e = tid; e < 2 * g.KcM * g.JS; e += CG_ADJ_THREADS) sDS[e] = 0.f;
+  cg_adj_zero_pad_rows(t, g, sDE, 2);
+  cg_adj_weight(t.W0, t, g, sW);
   cg_adj_consts(t, g, sK, true, false);
-  const int MT = g.KcM / 16, ntiles = (g.Pn + CG_ADJ_PT - 1) / CG_ADJ_PT;
+  const int MT = g.KcM / 16, KJ = t.Kc * t.J;
   cg_f32x4 wacc[CG_ADJ_MAXW];
 #pragma unroll
   for (int u = 0; u < CG_ADJ_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* ebase = t.e + (long long)b * t.Kc * g.Pn;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int p0 = tile * CG_ADJ_PT, np = min(CG_ADJ_PT, g.Pn - p0);
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
     __syncthreads();
-    cg_adj_stage(t, g, t.g, b, p0, sDE, [&](float4 x4, int c, long long idx, float val[4]) {
+    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
       const float* k = sK + 8 * c;
-      const float gv[4] = {x4.x, x4.y, x4.z, x4.w};
-      if (!t.train) {
+      float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) val[j] = gv[j] * k[2];
-        return;
-      }
-      const long long off = idx >= 0 ? idx : -idx - 1;
-      const float* ep = t.e + off;
-      const int n = idx >= 0 ? 4 : 1;
-      for (int j = 0; j < n; ++j) val[j] = k[2] * (gv[j] - k[4] - (ep[j] - k[0]) * k[1] * k[5]);
+      for (int j = 0; j < N; ++j)
+        v[j] = !ok ? 0.f : t.train ? k[2] * (gbuf[off + j] - k[4] - (ebuf[off + j] - k[0]) * k[1] * k[5]) : gbuf[off + j] * k[2];
+      cg_adj_put<VEC>(g, sDE, c, pp, v);
     });
     __syncthreads();
+    if (tile + 1 < tile1 && !(dbg & 8)) {
+      const int q0 = p0 + g.PT, nq = min(g.PT, g.Pn - q0);
+      cg_adj_fetch<VEC>(g, gsrc, t.Kc, g.Pn, q0, nq, gbuf);
+      if (t.train) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, q0, nq, ebuf);
+    }
     // dW0[u][k] += sum_p de[u][p] o[k][p]: the seed generated along p in the B fragments (lane = slab k)
 #pragma unroll
     for (int u = 0; u < CG_ADJ_MAXW; ++u) {
       const int id = u * nw + wave;
-      if (id < MT * MT) {
+      if (id < MT * MT && !(dbg & 1)) {
         const int mt = id / MT, n2 = id - mt * MT, kk = 16 * n2 + l15;
-        const float* ap = cg_tfrag_ptr<0>(sDE + 16 * mt * CG_ADJ_PS, CG_ADJ_PS, l15, slot);
-        for (int k0 = 0; k0 < CG_ADJ_PT; k0 += 16) {
+        const float* ap = cg_tfrag_ptr<0>(sDE + 16 * mt * g.PS, g.PS, l15, slot);
+#pragma unroll 4
+        for (int k0 = 0; k0 < g.PT; k0 += 16) {
           float av[4];
-          cg_tfrag<0>(ap, CG_ADJ_PS, k0, av);
+          cg_tfrag<0>(ap, g.PS, k0, av);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int p = p0 + k0 + 4 * slot + s;
@@ -419,16 +533,16 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailP
         }
       }
     }
-    // do[k][p] = sum_u W0[u][k] de[u][p]  ->  dS, dQ
-    for (int w = wave; w < MT * 2; w += nw) {
-      const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
+    // do[k][p] = sum_u W0[u][k] de[u][p]  ->  dS (runs of equal a inside the 16 lanes of a column group), image for dQ
+    for (int w = wave; w < MT * g.NP && !(dbg & 2); w += nw) {
+      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
       const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sDE + n0, CG_ADJ_PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sDE + n1, CG_ADJ_PS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sDE + n0, g.PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sDE + n1, g.PS, l15, slot);
       for (int k0 = 0; k0 < g.KcM; k0 += 16) {
         float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, CG_ADJ_PS, k0, b0v); cg_tfrag<1>(bp1, CG_ADJ_PS, k0, b1v);
+        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
@@ -440,39 +554,45 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailP
         const int pp = (h ? n1 : n0) + l15, p = p0 + pp;
         const bool pok = pp < np;
         const int a = pok ? (int)cg_adj_div((unsigned)p, g.magicJ) : -1, bp = pok ? p - a * t.J : 0;
-        // the 16 lanes of a column group hold consecutive positions: distinct b' (no same-address LDS atomics for dQ when
-        // J >= 16), runs of equal a (segmented sum, one atomic per run for dS)
-        int an[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) an[o] = __shfl_down(a, 1 << o, 16);
-        const int aprev = __shfl_up(a, 1, 16);
-        const bool head = pok && (l15 == 0 || aprev != a);
+        // a of the lanes 1, 2, 4, 8 further on in the row (-2: none), and of the previous lane
+        const int an0 = cg_dpp<0x101>(-2, a), an1 = cg_dpp<0x102>(-2, a), an2 = cg_dpp<0x104>(-2, a), an3 = cg_dpp<0x108>(-2, a);
+        const int aprev = cg_dpp<0x111>(-2, a);
+        const bool head = pok && aprev != a;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int k = 16 * mt + 4 * slot + q;
-          const bool kok = k < t.Kc;                         // uniform over the 16 lanes of a group
+          const bool kok = k < t.Kc;                         // uniform over the 16 lanes of a row
           const float d = (pok && kok) ? (h ? c1[q] : c0[q]) : 0.f;
+          sDO[k * g.PS + pp] = d;
           float v = (pok && kok) ? d * sQ[k * g.JS + bp] : 0.f;
-#pragma unroll
-          for (int o = 0; o < 4; ++o) {
-            const float vn = __shfl_down(v, 1 << o, 16);
-            if (l15 + (1 << o) < 16 && an[o] == a) v += vn;
-          }
+          // segmented sum over the runs of equal a: afterwards the first lane of a run holds the run's total
+          { const float vn = cg_dpp<0x101>(0.f, v); if (an0 == a) v += vn; }
+          { const float vn = cg_dpp<0x102>(0.f, v); if (an1 == a) v += vn; }
+          { const float vn = cg_dpp<0x104>(0.f, v); if (an2 == a) v += vn; }
+          { const float vn = cg_dpp<0x108>(0.f, v); if (an3 == a) v += vn; }
           if (head && kok) atomicAdd(&sDS[k * g.JS + a], v);
-          if (pok && kok) atomicAdd(&sDQ[k * g.JS + bp], d * sS[k * g.JS + a]);
         }
       }
     }
+    __syncthreads();
+    // dQ[k][b'] += sum over the tile's positions p = (a, b') of do[k][p] S[k][a]: every cell has one owner thread
+    const int r0 = p0 - (int)cg_adj_div((unsigned)p0, g.magicJ) * t.J;     // b' of the tile's first position
+    for (int cell = tid; cell < KJ && !(dbg & 16); cell += CG_ADJ_THREADS) {
+      const int k = (int)cg_adj_div((unsigned)cell, g.magicJ), bq = cell - k * t.J;
+      float acc = 0.f;
+      for (int pp = bq - r0 + (bq < r0 ? t.J : 0); pp < np; pp += t.J)
+        acc += sDO[k * g.PS + pp] * sS[k * g.JS + (int)cg_adj_div((unsigned)(p0 + pp), g.magicJ)];
+      sDQ[k * g.JS + bq] += acc;
+    }
   }
   __syncthreads();
-  // write dS / dQ back in the layouts of s (V,T) and q (T,V)
-  const int V = t.domain == 0 ? t.Kc : t.J, T = t.domain == 0 ? t.J : t.Kc;
-  float* dsb = t.ds + (long long)b * V * T;
-  float* dqb = t.dq + (long long)b * T * V;
-  for (int e = tid; e < t.Kc * t.J; e += CG_ADJ_THREADS) {
-    const int k = e / t.J, a = e - k * t.J;
-    if (t.domain == 0) { dsb[k * T + a] = sDS[k * g.JS + a]; dqb[a * V + k] = sDQ[k * g.JS + a]; }
-    else { dsb[a * T + k] = sDS[k * g.JS + a]; dqb[k * V + a] = sDQ[k * g.JS + a]; }
+  // this chunk's share of dS / dQ: [b][chunk][2][Kc * J], summed over the chunks by cg_adj_finish_kernel
+  if (dbg & 32) return;
+  float* part = t.part + ((long long)b * g.nch + ch) * 2 * KJ;
+  for (int cell = tid; cell < KJ; cell += CG_ADJ_THREADS) {
+    const int k = (int)cg_adj_div((unsigned)cell, g.magicJ), a = cell - k * t.J;
+    part[cell] = sDS[k * g.JS + a];
+    part[KJ + cell] = sDQ[k * g.JS + a];
   }
   float* dW = t.dW0_ws + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * t.Kc * t.Kc;
 #pragma unroll
@@ -487,13 +607,35 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailP
       }
     }
   }
-  (void)ebase;
 }
 
-// per-channel parameter gradients + fold of the replicated weight gradients (both towers)
+__global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailPair pr) {
+  const CgAdjTail& t = pr.t[blockIdx.y];
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
+  if (ch >= g.nch) return;
+  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
+  if ((g.Pn & 3) == 0) cg_adj_n2_body<true>(t, g, b, ch, tile0, tile1, pr.dbg);
+  else cg_adj_n2_body<false>(t, g, b, ch, tile0, tile1, pr.dbg);
+}
+
+// per-channel parameter gradients, fold of the replicated weight gradients and of the per-chunk dS / dQ (both towers)
 __global__ void cg_adj_finish_kernel(CgAdjTailPair pr) {
   const CgAdjTail& t = pr.t[blockIdx.y];
-  const int n = t.Kc * t.Kc;
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int n = t.Kc * t.Kc, KJ = t.Kc * t.J;
+  const int V = t.domain == 0 ? t.Kc : t.J, T = t.domain == 0 ? t.J : t.Kc;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)t.B * KJ; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / KJ), e = (int)(i - (long long)b * KJ), k = e / t.J, a = e - k * t.J;
+    const float* part = t.part + (long long)b * g.nch * 2 * KJ + e;
+    float sd = 0.f, sq = 0.f;
+    for (int c = 0; c < g.nch; ++c) { sd += part[(long long)c * 2 * KJ]; sq += part[(long long)c * 2 * KJ + KJ]; }
+    // layouts of s (V,T) and q (T,V)
+    float* dsb = t.ds + (long long)b * V * T;
+    float* dqb = t.dq + (long long)b * T * V;
+    if (t.domain == 0) { dsb[k * T + a] = sd; dqb[a * V + k] = sq; }
+    else { dsb[a * T + k] = sd; dqb[k * V + a] = sq; }
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float s0 = 0.f, s4 = 0.f;
     for (int r = 0; r < CG_ADJ_REPLICAS; ++r) { s0 += t.dW0_ws[(long long)r * n + i]; s4 += t.dW4_ws[(long long)r * n + i]; }
@@ -501,12 +643,34 @@ __global__ void cg_adj_finish_kernel(CgAdjTailPair pr) {
   }
   if (blockIdx.x == 0)
     for (int c = threadIdx.x; c < t.Kc; c += blockDim.x) {
-      t.dgamma[c] = (float)t.red[2 * c + 1]; t.dbeta[c] = (float)t.red[2 * c];
-      if (c == 0) t.dalpha[0] = (float)t.red[2 * t.Kc];
+      t.dgamma[c] = (float)cg_adj_red(t, 2 * c + 1); t.dbeta[c] = (float)cg_adj_red(t, 2 * c);
+      if (c == 0) t.dalpha[0] = (float)cg_adj_red(t, 2 * t.Kc);
     }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+static unsigned cg_adj_magic(int d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
+// tiles per workgroup: long workgroups amortise their prologue (weights, tables) when the batch alone fills the chip
+static int cg_adj_tpw(int B) { return B >= 128 ? CG_ADJ_TPW_MAX : B >= 64 ? 4 : B >= 32 ? 2 : 1; }
+static CgAdjGeom cg_adj_geometry(int B, int Kc, int J) {
+  CgAdjGeom g;
+  g.KcM = (Kc + 15) & ~15;
+  g.WS = g.KcM + 4;
+  g.JS = J + 1;
+  g.Pn = J * J;
+  g.PT = g.KcM > 32 ? 64 : g.KcM > 16 ? 128 : 256;       // KcM * PT = 4096
+  g.PS = g.PT + 4;
+  g.NP = g.PT / 32;                                      // pairs of 16-position column groups per tile
+  g.lgq = g.KcM > 32 ? 4 : g.KcM > 16 ? 5 : 6;           // log2(PT / 4)
+  g.ntiles = (g.Pn + g.PT - 1) / g.PT;
+  g.tpw = cg_adj_tpw(B);
+  g.nch = (g.ntiles + g.tpw - 1) / g.tpw;
+  g.magicJ = cg_adj_magic(J); g.magicKc = cg_adj_magic(Kc); g.magicPad = cg_adj_magic(g.WS - Kc);
+  return g;
+}
+static int cg_adj_dbg() { static const int v = getenv("CG_ADJ_DBG") ? atoi(getenv("CG_ADJ_DBG")) : 0; return v; }
+static int cg_adj_tile(int Kc) { const int KcM = (Kc + 15) & ~15; return KcM > 32 ? 64 : KcM > 16 ? 128 : 256; }
+
 static int cg_adj_check(const CgAdjTail* it, int n) {
   if (!it || n <= 0 || n > 2) return CG_EARG;
   for (int i = 0; i < n; ++i) {
@@ -521,32 +685,44 @@ static int cg_adj_check(const CgAdjTail* it, int n) {
 static size_t cg_adj_lds(const CgAdjTail* it, int n, int phase, bool bwd) {
   size_t best = 0;
   for (int i = 0; i < n; ++i) {
-    const int KcM = (it[i].Kc + 15) & ~15, WS = KcM + 4, JS = it[i].J + 1;
+    const int KcM = (it[i].Kc + 15) & ~15, WS = KcM + 4, JS = it[i].J + 1, PS = cg_adj_tile(it[i].Kc) + 4;
     size_t f;
     if (!bwd && phase == 1) f = (size_t)2 * KcM * JS + (size_t)KcM * WS + 2 + (size_t)4 * KcM;                 // tables, W0, f64 sums
-    else if (!bwd) f = (size_t)KcM * CG_ADJ_PS + (size_t)KcM * WS + (size_t)8 * KcM;
-    else if (phase == 1) f = (size_t)2 * KcM * CG_ADJ_PS + (size_t)KcM * WS + (size_t)8 * KcM + (size_t)2 * (2 * KcM + 1) + 2;
-    else f = (size_t)4 * KcM * JS + (size_t)KcM * CG_ADJ_PS + (size_t)KcM * WS + (size_t)8 * KcM;
+    else if (!bwd) f = (size_t)KcM * PS + (size_t)KcM * WS + (size_t)8 * KcM;
+    else if (phase == 1) f = (size_t)3 * KcM * PS + (size_t)KcM * WS + (size_t)8 * KcM + (size_t)2 * (2 * KcM + 1) + 2;
+    else f = (size_t)4 * KcM * JS + (size_t)2 * KcM * PS + (size_t)KcM * WS + (size_t)8 * KcM;
     best = f > best ? f : best;
   }
   return best * sizeof(float) + 16;
 }
 
+static int cg_adj_chunks(int B, int Kc, int J) { const int PT = cg_adj_tile(Kc), tpw = cg_adj_tpw(B); return ((J * J + PT - 1) / PT + tpw - 1) / tpw; }
+static int cg_adj_max_chunks(const CgAdjTail* it, int n) {
+  int m = 1;
+  for (int i = 0; i < n; ++i) m = cg_adj_chunks(it[i].B, it[i].Kc, it[i].J) > m ? cg_adj_chunks(it[i].B, it[i].Kc, it[i].J) : m;
+  return m;
+}
+
+// zeroed scratch of one tower: the replicated weight gradients (two halves: dW0_ws, dW4_ws) / f64 words of `red`
 extern "C" long long cg_map2adj_tail_ws_floats(int Kc) { return (long long)2 * CG_ADJ_REPLICAS * Kc * Kc; }
+extern "C" long long cg_map2adj_tail_red_doubles(int Kc) { return (long long)CG_ADJ_REPLICAS * (2 * Kc + 1); }
+// floats of the per-chunk dS / dQ scratch `part` (no zeroing needed)
+extern "C" long long cg_map2adj_tail_part_floats(int B, int Kc, int J) { return (long long)B * cg_adj_chunks(B, Kc, J) * 2 * Kc * J; }
 
 // include/cistgcn_hip.h : cg_map2adj_tail_fwd (phases 1, 2) / cg_map2adj_tail_bwd (phases 1, 2)
 extern "C" int cg_map2adj_tail_fwd(const CgAdjTail* items, int n, int phase, void* stream_) {
   int st = cg_adj_check(items, n);
   if (st != CG_OK) return st;
   CgAdjTailPair pr;
-  pr.n = n; pr.pad = 0;
+  pr.n = n; pr.nch_max = cg_adj_max_chunks(items, n); pr.dbg = cg_adj_dbg(); pr.pad = 0;
+  for (int i = 0; i < n; ++i) pr.g[i] = cg_adj_geometry(items[i].B, items[i].Kc, items[i].J);
   for (int i = 0; i < n; ++i) {
     pr.t[i] = items[i];
     if (phase == 1 && items[i].train && !items[i].bn.stats) return CG_EARG;
     if (phase == 2 && !items[i].adj) return CG_EARG;
   }
   const size_t lds = cg_adj_lds(items, n, phase, false);
-  dim3 grid((unsigned)items[0].B, (unsigned)n), block(CG_ADJ_THREADS);
+  dim3 grid((unsigned)(items[0].B * pr.nch_max), (unsigned)n), block(CG_ADJ_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
   if (phase == 1) {
     hipError_t e = hipFuncSetAttribute((const void*)cg_adj_m1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -564,15 +740,16 @@ extern "C" int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, voi
   int st = cg_adj_check(items, n);
   if (st != CG_OK) return st;
   CgAdjTailPair pr;
-  pr.n = n; pr.pad = 0;
+  pr.n = n; pr.nch_max = cg_adj_max_chunks(items, n); pr.dbg = cg_adj_dbg(); pr.pad = 0;
+  for (int i = 0; i < n; ++i) pr.g[i] = cg_adj_geometry(items[i].B, items[i].Kc, items[i].J);
   for (int i = 0; i < n; ++i) {
     const CgAdjTail& t = items[i];
     pr.t[i] = t;
     if (!t.dadj || !t.g || !t.red || !t.dW0_ws || !t.dW4_ws) return CG_EARG;
-    if (phase == 2 && (!t.ds || !t.dq || !t.dW0 || !t.dW4 || !t.dgamma || !t.dbeta || !t.dalpha)) return CG_EARG;
+    if (phase == 2 && (!t.ds || !t.dq || !t.part || !t.dW0 || !t.dW4 || !t.dgamma || !t.dbeta || !t.dalpha)) return CG_EARG;
   }
   const size_t lds = cg_adj_lds(items, n, phase, true);
-  dim3 grid((unsigned)items[0].B, (unsigned)n), block(CG_ADJ_THREADS);
+  dim3 grid((unsigned)(items[0].B * pr.nch_max), (unsigned)n), block(CG_ADJ_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
   if (phase == 1) {
     hipError_t e = hipFuncSetAttribute((const void*)cg_adj_n1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -584,7 +761,7 @@ extern "C" int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, voi
     hipLaunchKernelGGL(cg_adj_n2_kernel, grid, block, lds, stream, pr);
     st = cg_launch_status();
     if (st != CG_OK) return st;
-    hipLaunchKernelGGL(cg_adj_finish_kernel, dim3(8, (unsigned)n), dim3(256), 0, stream, pr);
+    hipLaunchKernelGGL(cg_adj_finish_kernel, dim3(128, (unsigned)n), dim3(256), 0, stream, pr);
   } else return CG_EARG;
   return cg_launch_status();
 }

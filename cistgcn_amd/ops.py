@@ -1568,9 +1568,11 @@ class _Map2AdjTail(torch.autograd.Function):
             Kc = t.Kc
             ws = int(_lib.lib().cg_map2adj_tail_ws_floats(Kc))
             zb, _ = _zeros(ws, dev)
-            red = arena.take(2 * Kc + 1)
+            red = arena.take(int(_lib.lib().cg_map2adj_tail_red_doubles(Kc)))
             g = torch.empty_like(e[i])
-            keep += [g, zb]
+            part = torch.empty(int(_lib.lib().cg_map2adj_tail_part_floats(t.B, Kc, t.J)), dtype=f32, device=dev)
+            t.part = part.data_ptr()
+            keep += [g, zb, part]
             ds, dq = torch.empty_like(ts[7 * i]), torch.empty_like(ts[7 * i + 1])
             dw = torch.empty(2, Kc, Kc, dtype=f32, device=dev)
             small = torch.empty(3, Kc, dtype=f32, device=dev)

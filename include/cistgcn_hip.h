@@ -241,14 +241,16 @@ typedef struct CgAdjTail {
   float drop_p; unsigned int salt; const unsigned long long* seed;
   float* e; float* adj;          /* (B,Kc,J,J) */
   float* tap;                    /* optional (B,Kc,J,J): PReLU output (diagnostics) */
-  const float* dadj; float* g; double* red;       /* g (B,Kc,J,J) scratch; red [2 Kc + 1] */
-  float* ds; float* dq;
+  const float* dadj; float* g; double* red;       /* g (B,Kc,J,J) scratch; red: cg_map2adj_tail_red_doubles(Kc) f64 words */
+  float* ds; float* dq; float* part;   /* part: cg_map2adj_tail_part_floats(B, Kc, J) floats of scratch */
   float* dW0_ws; float* dW4_ws;  /* cg_map2adj_tail_ws_floats(Kc) / 2 floats each */
   float* dW0; float* dW4; float* dgamma; float* dbeta; float* dalpha;
 } CgAdjTail;
 int cg_map2adj_tail_fwd(const CgAdjTail* items, int n, int phase, void* stream);
 int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, void* stream);
 long long cg_map2adj_tail_ws_floats(int Kc);
+long long cg_map2adj_tail_part_floats(int B, int Kc, int J);
+long long cg_map2adj_tail_red_doubles(int Kc);
 
 /* ---- evaluation harness counterpart, environment/test.py:97-132 ----------------------
  * y[r,k,:] = x[r,idx[k],:] : `inputs[:, :, dim_used]` (32 -> 22 joints); x (rows,Jin,3), y (rows,Jout,3) contiguous */

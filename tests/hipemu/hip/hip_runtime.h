@@ -78,6 +78,23 @@ static inline T __shfl_up(T v, unsigned delta, int width = 64) {
   return r;
 }
 
+// DPP lane exchange inside a row of 16 lanes: row_shl:n (0x100 + n: lane i takes lane i + n), row_shr:n (0x110 + n: lane i - n),
+// row_ror:n (0x120 + n: rotation).  A lane whose source falls outside its row keeps `old` (bound_ctrl off) or takes 0.
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+  const int lin = (int)threadIdx.x, lane = lin % 64, wave = lin / 64, l15 = lane & 15, n = ctrl & 15, kind = ctrl & 0x1f0;
+  *reinterpret_cast<int*>(hipemu::wave_slot(wave, lane)) = src;
+  hipemu::wave_barrier(wave);
+  int sl = -1;
+  if (kind == 0x100) sl = l15 + n < 16 ? l15 + n : -1;
+  else if (kind == 0x110) sl = l15 - n;
+  else if (kind == 0x120) sl = (l15 - n) & 15;
+  else { fprintf(stderr, "hipemu: unsupported dpp control 0x%x\n", ctrl); abort(); }
+  int r = bound_ctrl ? 0 : old;
+  if (sl >= 0 && wave * 64 + (lane - l15) + sl < (int)blockDim.x) r = *reinterpret_cast<int*>(hipemu::wave_slot(wave, (lane - l15) + sl));
+  hipemu::wave_barrier(wave);
+  return r;
+}
+
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
   static_assert(sizeof(T) <= 16, "shuffle payload");

@@ -1,12 +1,8 @@
 #!/bin/bash
-# A/B of plan switches (environment variables) on one box, two rounds to see the noise.
-# usage: gpu_ab_env.sh "VAR=a VAR2=b" "VAR=c" ...
-set -u
-mkdir -p gpurun_out
-for round in 1 2; do
-for cfg in "$@"; do
-  a=$(env $cfg timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline 2>&1 | grep -o '"ms_per_step": [0-9.]*') || exit 1
-  b=$(env $cfg timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --workload cistgcn64_b256_t50_v22 2>&1 | grep -o '"ms_per_step": [0-9.]*') || exit 1
-  echo "$cfg: $a | $b"
-done
+# A/B of one environment switch on one box: gpu_ab_env.sh VAR [bench args...] -> headline / secondary ms per step for VAR=1 and VAR=0
+VAR=$1; shift
+python -m cistgcn_amd.build >/dev/null 2>&1 || exit 1
+for v in 1 0 1 0; do
+  env $VAR=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-roofline --no-eval --steps 40 "$@" 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$VAR=$v headline %.2f ms  secondary %.3f ms' % (d['ms_per_step'], d['secondary']['ms_per_step']))"
 done
