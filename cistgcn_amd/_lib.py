@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libcistgcn_hip.so")
 
 _handle = None
 STAT_REPLICAS = 16     # CG_STAT_REPLICAS of include/cistgcn_hip.h
+ALPHA_SLOTS = 64       # CG_ALPHA_SLOTS: f64 words the partial sums of a shared PReLU slope's gradient are spread over
 # Host pointers are refused unless a test harness has injected an emulated build of the very same
 # kernel sources (tests/hipemu).  The product never sets this.
 _host_pointers_ok = False

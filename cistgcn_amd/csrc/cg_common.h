@@ -69,6 +69,16 @@ __device__ __forceinline__ uint32_t cg_rand_u32(unsigned long long seed, unsigne
 // Dropout keep-scale: 0 (dropped) or 1/(1-p).  One 64-bit hash serves four consecutive elements (16 bits each), so
 // the vectorised row kernels draw once per float4; the scalar path derives the same bits from (idx >> 2, idx & 3).
 // The drop probability is therefore quantised to 1/65536.
+// The gradient of a shared PReLU slope is a sum over the whole tensor.  One f64 word would take an atomic from every
+// workgroup: same-address atomics serialise at ~20 ns each on MI355X (measured, profiles/README.md), 4096 of them cost more than
+// the kernel's memory traffic.  Its partial sums are therefore spread over CG_ALPHA_SLOTS words behind the channel sums.
+#define CG_ALPHA_SLOTS 64
+__device__ __forceinline__ double cg_alpha_sum(const double* slots) {
+  double s = 0.0;
+  for (int i = 0; i < CG_ALPHA_SLOTS; ++i) s += slots[i];
+  return s;
+}
+
 __device__ __forceinline__ unsigned long long cg_drop_bits(unsigned long long seed, unsigned int salt, unsigned long long quad) {
   unsigned long long z = quad + seed * 0x9E3779B97F4A7C15ull + ((unsigned long long)salt << 40) + 0x632BE59BD9B4E019ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

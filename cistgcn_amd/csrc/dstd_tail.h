@@ -29,8 +29,8 @@ struct CgDstdTail {
                                                              // compressor PReLU - not needed by the computation (diagnostics / branch records)
   // backward
   const float* dout; const float* dpooled; float* dgate;
-  double* red_c;                // [2C + 1] f64, zero on entry
-  float* gp[2]; double* red_p[2];   // gradient in front of prelu1/2's BatchNorm (B,C,T,V); [2C + 1] f64 each, zero on entry
+  double* red_c;                // [2C + CG_ALPHA_SLOTS] f64, zero on entry: channel sums, then the spread partial sums of d alpha
+  float* gp[2]; double* red_p[2];   // gradient in front of prelu1/2's BatchNorm (B,C,T,V); [2C + CG_ALPHA_SLOTS] f64 each, zero on entry
   float* dWc_ws; float* dWc;    // cg_dstd_tail_ws_floats(C) zeroed scratch; (C, 2C)
   float* dr[2]; float* dw[2]; double* red_t[2]; float* dy[2];
   float* dgamma_t[2]; float* dbeta_t[2]; float* dalpha_d[2];

@@ -23,6 +23,7 @@
 #include "cg_common.h"
 #include "dstd_tail.h"
 #include "cg_phase.h"
+#include <stdlib.h>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
@@ -367,7 +368,7 @@ __device__ __forceinline__ float cg_tail_gc(const CgDstdTail& t, const CgAff& ac
   return u > 0.f ? dh : alpha * dh;
 }
 
-// K2: red_c[c] = { sum g_c, sum g_c * h0hat }, red_c[2C] += sum_{u <= 0} dh * u   (d alpha_c)
+// K2: red_c[c] = { sum g_c, sum g_c * h0hat }, red_c[2C + slot] += sum_{u <= 0} dh * u   (d alpha_c, CG_ALPHA_SLOTS partial sums)
 __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
   __shared__ double red[48];
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
@@ -387,7 +388,7 @@ __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
   }
   s1 = cg_block_sum(s1, red); s2 = cg_block_sum(s2, red + 16); sa = cg_block_sum(sa, red + 32);
   if (threadIdx.x == 0) {
-    atomicAdd(&t.red_c[2 * c], s1); atomicAdd(&t.red_c[2 * c + 1], s2); atomicAdd(&t.red_c[2 * t.C], sa);
+    atomicAdd(&t.red_c[2 * c], s1); atomicAdd(&t.red_c[2 * c + 1], s2); atomicAdd(&t.red_c[2 * t.C + ((c + 5 * (int)blockIdx.y) & (CG_ALPHA_SLOTS - 1))], sa);
   }
 }
 
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     const int c2 = e >> 1, i = c2 >= C ? 1 : 0, c = c2 - i * C;
     atomicAdd(&t.red_p[i][2 * c + (e & 1)], sRed[e]);
   }
-  if (tid < 2) atomicAdd(&t.red_p[tid][2 * C], sRed[2 * C2M + tid]);
+  if (tid < 2) atomicAdd(&t.red_p[tid][2 * C + ((int)blockIdx.x & (CG_ALPHA_SLOTS - 1))], sRed[2 * C2M + tid]);
   float* dW = t.dWc_ws + (long long)(blockIdx.x % replicas) * C * C2;
 #pragma unroll
   for (int u = 0; u < CG_TAIL_MAXW; ++u) {
@@ -622,7 +623,10 @@ __global__ void cg_tail_k4_kernel(CgDstdTail t, int rb) {
     if (lane == 0) t.dw[i][(long long)b * t.C + c] = (float)swd;
   }
   s1 = cg_wave_sum(s1); s2 = cg_wave_sum(s2); sa = cg_wave_sum(sa);
-  if (lane == 0) { atomicAdd(&t.red_t[i][2 * c], s1); atomicAdd(&t.red_t[i][2 * c + 1], s2); atomicAdd(&t.red_t[i][2 * t.C], sa); }
+  if (lane == 0) {
+    atomicAdd(&t.red_t[i][2 * c], s1); atomicAdd(&t.red_t[i][2 * c + 1], s2);
+    atomicAdd(&t.red_t[i][2 * t.C + ((c + 5 * (int)blockIdx.y + 17 * wave) & (CG_ALPHA_SLOTS - 1))], sa);
+  }
 }
 
 // K5: dy = BN_t'(g_d * keep); also the per-channel parameter gradients of all three BatchNorm levels and the PReLU slopes
@@ -646,8 +650,8 @@ __global__ void cg_tail_k5_kernel(CgDstdTail t, int rb) {
     t.dgamma_p[i][c] = (float)t.red_p[i][2 * c + 1]; t.dbeta_p[i][c] = (float)t.red_p[i][2 * c];
     if (i == 0) { t.dgamma_c[c] = (float)t.red_c[2 * c + 1]; t.dbeta_c[c] = (float)t.red_c[2 * c]; }
     if (c == 0) {
-      t.dalpha_d[i][0] = (float)t.red_t[i][2 * t.C]; t.dalpha_p[i][0] = (float)t.red_p[i][2 * t.C];
-      if (i == 0) t.dalpha_c[0] = (float)t.red_c[2 * t.C];
+      t.dalpha_d[i][0] = (float)cg_alpha_sum(t.red_t[i] + 2 * t.C); t.dalpha_p[i][0] = (float)cg_alpha_sum(t.red_p[i] + 2 * t.C);
+      if (i == 0) t.dalpha_c[0] = (float)cg_alpha_sum(t.red_c + 2 * t.C);
     }
   }
 }

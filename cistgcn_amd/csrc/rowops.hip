@@ -383,7 +383,7 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormActBatch batch) {
   if (threadIdx.x == 0) {
     atomicAdd(&a.red[2 * c], s1);
     atomicAdd(&a.red[2 * c + 1], s2);
-    if (a.alpha) atomicAdd(&a.red[2 * C + (a.alpha_n == 1 ? 0 : c)], sa);
+    if (a.alpha) atomicAdd(&a.red[2 * C + (a.alpha_n == 1 ? ((c + 5 * (int)blockIdx.y) & (CG_ALPHA_SLOTS - 1)) : c)], sa);
   }
 }
 
@@ -450,7 +450,7 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormActBatch batch) {
       if (a.dbeta) a.dbeta[c] = (float)a.red[2 * c];
     }
     if (a.alpha && a.dalpha) {
-      if (a.alpha_n == 1) { if (c == 0) a.dalpha[0] = (float)a.red[2 * C]; }
+      if (a.alpha_n == 1) { if (c == 0) a.dalpha[0] = (float)cg_alpha_sum(a.red + 2 * C); }
       else a.dalpha[c] = (float)a.red[2 * C + c];
     }
   }

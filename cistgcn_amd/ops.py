@@ -732,7 +732,7 @@ class _NormActMany(torch.autograd.Function):
                     a.dadd, a.dav = dadd.data_ptr(), _view4(dadd)
             flags[i] = 1 if (bn is not None or alpha is not None) else 0
             if flags[i]:
-                a.red = _arena(dev).take(2 * C + nalpha).data_ptr()
+                a.red = _arena(dev).take(2 * C + (_lib.ALPHA_SLOTS if nalpha == 1 else nalpha)).data_ptr()
                 if bn is not None:
                     dgamma = torch.empty(C, dtype=torch.float32, device=dev)
                     dbeta = torch.empty(C, dtype=torch.float32, device=dev)
@@ -1451,9 +1451,9 @@ class _DstdTail(torch.autograd.Function):
         _lib.call("cg_se_gate_bwd", _ptr(pooled), _ptr(sw1), _ptr(sw2), _ptr(gate), _ptr(dgate), _ptr(dpooled), _ptr(dsw1), _ptr(dsw2),
                   B, C, H, 1, stream)
         arena = _arena(dev)
-        red_c = arena.take(2 * C + 1)
-        red_p = [arena.take(2 * C + 1) for _ in range(2)]
-        red_t = [arena.take(2 * C + 1) for _ in range(2)]
+        red_c = arena.take(2 * C + _lib.ALPHA_SLOTS)
+        red_p = [arena.take(2 * C + _lib.ALPHA_SLOTS) for _ in range(2)]
+        red_t = [arena.take(2 * C + _lib.ALPHA_SLOTS) for _ in range(2)]
         big = [torch.empty(B, C, T, V, dtype=f32, device=dev) for _ in range(6)]            # gp x2, dr x2, dy x2
         dws = [torch.empty(B, C, dtype=f32, device=dev) for _ in range(2)]
         small = torch.empty(15, C, dtype=f32, device=dev)   # dgamma/dbeta of tcn1,2 prelu1,2 compressor (10 rows) + 5 slope gradients

@@ -30,6 +30,9 @@ extern "C" {
  * every workgroup adds {sum, sum of squares} into replica (block id mod CG_STAT_REPLICAS) so that f64 atomics do
  * not serialise on one address; cg_norm_act_fwd sums the replicas. */
 #define CG_STAT_REPLICAS 16
+/* The gradient of a shared PReLU slope (one scalar per tensor) is accumulated as CG_ALPHA_SLOTS partial sums behind the channel
+ * sums of a `red` buffer: same-address f64 atomics serialise, thousands of workgroups on one word cost more than the kernel. */
+#define CG_ALPHA_SLOTS 64
 
 /* 4-D strided view: n[0] batch, n[1] channel, n[2] x n[3] positions; s[] in elements.
  * NCTV, NTCV (CISTGCN.py:582) and (N,3,V,T) (:592) views of one buffer differ only in s[]. */
@@ -111,7 +114,7 @@ typedef struct CgNormAct {
   float* dx; CgView4 dxv;
   float* dadd; CgView4 dav;
   float* dpre;
-  double* red;                   /* [2C + alpha_n] f64 scratch, zero on entry */
+  double* red;                   /* [2C + (alpha_n == 1 ? CG_ALPHA_SLOTS : alpha_n)] f64 scratch, zero on entry */
   float* dgamma; float* dbeta; float* dalpha;
   double* ystats;                /* forward, optional: [C][2] f64 sums of y (zero on entry) for the BatchNorm consuming y */
 } CgNormAct;

