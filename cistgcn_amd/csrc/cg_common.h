@@ -69,6 +69,21 @@ __device__ __forceinline__ uint32_t cg_rand_u32(unsigned long long seed, unsigne
 // Dropout keep-scale: 0 (dropped) or 1/(1-p).  One 64-bit hash serves four consecutive elements (16 bits each), so
 // the vectorised row kernels draw once per float4; the scalar path derives the same bits from (idx >> 2, idx & 3).
 // The drop probability is therefore quantised to 1/65536.
+// ---- lane exchange inside a row of 16 lanes on the VALU (DPP), no LDS round trip -----------------------------------------------
+// CTRL: 0x100 + n row_shl (lane i takes lane i + n), 0x110 + n row_shr (lane i takes lane i - n), 0x120 + n row_ror (rotation).
+// A lane whose source falls outside its row keeps `old`.
+template <int CTRL>
+__device__ __forceinline__ float cg_dpp(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int cg_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+// sum over the 16 lanes of a row, in every lane of the row
+__device__ __forceinline__ float cg_row16_sum(float v) {
+  v += cg_dpp<0x128>(0.f, v); v += cg_dpp<0x124>(0.f, v); v += cg_dpp<0x122>(0.f, v); v += cg_dpp<0x121>(0.f, v);
+  return v;
+}
+
 // The gradient of a shared PReLU slope is a sum over the whole tensor.  One f64 word would take an atomic from every
 // workgroup: same-address atomics serialise at ~20 ns each on MI355X (measured, profiles/README.md), 4096 of them cost more than
 // the kernel's memory traffic.  Its partial sums are therefore spread over CG_ALPHA_SLOTS words behind the channel sums.

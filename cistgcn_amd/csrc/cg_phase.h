@@ -63,21 +63,6 @@ __device__ __forceinline__ const float* cg_tfrag_ptr(const float* base, int rs, 
 }
 
 
-// ---- lane exchange inside a row of 16 lanes on the VALU (DPP), no LDS round trip -----------------------------------------------
-// CTRL: 0x100 + n row_shl (lane i takes lane i + n), 0x110 + n row_shr (lane i takes lane i - n), 0x120 + n row_ror (rotation).
-// A lane whose source falls outside its row keeps `old`.
-template <int CTRL>
-static __device__ __forceinline__ float cg_dpp(float old, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-static __device__ __forceinline__ int cg_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
-// sum over the 16 lanes of a row, in every lane of the row
-static __device__ __forceinline__ float cg_row16_sum(float v) {
-  v += cg_dpp<0x128>(0.f, v); v += cg_dpp<0x124>(0.f, v); v += cg_dpp<0x122>(0.f, v); v += cg_dpp<0x121>(0.f, v);
-  return v;
-}
-
 // keep factors of the four consecutive elements idx0 .. idx0 + 3 (idx0 % 4 == 0): one hash, as cg_norm_act's float4 path
 static __device__ __forceinline__ void cg_keep4(bool on, float p, unsigned long long seed, unsigned int salt, unsigned long long idx0, float keep[4]) {
   if (!on) { keep[0] = keep[1] = keep[2] = keep[3] = 1.f; return; }

@@ -87,15 +87,47 @@ extern "C" int cg_feature_lift_bwd(const float* x, const float* df, float* dx, l
 // ---------------------------------------------------------------------------------------------
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
+// lanes that share a row of V values: 16, 32 or 64 (a row wider than 64 is walked in steps of 64)
+__device__ __forceinline__ int cg_stats_lpr(int V) { return V <= 16 ? 16 : V <= 32 ? 32 : 64; }
+// sum over the `lpr` lanes of a row group, in every lane of the group
+__device__ __forceinline__ float cg_stats_group_sum(float v, int lpr) {
+  v = cg_row16_sum(v);
+  if (lpr >= 32) v += __shfl_xor(v, 16, 64);
+  if (lpr >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// per-(c,t) row mean and centred sum of squares (one coalesced read of the sample: a group of lanes per row, the row's
+// values stay in registers between the two sums), then per-c mean and std
 __device__ __forceinline__ void cg_stats_rows(const float* xb, int C, int T, int V, float* rm, float* rq, float* cm, float* cs) {
-  for (int r = threadIdx.x; r < C * T; r += blockDim.x) {
-    const float* row = xb + (long long)r * V;
-    float m = 0.f;
-    for (int v = 0; v < V; ++v) m += row[v];
-    m /= (float)V;
-    float q = 0.f;
-    for (int v = 0; v < V; ++v) { const float d = row[v] - m; q += d * d; }
-    rm[r] = m; rq[r] = q;
+  const int lpr = cg_stats_lpr(V), gl = threadIdx.x & (lpr - 1), grp = threadIdx.x / lpr, ngrp = blockDim.x / lpr;
+  const int rows = C * T, iters = (rows + 4 * ngrp - 1) / (4 * ngrp);
+  for (int it = 0; it < iters; ++it) {                 // every lane runs every iteration: the group sums are wave-wide exchanges
+    float x0[4], s[4], m[4], q[4];
+    int rr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // four rows per group in flight
+      rr[k] = (4 * it + k) * ngrp + grp;
+      const bool ok = rr[k] < rows && gl < V;
+      x0[k] = ok ? xb[(long long)rr[k] * V + gl] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s[k] = x0[k];
+      if (V > 64 && rr[k] < rows) for (int v = gl + 64; v < V; v += 64) s[k] += xb[(long long)rr[k] * V + v];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = cg_stats_group_sum(s[k], lpr) / (float)V;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      q[k] = (rr[k] < rows && gl < V) ? (x0[k] - m[k]) * (x0[k] - m[k]) : 0.f;
+      if (V > 64 && rr[k] < rows) for (int v = gl + 64; v < V; v += 64) { const float d = xb[(long long)rr[k] * V + v] - m[k]; q[k] += d * d; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      q[k] = cg_stats_group_sum(q[k], lpr);
+      if (rr[k] < rows && gl == 0) { rm[rr[k]] = m[k]; rq[rr[k]] = q[k]; }
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -110,7 +142,7 @@ __device__ __forceinline__ void cg_stats_rows(const float* xb, int C, int T, int
   __syncthreads();
 }
 
-__global__ void cg_dstd_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int V) {
+__global__ __launch_bounds__(1024) void cg_dstd_stats_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int C, int T, int V) {
   float* rm = (float*)cg_dyn_lds;
   float* rq = rm + C * T;
   float* cm = rq + C * T;
@@ -141,7 +173,8 @@ __global__ void cg_dstd_stats_fwd_kernel(const float* __restrict__ x, float* __r
   }
 }
 
-__global__ void cg_dstd_stats_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
+// backward: d x[c,t,v] = x * P[c,t] + Q[c,t] with row coefficients from the four statistics' gradients
+__global__ __launch_bounds__(1024) void cg_dstd_stats_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dx,
                                          int C, int T, int V) {
   float* rm = (float*)cg_dyn_lds;
   float* rq = rm + C * T;
@@ -149,6 +182,8 @@ __global__ void cg_dstd_stats_bwd_kernel(const float* __restrict__ x, const floa
   float* cs = cm + C;
   float* tS = cs + C;       // [T] std over c of row stds
   float* tM = tS + T;       // [T] mean over c of row stds
+  float* rP = tM + T;       // [C*T] slope of the row
+  float* rQ = rP + C * T;   // [C*T] offset of the row
   __shared__ float gS, gSm;
   const int b = blockIdx.x;
   const float* xb = x + (long long)b * C * T * V;
@@ -175,34 +210,40 @@ __global__ void cg_dstd_stats_bwd_kernel(const float* __restrict__ x, const floa
   __syncthreads();
   const float g0 = g[0] / (float)(C * T * V);
   const float gall = g[1 + T];
-  float* dxb = dx + (long long)b * C * T * V;
-  for (int i = threadIdx.x; i < C * T * V; i += blockDim.x) {
-    const int v = i % V, r = i / V, t = r % T, c = r / T;
-    (void)v;
-    const float xv = xb[i];
-    float d = g0 + g[1 + t] / (float)(C * V);
-    // std over c of s_c, s_c = std over (t,v)
-    d += gall * (cs[c] - gSm) / ((float)(C - 1) * gS) * (xv - cm[c]) / ((float)(T * V - 1) * cs[c]);
-    // std over c of s_ct, s_ct = std over v
+  for (int r = threadIdx.x; r < C * T; r += blockDim.x) {
+    const int c = r / T, t = r - c * T;
+    // std over c of s_c, s_c = std over (t,v);  std over c of s_ct, s_ct = std over v
+    const float pc = gall * (cs[c] - gSm) / ((float)(C - 1) * gS) / ((float)(T * V - 1) * cs[c]);
     const float sct = sqrtf(rq[r] / (float)(V - 1));
-    d += g[2 + T + t] * (sct - tM[t]) / ((float)(C - 1) * tS[t]) * (xv - rm[r]) / ((float)(V - 1) * sct);
-    dxb[i] = d;
+    const float pr = g[2 + T + t] * (sct - tM[t]) / ((float)(C - 1) * tS[t]) / ((float)(V - 1) * sct);
+    rP[r] = pc + pr;
+    rQ[r] = g0 + g[1 + t] / (float)(C * V) - pc * cm[c] - pr * rm[r];
+  }
+  __syncthreads();
+  float* dxb = dx + (long long)b * C * T * V;
+  const int lpr = cg_stats_lpr(V), gl = threadIdx.x & (lpr - 1), grp = threadIdx.x / lpr, ngrp = blockDim.x / lpr;
+#pragma unroll 4
+  for (int r = grp; r < C * T; r += ngrp) {
+    const float P = rP[r], Q = rQ[r];
+    for (int v = gl; v < V; v += 64) dxb[(long long)r * V + v] = xb[(long long)r * V + v] * P + Q;
   }
 }
 
-static size_t cg_dstd_lds(int C, int T) { return (size_t)(2 * C * T + 2 * C + 2 * T) * sizeof(float); }
+static size_t cg_dstd_lds(int C, int T) { return (size_t)(4 * C * T + 2 * C + 2 * T) * sizeof(float); }
 
 extern "C" int cg_dstd_stats_fwd(const float* x, float* out, int B, int C, int T, int V, void* stream_) {
   if (!x || !out) return CG_EARG;
   if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_dstd_stats_fwd_kernel, dim3(B), dim3(256), cg_dstd_lds(C, T), (hipStream_t)stream_, x, out, C, T, V);
+  if (hipFuncSetAttribute((const void*)cg_dstd_stats_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_dstd_stats_fwd_kernel, dim3(B), dim3(1024), cg_dstd_lds(C, T), (hipStream_t)stream_, x, out, C, T, V);
   return cg_launch_status();
 }
 
 extern "C" int cg_dstd_stats_bwd(const float* x, const float* dout, float* dx, int B, int C, int T, int V, void* stream_) {
   if (!x || !dout || !dx) return CG_EARG;
   if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_dstd_stats_bwd_kernel, dim3(B), dim3(256), cg_dstd_lds(C, T), (hipStream_t)stream_, x, dout, dx, C, T, V);
+  if (hipFuncSetAttribute((const void*)cg_dstd_stats_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_dstd_stats_bwd_kernel, dim3(B), dim3(1024), cg_dstd_lds(C, T), (hipStream_t)stream_, x, dout, dx, C, T, V);
   return cg_launch_status();
 }
 

@@ -524,6 +524,7 @@ def check_stage_kernels(device):
     # rows of 40 joints (one wave per row), and a sample large enough for the 16-wave workgroup (8 x 50 x 22)
     _run(ops.dstd_stats, O.CISTGCN.block_stats, [_rand(g, 2, 3, 4, 40)], device, what="dstd_stats V=40")
     _run(ops.dstd_stats, O.CISTGCN.block_stats, [_rand(g, 2, 8, 50, 22) + 0.5], device, what="dstd_stats 8x50x22")
+    _run(ops.dstd_stats, O.CISTGCN.block_stats, [_rand(g, 2, 3, 2, 70)], device, what="dstd_stats V=70")      # rows wider than a wave
     pred, tgt = 50 + 350 * _rand(g, 4, 25, 22, 3), 50 + 350 * _rand(g, 4, 25, 22, 3)
     pd = _leaf(pred, device)
     pr = _leaf(pred, "cpu")
