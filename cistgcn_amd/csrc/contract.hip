@@ -198,8 +198,7 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
           s += (double)v; q += (double)v * (double)v;
         }
         if (stats != nullptr) {      // the 16 lanes of a row reduce in registers, one LDS atomic per row and wave
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) { s += __shfl_down(s, off, 16); q += __shfl_down(q, off, 16); }
+          s = cg_row16_sum(s); q = cg_row16_sum(q);
           if (l15 == 0 && row_ok) { atomicAdd(&sStat[mt][0], s); atomicAdd(&sStat[mt][1], q); }
         }
       }
@@ -248,8 +247,7 @@ __device__ __forceinline__ void cg_contract_body(const CgContractDesc& d, long l
         s += (double)v; q += (double)v * (double)v;
       }
       if (stats != nullptr) {        // tx = 0..15 share the row
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { s += __shfl_down(s, off, 16); q += __shfl_down(q, off, 16); }
+        s = cg_row16_sum(s); q = cg_row16_sum(q);
         if (tx == 0 && row_ok) { atomicAdd(&sStat[ty + 16 * i][0], s); atomicAdd(&sStat[ty + 16 * i][1], q); }
       }
     }
@@ -370,8 +368,7 @@ __device__ __forceinline__ void cg_stream_body(const CgContractBatch& batch, con
       if (stats != nullptr) {
         double s1 = ok ? ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w) : 0.0;
         double s2 = ok ? ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w) : 0.0;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 16); s2 += __shfl_down(s2, off, 16); }
+        s1 = cg_row16_sum(s1); s2 = cg_row16_sum(s2);
         if (l15 == 0 && m < M) { atomicAdd(&sStat[mt][0], s1); atomicAdd(&sStat[mt][1], s2); }
       }
     }

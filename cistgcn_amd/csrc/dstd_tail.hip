@@ -86,6 +86,7 @@ __global__ void cg_tail_f1_kernel(CgDstdTail t, int rb) {
 #define CG_TAIL_THREADS 256
 #define CG_TAIL_PT3 32                // positions per tile of the backward GEMM phase (two workgroups per CU)
 #define CG_TAIL_PS3 (CG_TAIL_PT3 + 4)
+#define CG_TAIL_K3_TASKS 2            // d a tasks of a wave per tile: (2C / 16 <= 8 channel tiles) * (PT3 / 32) / 4 waves
 
 // per-channel constants of the forward chain of branch i, channel c, staged in LDS: [2C][8]
 //   0 mean_t  1 scale_t  2 beta_t  3 alpha_d  4 mean_p  5 rstd_p  6 gamma_p  7 beta_p
@@ -288,8 +289,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
         if (ok1) hb[(long long)co * P + n1 + l15] = v1;
         if (t.train) {
           float s1 = v0 + v1, s2 = v0 * v0 + v1 * v1;
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+          s1 = cg_row16_sum(s1); s2 = cg_row16_sum(s2);
           if (l15 == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
         }
       }
@@ -425,6 +425,9 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
 #pragma unroll
   for (int u = 0; u < CG_TAIL_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float alpha_c = t.alpha_c[0];
+  float racc[CG_TAIL_K3_TASKS][4][3];              // per lane: sums of g_p, g_p * zhat and the d alpha_p terms of the wave's d a tasks
+#pragma unroll
+  for (int i = 0; i < CG_TAIL_K3_TASKS * 12; ++i) (&racc[0][0][0])[i] = 0.f;
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
     if (lid >= total) break;
@@ -478,7 +481,8 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         const int mt = id / NT2, n2 = id - mt * NT2, c2 = 16 * n2 + l15;
         const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
         const bool cok = c2 < C2;
-        const float gam = cok ? t.bn_p[i].gamma[c] : 0.f, bet = cok ? t.bn_p[i].beta[c] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        (void)c;
         const float* ap = cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
         const float* bp = cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
         for (int k0 = 0; k0 < CG_TAIL_PT3; k0 += 16) {
@@ -494,7 +498,11 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       }
     }
     // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat
-    for (int w = wave; w < NT2 * (CG_TAIL_PT3 / 32); w += nw) {
+    // (per lane in registers over all tiles of the workgroup: a wave owns the same (at most CG_TAIL_K3_TASKS) c2 tiles in every tile)
+#pragma unroll
+    for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
+      const int w = wave + nw * ti;
+      if (w >= NT2 * (CG_TAIL_PT3 / 32)) break;
       const int mt = w / (CG_TAIL_PT3 / 32), n0 = 32 * (w % (CG_TAIL_PT3 / 32)), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
       const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, WS, l15, slot);
@@ -514,8 +522,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         const int c2 = 16 * mt + 4 * slot + q;
         const bool cok = c2 < C2;
         const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
-        const float gam = cok ? t.bn_p[i].gamma[c] : 0.f, bet = cok ? t.bn_p[i].beta[c] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
-        float s1 = 0.f, s2 = 0.f, sa = 0.f;
+        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pp = (h ? n1 : n0) + l15;
@@ -524,15 +531,24 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
             const float zh = sZ[c2 * CG_TAIL_PS3 + pp], v = gam * zh + bet;
             const float g = v > 0.f ? da : alp * da;
             t.gp[i][((long long)b * C + c) * P + p0 + pp] = g;
-            s1 += g; s2 += g * zh;
-            if (!(v > 0.f)) sa += da * v;
+            racc[ti][q][0] += g; racc[ti][q][1] += g * zh;
+            if (!(v > 0.f)) racc[ti][q][2] += da * v;
           }
         }
+      }
+    }
+  }
+  // one cross-lane reduction for all tiles (a row of 16 lanes holds the positions of a channel)
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); sa += __shfl_xor(sa, off, 64); }
-        if (l15 == 0 && cok) {
-          atomicAdd(&sRed[2 * c2], (double)s1); atomicAdd(&sRed[2 * c2 + 1], (double)s2); atomicAdd(&sRed[2 * C2M + i], (double)sa);
-        }
+  for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
+    const int w = wave + nw * ti;
+    if (w >= NT2 * (CG_TAIL_PT3 / 32)) break;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c2 = 16 * (w / (CG_TAIL_PT3 / 32)) + 4 * slot + q;
+      const float s1 = cg_row16_sum(racc[ti][q][0]), s2 = cg_row16_sum(racc[ti][q][1]), sa = cg_row16_sum(racc[ti][q][2]);
+      if (l15 == 0 && c2 < C2) {
+        atomicAdd(&sRed[2 * c2], (double)s1); atomicAdd(&sRed[2 * c2 + 1], (double)s2); atomicAdd(&sRed[2 * C2M + (c2 >= C ? 1 : 0)], (double)sa);
       }
     }
   }

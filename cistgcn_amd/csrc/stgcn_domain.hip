@@ -333,8 +333,7 @@ __global__ __launch_bounds__(256) void cg_stgcn_domain_fwd_mfma_kernel(const flo
         if (ok) yb[co * TV + cg_dom_off<DOMAIN>(g, g0 + grp, o)] = v;
         if (ystats) {          // the 16 lanes of a row hold the same channel: reduce them before touching LDS
           float s1 = v, s2 = v * v;
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 16); s2 += __shfl_down(s2, off, 16); }
+          s1 = cg_row16_sum(s1); s2 = cg_row16_sum(s2);
           if (l15 == 0 && co < g.Cout) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
         }
       }

@@ -434,8 +434,7 @@ __global__ __launch_bounds__(CG_DOMM_THREADS, 2) void cg_stgcn_domain_fwd_mfma2_
         if (ok1 && cok) yb[co * TV + a1] = v1;
         if (ystats) {          // the 16 lanes of a slot hold the same channel: reduce them before touching LDS
           float s1 = v0 + v1, s2 = v0 * v0 + v1 * v1;
-#pragma unroll
-          for (int off = 8; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+          s1 = cg_row16_sum(s1); s2 = cg_row16_sum(s2);
           if (l15 == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
         }
       }

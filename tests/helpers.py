@@ -11,12 +11,14 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("eval_", "aug_")))
 
 
-def make_cfg(C, T, V, dropout=0.0, To=25, hidden=64, interp=(True,) * 5, interp_o=(True,)):
-    """Attribute-style config with the schema of the reference YAML (train_h36m.yaml:1-28)."""
+def make_cfg(C, T, V, dropout=0.0, To=25, hidden=64, interp=None, interp_o=(True,), blocks=4, txc=4):
+    """Attribute-style config with the schema of the reference YAML (train_h36m.yaml:1-28); `blocks` / `txc` shrink the
+    depth (model_complexity entries, n_txcnn_layers) for the emulated CPU runs."""
+    interp = (True,) * (blocks + 1) if interp is None else interp
     arch = NS(model_params=NS(
-        input_n=T, output_n=To, joints=V, n_txcnn_layers=4, txc_kernel_size=3, reduction=8,
+        input_n=T, output_n=To, joints=V, n_txcnn_layers=txc, txc_kernel_size=3, reduction=8,
         hidden_dim=hidden, clipping=15,
-        input_gcn=NS(model_complexity=[C] * 4, interpretable=list(interp)),
+        input_gcn=NS(model_complexity=[C] * blocks, interpretable=list(interp)),
         output_gcn=NS(model_complexity=[3], interpretable=list(interp_o))))
     return arch, NS(dropout=dropout)
 

@@ -48,7 +48,7 @@ def _worker_body(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     C, T, V = CFG["C"], CFG["T"], CFG["V"]
-    kw = dict(To=CFG["To"], hidden=CFG["hidden"])
+    kw = dict(To=CFG["To"], hidden=CFG["hidden"], blocks=2, txc=2)     # two input blocks: the cut sits between them
     net, ora = checks.build_pair(C, T, V, "cpu", seed=0, **kw)          # same seed -> same replica weights on every rank
     g = torch.Generator().manual_seed(77)
     with torch.no_grad():

@@ -1,5 +1,5 @@
-"""Whole-model parity on the CPU-only box at a miniature shape (the model is parametric in
-(T_in, T_out, V, C, hidden_dim)): the shipped kernels under the test-only HIP shim vs the oracle,
+"""Whole-model parity on the CPU-only box at a miniature shape and depth (the model is parametric in
+(T_in, T_out, V, C, hidden_dim, number of blocks)): the shipped kernels under the test-only HIP shim vs the oracle,
 eval and train mode, forward, loss, every gradient, attributes and running statistics.
 Full-size parity runs on the MI355X (tests/test_gpu_parity.py)."""
 import pytest
@@ -18,13 +18,13 @@ def _emulated_kernels():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", ["eval"])          # train mode: the strict test below
 def test_tiny_model_matches_oracle(mode):
-    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8)
+    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=2, txc=2)
 
 
 @pytest.mark.timeout(900)
 def test_tiny_model_every_gradient_strict():
     """all parameter gradients within 1e-4 * max(0.1, max|ref|) with the oracle on the branches the kernels took"""
-    checks.check_model_branch_replay("cpu", 4, 4, 5, 2, "train", To=8, hidden=8, grad_floor=0.1)
+    checks.check_model_branch_replay("cpu", 4, 4, 5, 2, "train", To=8, hidden=8, grad_floor=0.1, blocks=2, txc=2)
 
 
 @pytest.mark.timeout(900)
@@ -33,7 +33,7 @@ def test_model_survives_jit_trace():
     with dropout on: the hot path appears as one opaque node, the seed is not advanced while tracing (the tracer's check run
     draws the same masks) and the traced module replays to the same prediction."""
     import torch
-    net, _ = checks.build_pair(4, 4, 5, "cpu", To=8, hidden=8, dropout=0.1)
+    net, _ = checks.build_pair(4, 4, 5, "cpu", To=8, hidden=8, dropout=0.1, blocks=1, txc=1)
     net.train()
     x = 50 + 350 * torch.randn(2, 4, 5, 3, generator=torch.Generator().manual_seed(3))
     traced = torch.jit.trace(net, x)
