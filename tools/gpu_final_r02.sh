@@ -23,3 +23,4 @@ cd $GRAFT_REPO_ROOT
 bash tools/gpu_pmc_kernels.sh step_c64 cg_ tools/prof_step.py cistgcn64_b256_t50_v22 2 > gpurun_out/r2_pmc_step.log 2>&1; tail -3 gpurun_out/r2_pmc_step.log
 bash tools/gpu_pmc_kernels.sh domain cg_stgcn_domain tools/prof_domain_sq.py 2 > gpurun_out/r2_pmc_domain.log 2>&1; tail -3 gpurun_out/r2_pmc_domain.log
 bash tools/gpu_pmc_kernels.sh tail cg_tail tools/prof_tail.py > gpurun_out/r2_pmc_tail.log 2>&1; tail -3 gpurun_out/r2_pmc_tail.log
+bash tools/gpu_pmc_kernels.sh adj cg_adj tools/prof_adj.py > gpurun_out/r2_pmc_adj.log 2>&1; tail -3 gpurun_out/r2_pmc_adj.log
