@@ -46,8 +46,9 @@ def main():
     os.makedirs(DST, exist_ok=True)
     copy(os.path.join(SRC, "r02_bench.json"), "r02_bench_default.json")
     for w in (HEADLINE, "cistgcn8_b16_t50_v22"):
-        for f in glob.glob(os.path.join(SRC, "prof_r02_" + w, "*", "*_kernel_stats.csv")):
-            copy(f, "r02_%s_kernel_stats.csv" % w)
+        found = sorted(glob.glob(os.path.join(SRC, "prof_r02_" + w, "*", "*_kernel_stats.csv")), key=os.path.getmtime)
+        if found:                                  # gpurun merges into gpurun_out/: earlier runs' files (other pids) stay around
+            copy(found[-1], "r02_%s_kernel_stats.csv" % w)
     copy(os.path.join(SRC, "pmc_step_c64", "summary.txt"), "r02_step_c64_pmc.txt")
     copy(os.path.join(SRC, "pmc_domain", "summary.txt"), "r02_stgcn_domain_pmc.txt")
     copy(os.path.join(SRC, "pmc_tail", "summary.txt"), "r02_dstd_tail_pmc.txt")
