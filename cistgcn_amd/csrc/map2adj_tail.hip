@@ -111,13 +111,19 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
   const int MT = g.KcM / 16;
   float* eb = t.e + (long long)b * t.Kc * g.Pn;
   const int P0 = tile0 * g.PT, ngroups = (min(g.Pn, tile1 * g.PT) - P0 + 31) / 32;
+  // C[position][channel] tiles: a lane ends up with four consecutive positions of ONE channel (float4 stores, per-lane channel
+  // sums); a wave keeps its channel tile (4 % MT == 0), so the sums stay in registers over all its groups
+  const bool vec = (g.Pn & 3) == 0;
+  const int mt = wave % MT, u = 16 * mt + l15;
+  const bool uok = u < t.Kc;
+  const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * g.WS, g.WS, l15, slot);
+  float s1 = 0.f, s2 = 0.f;
   for (int w = wave; w < ngroups * MT; w += CG_ADJ_THREADS / 64) {       // (group of 32 positions, u tile)
-    const int grp = w / MT, mt = w - grp * MT, p0 = P0 + 32 * grp;
+    const int grp = w / MT, p0 = P0 + 32 * grp;
     const int pa = p0 + l15, pb = p0 + 16 + l15;
     const int aa = (int)cg_adj_div((unsigned)pa, g.magicJ), ab = (int)cg_adj_div((unsigned)pb, g.magicJ);
     const bool oka = pa < g.Pn, okb = pb < g.Pn;
     cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-    const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * g.WS, g.WS, l15, slot);
     for (int k0 = 0; k0 < g.KcM; k0 += 16) {
       float av[4], b0v[4], b1v[4];
       cg_tfrag<0>(ap, g.WS, k0, av);
@@ -125,23 +131,30 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
       cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, okb ? ab : 0, okb ? pb - ab * t.J : 0, okb, b1v);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
       }
     }
+    if (uok) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int u = 16 * mt + 4 * slot + q;
-      const bool uok = u < t.Kc;
-      const float v0 = (uok && oka) ? c0[q] : 0.f, v1 = (uok && okb) ? c1[q] : 0.f;
-      if (uok && oka) eb[(long long)u * g.Pn + pa] = v0;
-      if (uok && okb) eb[(long long)u * g.Pn + pb] = v1;
-      if (t.train) {
-        const float s1 = cg_row16_sum(v0 + v1), s2 = cg_row16_sum(v0 * v0 + v1 * v1);
-        if (l15 == 0 && uok) { atomicAdd(&sStat[2 * u], (double)s1); atomicAdd(&sStat[2 * u + 1], (double)s2); }
+      for (int h = 0; h < 2; ++h) {
+        const int pq = p0 + 16 * h + 4 * slot;               // first of this lane's four positions
+        const cg_f32x4 c = h ? c1 : c0;
+        float* dst = eb + (long long)u * g.Pn + pq;
+        if (vec) {
+          if (pq < g.Pn) {
+            *reinterpret_cast<float4*>(dst) = make_float4(c[0], c[1], c[2], c[3]);
+            s1 += (c[0] + c[1]) + (c[2] + c[3]); s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (pq + q < g.Pn) { dst[q] = c[q]; s1 += c[q]; s2 += c[q] * c[q]; }
+        }
       }
     }
   }
+  if (t.train && uok) { atomicAdd(&sStat[2 * u], (double)s1); atomicAdd(&sStat[2 * u + 1], (double)s2); }
   if (t.train) {
     __syncthreads();
     double* rep = t.bn.stats + (long long)(blockIdx.x % CG_STAT_REPLICAS) * 2 * t.Kc;
@@ -273,17 +286,24 @@ __device__ __forceinline__ void cg_adj_m2_body(const CgAdjTail& t, const CgAdjGe
         float av[4], b0v[4], b1v[4];
         cg_tfrag<0>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {                     // C[position][channel]: four consecutive positions per lane
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
         }
       }
+      const int u = 16 * mt + l15;
+      if (u < t.Kc) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int u = 16 * mt + 4 * slot + q;
-        if (u >= t.Kc) continue;
-        if (n0 + l15 < np) ab[(long long)u * g.Pn + p0 + n0 + l15] = c0[q];
-        if (n1 + l15 < np) ab[(long long)u * g.Pn + p0 + n1 + l15] = c1[q];
+        for (int h = 0; h < 2; ++h) {
+          const int pq = (h ? n1 : n0) + 4 * slot;
+          const cg_f32x4 c = h ? c1 : c0;
+          float* dst = ab + (long long)u * g.Pn + p0 + pq;
+          if (VEC) { if (pq < np) *reinterpret_cast<float4*>(dst) = make_float4(c[0], c[1], c[2], c[3]); }
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (pq + q < np) dst[q] = c[q];
+          }
+        }
       }
     }
   }
@@ -332,9 +352,7 @@ __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGe
 #pragma unroll
   for (int u = 0; u < CG_ADJ_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   float* gb = t.g + (long long)b * t.Kc * g.Pn;
-  float racc[2][4][2], sa = 0.f;                   // per lane: sums of g and g e_hat of the wave's (at most two) dh tasks, d alpha
-#pragma unroll
-  for (int i = 0; i < 16; ++i) (&racc[0][0][0])[i] = 0.f;
+  float racc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sa = 0.f;   // per lane: sums of g and g e_hat (one channel per dh task), d alpha
   if (dbg & 64) tile1 = tile0;
   for (int tile = tile0; tile < tile1; ++tile) {
     const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
@@ -393,44 +411,48 @@ __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGe
         float av[4], b0v[4], b1v[4];
         cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {                     // C[position][channel]: four consecutive positions per lane
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
         }
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int u = 16 * mt + 4 * slot + q;
-        const bool uok = u < t.Kc;
-        const float gam = uok ? sK[8 * u + 6] : 0.f, bet = uok ? sK[8 * u + 3] : 0.f;
+      const int u = 16 * mt + l15;
+      if (u < t.Kc) {
+        const float gam = sK[8 * u + 6], bet = sK[8 * u + 3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int pp = (h ? n1 : n0) + l15;
-          const float dh = h ? c1[q] : c0[q];
-          if (uok && pp < np) {
-            const float eh = sE[u * g.PS + pp], keep = sP[u * g.PS + pp];
-            const float upre = (gam * eh + bet) * keep;
-            const float gg = (upre > 0.f ? dh : alpha * dh) * keep;
-            gb[(long long)u * g.Pn + p0 + pp] = gg;
-            racc[ti][q][0] += gg; racc[ti][q][1] += gg * eh;
-            if (!(upre > 0.f)) sa += dh * upre;
+          const int pq = (h ? n1 : n0) + 4 * slot;
+          if (pq >= np) continue;
+          const cg_f32x4 c = h ? c1 : c0;
+          const float4 e4 = *reinterpret_cast<const float4*>(sE + u * g.PS + pq), k4 = *reinterpret_cast<const float4*>(sP + u * g.PS + pq);
+          const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, kv[4] = {k4.x, k4.y, k4.z, k4.w};
+          float gv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool in = VEC || pq + q < np;
+            const float upre = (gam * ev[q] + bet) * kv[q];
+            gv[q] = in ? (upre > 0.f ? c[q] : alpha * c[q]) * kv[q] : 0.f;
+            racc[ti][0] += gv[q]; racc[ti][1] += gv[q] * ev[q];
+            if (in && !(upre > 0.f)) sa += c[q] * upre;
+          }
+          float* dst = gb + (long long)u * g.Pn + p0 + pq;
+          if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (pq + q < np) dst[q] = gv[q];
           }
         }
       }
     }
   }
-  // one cross-lane reduction for all tiles of the workgroup (rows of 16 lanes hold the positions of a channel)
+  // the four lanes l15, l15 + 16, .. of a wave hold partial sums of one channel: straight into the workgroup's f64 words
   sa = cg_row16_sum(sa);
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int w = wave + nw * ti;
     if (w >= MT * g.NP) break;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int u = 16 * (w / g.NP) + 4 * slot + q;
-      const float s1 = cg_row16_sum(racc[ti][q][0]), s2 = cg_row16_sum(racc[ti][q][1]);
-      if (l15 == 0 && u < t.Kc) { atomicAdd(&sRed[2 * u], (double)s1); atomicAdd(&sRed[2 * u + 1], (double)s2); }
-    }
+    const int u = 16 * (w / g.NP) + l15;
+    if (u < t.Kc) { atomicAdd(&sRed[2 * u], (double)racc[ti][0]); atomicAdd(&sRed[2 * u + 1], (double)racc[ti][1]); }
   }
   if (l15 == 0) atomicAdd(&sRed[2 * g.KcM], (double)sa);
   __syncthreads();
@@ -545,32 +567,30 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
         cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
         }
       }
+      // C[position][slab]: lane = slab k, four consecutive positions: the do image in one float4, dS by runs of equal a
+      const int k = 16 * mt + l15;
+      const bool kok = k < t.Kc;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int pp = (h ? n1 : n0) + l15, p = p0 + pp;
-        const bool pok = pp < np;
-        const int a = pok ? (int)cg_adj_div((unsigned)p, g.magicJ) : -1, bp = pok ? p - a * t.J : 0;
-        // a of the lanes 1, 2, 4, 8 further on in the row (-2: none), and of the previous lane
-        const int an0 = cg_dpp<0x101>(-2, a), an1 = cg_dpp<0x102>(-2, a), an2 = cg_dpp<0x104>(-2, a), an3 = cg_dpp<0x108>(-2, a);
-        const int aprev = cg_dpp<0x111>(-2, a);
-        const bool head = pok && aprev != a;
+        const int pq = (h ? n1 : n0) + 4 * slot;
+        const cg_f32x4 c = h ? c1 : c0;
+        float d[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int k = 16 * mt + 4 * slot + q;
-          const bool kok = k < t.Kc;                         // uniform over the 16 lanes of a row
-          const float d = (pok && kok) ? (h ? c1[q] : c0[q]) : 0.f;
-          sDO[k * g.PS + pp] = d;
-          float v = (pok && kok) ? d * sQ[k * g.JS + bp] : 0.f;
-          // segmented sum over the runs of equal a: afterwards the first lane of a run holds the run's total
-          { const float vn = cg_dpp<0x101>(0.f, v); if (an0 == a) v += vn; }
-          { const float vn = cg_dpp<0x102>(0.f, v); if (an1 == a) v += vn; }
-          { const float vn = cg_dpp<0x104>(0.f, v); if (an2 == a) v += vn; }
-          { const float vn = cg_dpp<0x108>(0.f, v); if (an3 == a) v += vn; }
-          if (head && kok) atomicAdd(&sDS[k * g.JS + a], v);
+        for (int q = 0; q < 4; ++q) d[q] = (kok && pq + q < np) ? c[q] : 0.f;
+        *reinterpret_cast<float4*>(sDO + k * g.PS + pq) = make_float4(d[0], d[1], d[2], d[3]);
+        if (kok && pq < np) {
+          int a = (int)cg_adj_div((unsigned)(p0 + pq), g.magicJ), bp = p0 + pq - a * t.J;
+          float acc = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (pq + q < np) acc += d[q] * sQ[k * g.JS + bp];
+            if (++bp == t.J) { if (a < t.J) atomicAdd(&sDS[k * g.JS + a], acc); acc = 0.f; bp = 0; ++a; }
+          }
+          if (bp != 0 && a < t.J) atomicAdd(&sDS[k * g.JS + a], acc);
         }
       }
     }

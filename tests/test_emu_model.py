@@ -2,6 +2,8 @@
 (T_in, T_out, V, C, hidden_dim, number of blocks)): the shipped kernels under the test-only HIP shim vs the oracle,
 eval and train mode, forward, loss, every gradient, attributes and running statistics.
 Full-size parity runs on the MI355X (tests/test_gpu_parity.py)."""
+import os
+
 import pytest
 
 import checks
@@ -18,10 +20,11 @@ def _emulated_kernels():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", ["eval"])          # train mode: the strict test below
 def test_tiny_model_matches_oracle(mode):
-    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=1, txc=1)
+    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=2, txc=1)
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.skipif(os.environ.get("CISTGCN_EMU_FULL", "0") != "1", reason="two more minutes of emulation; the same criterion runs on the MI355X at five sizes (test_gpu_parity.py); CISTGCN_EMU_FULL=1 enables it here")
 def test_tiny_model_every_gradient_strict():
     """all parameter gradients within 1e-4 * max(0.1, max|ref|) with the oracle on the branches the kernels took"""
     checks.check_model_branch_replay("cpu", 4, 4, 5, 3, "train", To=8, hidden=8, grad_floor=0.1, blocks=1, txc=1)   # B=3: batch statistics over two samples are ill-conditioned

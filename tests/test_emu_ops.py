@@ -20,7 +20,7 @@ def test_operator(check):
     if check in (checks.check_contract, checks.check_norm_act, checks.check_contract_kred):
         check("cpu", quick=True)
     elif check is checks.check_dstd_tail:
-        check("cpu", shapes=((3, 20, 7, 9), (2, 8, 10, 22)))
+        check("cpu", shapes=((3, 20, 7, 9),))
     elif check is checks.check_map2adj_tail:
         check("cpu", shapes=((3, 7, 9), (2, 6, 17)))
     else:
