@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-SHARDS = (2, 3)            # per-rank batch sizes (BASELINE configs[4]: mixed batch sizes)
+SHARDS = (3, 4)            # per-rank batch sizes (BASELINE configs[4]: mixed batch sizes)
 CFG = dict(C=4, T=4, V=5, To=8, hidden=8)
 
 
