@@ -104,6 +104,12 @@ class AdjTail(ctypes.Structure):
                 ("dW0", c_void_p), ("dW4", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p), ("dalpha", c_void_p)]
 
 
+class PwMaps(ctypes.Structure):
+    _fields_ = [("B", c_int), ("Cin", c_int), ("P", c_int), ("n", c_int), ("x", c_void_p),
+                ("W", c_void_p * 4), ("M", c_int * 4), ("y", c_void_p * 4), ("stats", c_void_p * 4),
+                ("dy", c_void_p * 4), ("dx", c_void_p), ("dW", c_void_p * 4), ("dW_ws", c_void_p)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -145,6 +151,9 @@ _SIGNATURES = {
     "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_bwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_ws_floats": [c_int],
+    "cg_pointwise_maps_fwd": [POINTER(PwMaps), P],
+    "cg_pointwise_maps_bwd": [POINTER(PwMaps), P],
+    "cg_pointwise_maps_ws_floats": [c_int],
     "cg_map2adj_tail_fwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_bwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_ws_floats": [c_int],

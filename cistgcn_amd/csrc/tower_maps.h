@@ -1,0 +1,21 @@
+// Argument block of the stacked pointwise maps (tower_maps.hip); mirrored by include/cistgcn_hip.h and cistgcn_amd/_lib.py.
+#pragma once
+
+#define CG_PWM_MAXN 4        // maps per launch
+#define CG_PWM_MAXROWS 128   // sum of the maps' output channels, each rounded up to 16
+
+// n pointwise (1x1) maps of ONE input: y_i[b,o,p] = sum_c W_i[o,c] x[b,c,p], x (B,Cin,P) contiguous, P % 4 == 0, Cin <= 64,
+// M_i <= 64, sum of ceil16(M_i) <= 128.  Forward reads x once for all maps; backward reads x and every dy once and produces the
+// input gradient of all maps (summed) and every weight gradient.
+struct CgPwMaps {
+  int B, Cin, P, n;
+  const float* x;
+  const float* W[CG_PWM_MAXN]; int M[CG_PWM_MAXN];
+  float* y[CG_PWM_MAXN];            // (B, M_i, P)
+  double* stats[CG_PWM_MAXN];       // optional [CG_STAT_REPLICAS][M_i][2] f64 sums of y_i, zero on entry
+  // backward
+  const float* dy[CG_PWM_MAXN];
+  float* dx;                        // (B, Cin, P): sum over the maps of W_i^T dy_i
+  float* dW[CG_PWM_MAXN];           // (M_i, Cin)
+  float* dW_ws;                     // cg_pointwise_maps_ws_floats(Cin) zeroed floats (replicated accumulators)
+};

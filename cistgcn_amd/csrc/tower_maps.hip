@@ -1,0 +1,310 @@
+// Stacked pointwise maps of one input: the first convolutions of the four Map2Adj towers of a DSTD_GC block (reference:
+// Map2Adj.time_compress[0] / joint_compress[0], CISTGCN.py:138-163, applied to the normalised block input by :183-186) read the
+// same (B,C,T,V) tensor.  As separate contractions the input travelled once per map forward and once per map and gradient
+// backward (the K-reduction weight gradient alone read it four times); here
+//   forward   y_i = W_i x for all maps from ONE staged tile of x (+ f64 channel sums of every y_i for the BatchNorm behind it)
+//   backward  dx = sum_i W_i^T dy_i and dW_i += dy_i x^T from ONE staged tile of x and of every dy_i
+// Persistent 512-thread workgroups walk [rows][PT positions] tiles (rows * PT = 8192: sixteen staging registers per thread and
+// tensor, next tile's loads in flight during the matrix work); products on v_mfma_f32_16x16x4_f32 with positions as the rows of
+// the result tile, so a lane ends with four consecutive positions of one channel (float4 stores); the maps' weights are stacked in
+// LDS, every map padded to a multiple of 16 rows.
+#include "cg_common.h"
+#include "cg_phase.h"
+#include "tower_maps.h"
+
+HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
+
+#define CG_PWM_THREADS 512     // eight waves per workgroup: a tile is rows * PT = 8192 elements, sixteen staging registers per thread
+#define CG_PWM_REPLICAS 16
+
+struct CgPwGeom {
+  int CinM, MM, WS, NT, CT;            // padded input channels, stacked rows, weight row stride, 16-row tiles of the stack / of Cin
+  int PT, PS, lgq;                     // tile width, LDS row stride, log2(PT / 4)
+  int tps, total, per;                 // tiles per sample, tiles, tiles per workgroup
+  int tile_map[CG_PWM_MAXROWS / 16], tile_row0[CG_PWM_MAXROWS / 16], row_base[CG_PWM_MAXN];
+};
+struct CgPwArgs { CgPwMaps t; CgPwGeom g; };
+
+// stacked weights -> sW [MM][WS]; rows beyond a map's M_i and columns beyond Cin are zero
+__device__ __forceinline__ void cg_pwm_weights(const CgPwArgs& a, float* sW) {
+  const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  const int n = g.MM * g.WS;
+#pragma unroll 4
+  for (int e = threadIdx.x; e < n; e += CG_PWM_THREADS) {
+    const int r = e / g.WS, c = e - r * g.WS, tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
+    sW[e] = (m < t.M[i] && c < t.Cin) ? t.W[i][m * t.Cin + c] : 0.f;
+  }
+}
+
+// a thread's share of a [rows][PT] tile: float4 number r is element 4 * (tid + 512 r) of the tile image
+template <typename SRC>
+__device__ __forceinline__ void cg_pwm_fetch(const CgPwGeom& g, int np, float buf[16], SRC src) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+    const float* p = pp < np ? src(row) : nullptr;         // nullptr: row outside the tensor
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p != nullptr) v = *reinterpret_cast<const float4*>(p + pp);
+    buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
+  }
+}
+__device__ __forceinline__ void cg_pwm_commit(const CgPwGeom& g, int rows, const float buf[16], float* img) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+    if (row < rows) *reinterpret_cast<float4*>(img + row * g.PS + pp) = make_float4(buf[4 * r], buf[4 * r + 1], buf[4 * r + 2], buf[4 * r + 3]);
+  }
+}
+
+// ======================================================================================================================
+// forward
+// ======================================================================================================================
+__global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) {
+  const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  float* sX = reinterpret_cast<float*>(cg_dyn_lds);              // [CinM][PS]
+  float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
+  double* sStat = reinterpret_cast<double*>(sW + g.MM * g.WS + ((g.CinM * g.PS + g.MM * g.WS) & 1));      // [MM][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
+  if (lid0 >= g.total) return;
+  float xbuf[16];
+  auto xsrc = [&](int lid) {
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT;
+    const float* base = t.x + (long long)b * t.Cin * t.P + p0;
+    cg_pwm_fetch(g, min(g.PT, t.P - p0), xbuf, [&](int row) { return row < t.Cin ? base + (long long)row * t.P : nullptr; });
+  };
+  xsrc(lid0);
+  cg_pwm_weights(a, sW);
+  for (int e = tid; e < g.CinM * g.PS; e += CG_PWM_THREADS) sX[e] = 0.f;
+  const bool stats = t.stats[0] != nullptr;
+  if (stats) for (int e = tid; e < 2 * g.MM; e += CG_PWM_THREADS) sStat[e] = 0.0;
+  for (int lid = lid0; lid < lid1; ++lid) {
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    __syncthreads();
+    cg_pwm_commit(g, t.Cin, xbuf, sX);
+    __syncthreads();
+    if (lid + 1 < lid1) xsrc(lid + 1);
+    for (int w = wave; w < (g.PT / 32) * g.NT; w += CG_PWM_THREADS / 64) {
+      const int pg = w / g.NT, nt = w - pg * g.NT, n0 = 32 * pg, n1 = n0 + 16;
+      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      const float* wp = cg_tfrag_ptr<0>(sW + 16 * nt * g.WS, g.WS, l15, slot);
+      const float* xp0 = cg_tfrag_ptr<1>(sX + n0, g.PS, l15, slot);
+      const float* xp1 = cg_tfrag_ptr<1>(sX + n1, g.PS, l15, slot);
+      for (int k0 = 0; k0 < g.CinM; k0 += 16) {
+        float wv[4], x0v[4], x1v[4];
+        cg_tfrag<0>(wp, g.WS, k0, wv); cg_tfrag<1>(xp0, g.PS, k0, x0v); cg_tfrag<1>(xp1, g.PS, k0, x1v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                     // C[position][output channel]
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0v[s], wv[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1v[s], wv[s], c1, 0, 0, 0);
+        }
+      }
+      const int i = g.tile_map[nt], m = g.tile_row0[nt] + l15;
+      if (m < t.M[i]) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pq = (h ? n1 : n0) + 4 * slot;
+          const cg_f32x4 c = h ? c1 : c0;
+          if (pq < np) {
+            *reinterpret_cast<float4*>(t.y[i] + ((long long)b * t.M[i] + m) * t.P + p0 + pq) = make_float4(c[0], c[1], c[2], c[3]);
+            s1 += (c[0] + c[1]) + (c[2] + c[3]); s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+          }
+        }
+        if (stats) { atomicAdd(&sStat[2 * (16 * nt + l15)], (double)s1); atomicAdd(&sStat[2 * (16 * nt + l15) + 1], (double)s2); }
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    for (int e = tid; e < 2 * g.MM; e += CG_PWM_THREADS) {
+      const int r = e >> 1, tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
+      if (m < t.M[i]) atomicAdd(&t.stats[i][((long long)(blockIdx.x % CG_STAT_REPLICAS) * t.M[i] + m) * 2 + (e & 1)], sStat[e]);
+    }
+  }
+}
+
+// ======================================================================================================================
+// backward
+// ======================================================================================================================
+#define CG_PWM_MAXW 4        // weight-gradient register tiles per wave: (128 / 16) * (64 / 16) / 8 waves
+
+__global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) {
+  const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  float* sD = reinterpret_cast<float*>(cg_dyn_lds);              // [MM][PS]   dy of every map, stacked
+  float* sX = sD + g.MM * g.PS;                                   // [CinM][PS]
+  float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_PWM_THREADS / 64;
+  const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
+  if (lid0 >= g.total) return;
+  float xbuf[16], dbuf[16];
+  auto fetch = [&](int lid) {
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    const float* xb = t.x + (long long)b * t.Cin * t.P + p0;
+    cg_pwm_fetch(g, np, xbuf, [&](int row) { return row < t.Cin ? xb + (long long)row * t.P : nullptr; });
+    cg_pwm_fetch(g, np, dbuf, [&](int row) -> const float* {
+      if (row >= g.MM) return nullptr;
+      const int tile = row >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (row & 15);
+      return m < t.M[i] ? t.dy[i] + ((long long)b * t.M[i] + m) * t.P + p0 : nullptr;
+    });
+  };
+  fetch(lid0);
+  cg_pwm_weights(a, sW);
+  for (int e = tid; e < (g.MM + g.CinM) * g.PS; e += CG_PWM_THREADS) sD[e] = 0.f;
+  cg_f32x4 wacc[CG_PWM_MAXW];
+#pragma unroll
+  for (int u = 0; u < CG_PWM_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int lid = lid0; lid < lid1; ++lid) {
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    __syncthreads();
+    cg_pwm_commit(g, g.MM, dbuf, sD);                              // rows of the padding and positions beyond the tensor arrive as zeros
+    cg_pwm_commit(g, t.Cin, xbuf, sX);
+    __syncthreads();
+    if (lid + 1 < lid1) fetch(lid + 1);
+    // dW[m][c] += sum_p dy[m][p] x[c][p]: two register tiles at a time (independent MFMA chains)
+#pragma unroll
+    for (int u = 0; u < CG_PWM_MAXW; u += 2) {
+      const int id0 = u * nw + wave, id1 = (u + 1) * nw + wave;
+      if (id0 < g.NT * g.CT) {
+        const bool two = id1 < g.NT * g.CT;
+        const int mt0 = id0 / g.CT, ct0 = id0 - mt0 * g.CT, mt1 = two ? id1 / g.CT : mt0, ct1 = two ? id1 - mt1 * g.CT : ct0;
+        const float* ap0 = cg_tfrag_ptr<0>(sD + 16 * mt0 * g.PS, g.PS, l15, slot);
+        const float* bp0 = cg_tfrag_ptr<0>(sX + 16 * ct0 * g.PS, g.PS, l15, slot);
+        const float* ap1 = cg_tfrag_ptr<0>(sD + 16 * mt1 * g.PS, g.PS, l15, slot);
+        const float* bp1 = cg_tfrag_ptr<0>(sX + 16 * ct1 * g.PS, g.PS, l15, slot);
+        cg_f32x4 w0 = wacc[u], w1 = wacc[u + 1];
+#pragma unroll 2
+        for (int k0 = 0; k0 < g.PT; k0 += 16) {
+          float a0[4], b0[4], a1[4], b1[4];
+          cg_tfrag<0>(ap0, g.PS, k0, a0); cg_tfrag<0>(bp0, g.PS, k0, b0); cg_tfrag<0>(ap1, g.PS, k0, a1); cg_tfrag<0>(bp1, g.PS, k0, b1);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], w0, 0, 0, 0);
+            w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], w1, 0, 0, 0);
+          }
+        }
+        wacc[u] = w0;
+        if (two) wacc[u + 1] = w1;
+      }
+    }
+    // dx[p][c] = sum_m dy[m][p] W[m][c]
+    for (int w = wave; w < (g.PT / 32) * g.CT; w += nw) {
+      const int pg = w / g.CT, ct = w - pg * g.CT, n0 = 32 * pg, n1 = n0 + 16;
+      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      const float* wp = cg_tfrag_ptr<1>(sW + 16 * ct, g.WS, l15, slot);
+      const float* dp0 = cg_tfrag_ptr<1>(sD + n0, g.PS, l15, slot);
+      const float* dp1 = cg_tfrag_ptr<1>(sD + n1, g.PS, l15, slot);
+      for (int k0 = 0; k0 < g.MM; k0 += 16) {
+        float wv[4], d0v[4], d1v[4];
+        cg_tfrag<1>(wp, g.WS, k0, wv); cg_tfrag<1>(dp0, g.PS, k0, d0v); cg_tfrag<1>(dp1, g.PS, k0, d1v);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d0v[s], wv[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d1v[s], wv[s], c1, 0, 0, 0);
+        }
+      }
+      const int c = 16 * ct + l15;
+      if (c < t.Cin) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pq = (h ? n1 : n0) + 4 * slot;
+          const cg_f32x4 cc = h ? c1 : c0;
+          if (pq < np) *reinterpret_cast<float4*>(t.dx + ((long long)b * t.Cin + c) * t.P + p0 + pq) = make_float4(cc[0], cc[1], cc[2], cc[3]);
+        }
+      }
+    }
+  }
+  float* ws = t.dW_ws + (long long)(blockIdx.x % CG_PWM_REPLICAS) * CG_PWM_MAXROWS * t.Cin;
+#pragma unroll
+  for (int u = 0; u < CG_PWM_MAXW; ++u) {
+    const int id = u * nw + wave;
+    if (id < g.NT * g.CT) {
+      const int mt = id / g.CT, ct = id - mt * g.CT;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 16 * mt + 4 * slot + q, c = 16 * ct + l15;
+        if (c < t.Cin) atomicAdd(&ws[r * t.Cin + c], wacc[u][q]);
+      }
+    }
+  }
+}
+
+__global__ void cg_pwm_fold_kernel(CgPwArgs a) {
+  const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  const int i = blockIdx.y;
+  if (i >= t.n) return;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < t.M[i] * t.Cin; e += gridDim.x * blockDim.x) {
+    const int m = e / t.Cin, c = e - m * t.Cin;
+    float s = 0.f;
+    for (int r = 0; r < CG_PWM_REPLICAS; ++r) s += t.dW_ws[((long long)r * CG_PWM_MAXROWS + g.row_base[i] + m) * t.Cin + c];
+    t.dW[i][e] = s;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
+  if (!t || t->n <= 0 || t->n > CG_PWM_MAXN) return CG_EARG;
+  if (t->B <= 0 || t->Cin <= 0 || t->Cin > 64 || t->P <= 0 || (t->P & 3)) return CG_ESHAPE;
+  if (!t->x) return CG_EARG;
+  int rows = 0, tile = 0;
+  for (int i = 0; i < t->n; ++i) {
+    if (t->M[i] <= 0 || t->M[i] > 64) return CG_ESHAPE;
+    if (!t->W[i]) return CG_EARG;
+    g->row_base[i] = rows;
+    for (int r0 = 0; r0 < t->M[i]; r0 += 16) { if (tile >= CG_PWM_MAXROWS / 16) return CG_ESHAPE; g->tile_map[tile] = i; g->tile_row0[tile] = r0; ++tile; }
+    rows = 16 * tile;
+  }
+  for (int k = tile; k < CG_PWM_MAXROWS / 16; ++k) { g->tile_map[k] = 0; g->tile_row0[k] = 1 << 20; }
+  for (int i = t->n; i < CG_PWM_MAXN; ++i) g->row_base[i] = 0;
+  g->CinM = (t->Cin + 15) & ~15; g->MM = rows; g->WS = g->CinM + 4; g->NT = rows / 16; g->CT = g->CinM / 16;
+  const int big = bwd ? (g->MM > g->CinM ? g->MM : g->CinM) : g->CinM;
+  int pt = 16 * CG_PWM_THREADS / big;
+  pt = pt > 256 ? 256 : pt;
+  g->PT = pt; g->PS = pt + 4;
+  g->lgq = 0;
+  while ((4 << g->lgq) < pt) ++g->lgq;
+  g->tps = (t->P + pt - 1) / pt;
+  g->total = t->B * g->tps;
+  const int nwg = g->total < 512 ? g->total : 512;
+  g->per = (g->total + nwg - 1) / nwg;
+  return CG_OK;
+}
+
+extern "C" long long cg_pointwise_maps_ws_floats(int Cin) { return (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * Cin; }
+
+// include/cistgcn_hip.h : cg_pointwise_maps_fwd / cg_pointwise_maps_bwd
+extern "C" int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream_) {
+  CgPwArgs a;
+  int st = cg_pwm_geometry(t, false, &a.g);
+  if (st != CG_OK) return st;
+  a.t = *t;
+  for (int i = 0; i < t->n; ++i) {
+    if (!t->y[i]) return CG_EARG;
+    if ((t->stats[i] != nullptr) != (t->stats[0] != nullptr)) return CG_EARG;
+  }
+  const size_t lds = ((size_t)a.g.CinM * a.g.PS + (size_t)a.g.MM * a.g.WS + 2 + (size_t)4 * a.g.MM) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)cg_pwm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
+  hipLaunchKernelGGL(cg_pwm_fwd_kernel, dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, (hipStream_t)stream_, a);
+  return cg_launch_status();
+}
+
+extern "C" int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream_) {
+  CgPwArgs a;
+  int st = cg_pwm_geometry(t, true, &a.g);
+  if (st != CG_OK) return st;
+  a.t = *t;
+  if (!t->dx || !t->dW_ws) return CG_EARG;
+  for (int i = 0; i < t->n; ++i) if (!t->dy[i] || !t->dW[i]) return CG_EARG;
+  const size_t lds = ((size_t)(a.g.MM + a.g.CinM) * a.g.PS + (size_t)a.g.MM * a.g.WS) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)cg_pwm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(cg_pwm_bwd_kernel, dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, stream, a);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  hipLaunchKernelGGL(cg_pwm_fold_kernel, dim3(8, (unsigned)t->n), dim3(256), 0, stream, a);
+  return cg_launch_status();
+}

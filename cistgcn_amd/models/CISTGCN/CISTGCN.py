@@ -225,6 +225,7 @@ class CISTGCN(nn.Module):
         # True: everything behind the tcn convolutions of a block as phase kernels (ops.dstd_tail); CISTGCN_FUSED_TAIL=0 is a tuning aid
         self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
         self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
+        self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
@@ -386,21 +387,32 @@ class CISTGCN(nn.Module):
         has_bres = not isinstance(m.residual, nn.Identity)
         # the normalised input feeds the statistics, the first-level maps, both graph stages and the identity residuals:
         # one alias per consumer, so that backward sums their gradients in one launch (ops.fanout)
-        xa = list(ops.fanout(xn0, 4 + (0 if has_res else 2) + (0 if has_bres else 1)))
+        maps = [d.map_to_adj for d in doms]
+        tower_in = [c for a in maps for c in (a.time_compress[0], a.joint_compress[0])]
+        tower_w = [c.weight.view(c.out_channels, c.in_channels) for c in tower_in]
+        # the four tower convolutions read the block input in one pass, forward and backward (csrc/tower_maps.hip)
+        stacked = self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(xn0, tower_w)
+        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (0 if has_res else 2) + (0 if has_bres else 1)))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
-        x_res = xa[4:6] if not has_res else None
+        k = 4
+        x_maps = None
+        if stacked:
+            x_maps, k = xa[4], 5
+        x_res = xa[k:k + 2] if not has_res else None
         x_bres = xa[-1] if not has_bres else None
         stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
-        maps = [d.map_to_adj for d in doms]
         # 1. every first-level map of xn
         items = [_rows_item(xn, m.conv_s[0], tr), _rows_item(xn, m.conv_t[0], tr)]
-        for a in maps:
-            items += [_pw_item(xn, a.time_compress[0], tr), _pw_item(xn, a.joint_compress[0], tr)]
+        if not stacked:
+            for a in maps:
+                items += [_pw_item(xn, a.time_compress[0], tr), _pw_item(xn, a.joint_compress[0], tr)]
         if has_res:
             items += [_pw_item(xn, d.residual[0], tr) for d in doms]
         if has_bres:
             items.append(_pw_item(xn, m.residual[0], tr))
         o = _run_items(items)
+        if stacked:
+            o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
         gs, gt, tc = o[0], o[1], o[2:6]
         # 2. their BatchNorm / PReLU tails
         calls = [dict(x=gs, bn=m.conv_s[1], drop=True, prelu=m.conv_s[3]), dict(x=gt, bn=m.conv_t[1], drop=True, prelu=m.conv_t[3])]

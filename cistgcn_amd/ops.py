@@ -1596,3 +1596,73 @@ def map2adj_tail(seeds, expansors, train, drop_p=0.0, salts=(0, 0), taps=None):
         kc = e[0].out_channels
         ts += [s, q, e[0].weight.view(kc, kc), e[1].weight, e[1].bias, e[3].weight, e[4].weight.view(kc, kc)]
     return _Map2AdjTail.apply(cfg, *ts)
+
+
+def pointwise_maps_ok(x, weights):
+    """True when `pointwise_maps` takes this problem (else the caller batches the maps through the generic contraction)."""
+    if x.dim() != 4 or not x.is_contiguous() or len(weights) > 4:
+        return False
+    B, C, H, W = x.shape
+    rows = sum((w.shape[0] + 15) // 16 * 16 for w in weights)
+    return C <= 64 and (H * W) % 4 == 0 and rows <= 128 and all(w.shape[0] <= 64 for w in weights)
+
+
+class _PointwiseMaps(torch.autograd.Function):
+    """y_i = W_i x for up to four 1x1 convolutions of one input, CISTGCN.py:138-163 / :183-186 (see csrc/tower_maps.hip).
+    Tensor inputs: x W_1 .. W_n; outputs y_1 .. y_n, then their f64 channel sums (or None)."""
+
+    @staticmethod
+    def _block(x, ws):
+        B, C, H, W = x.shape
+        t = _lib.PwMaps()
+        t.B, t.Cin, t.P, t.n = B, C, H * W, len(ws)
+        t.x = x.data_ptr()
+        for i, w in enumerate(ws):
+            t.W[i], t.M[i] = w.data_ptr(), w.shape[0]
+        return t
+
+    @staticmethod
+    def forward(ctx, want_stats, x, *ws):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        B, C, H, W = x.shape
+        dev, f32 = x.device, torch.float32
+        ws = [w if w.is_contiguous() else _copy(w) for w in ws]
+        t = _PointwiseMaps._block(x, ws)
+        ys = [torch.empty(B, w.shape[0], H, W, dtype=f32, device=dev) for w in ws]
+        stats = [_arena(dev).take(2 * w.shape[0] * _lib.STAT_REPLICAS) for w in ws] if want_stats else [None] * len(ws)
+        for i in range(len(ws)):
+            t.y[i], t.stats[i] = ys[i].data_ptr(), _ptr(stats[i])
+        _lib.call("cg_pointwise_maps_fwd", ctypes.byref(t), _stream(x))
+        ctx.save_for_backward(x, *ws)
+        if want_stats:
+            ctx.mark_non_differentiable(*stats)
+        return tuple(ys) + tuple(stats)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, *ws = ctx.saved_tensors
+        n = len(ws)
+        dys = grads[:n]
+        if any(d is None for d in dys):
+            raise RuntimeError("pointwise_maps: every map needs a gradient")
+        dys = [d if d.is_contiguous() else _copy(d) for d in dys]
+        dev, f32 = x.device, torch.float32
+        t = _PointwiseMaps._block(x, ws)
+        dx = torch.empty_like(x)
+        dws = [torch.empty_like(w) for w in ws]
+        zb, _ = _zeros(int(_lib.lib().cg_pointwise_maps_ws_floats(x.shape[1])), dev)
+        for i in range(n):
+            t.dy[i], t.dW[i] = dys[i].data_ptr(), dws[i].data_ptr()
+        t.dx, t.dW_ws = dx.data_ptr(), zb.data_ptr()
+        _lib.call("cg_pointwise_maps_bwd", ctypes.byref(t), _stream(x))
+        del dys
+        return (None, dx if ctx.needs_input_grad[1] else None) + tuple(dw if ctx.needs_input_grad[2 + i] else None for i, dw in enumerate(dws))
+
+
+def pointwise_maps(x, weights, want_stats=False):
+    """[(y_i, channel sums or None)] of the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W): one read of x forward, one read of x and
+    of every gradient backward.  Shapes outside `pointwise_maps_ok` are the caller's business."""
+    out = _PointwiseMaps.apply(bool(want_stats), x, *weights)
+    n = len(weights)
+    return [(out[i], out[n + i] if want_stats else None) for i in range(n)]

@@ -230,6 +230,27 @@ int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream);
 int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream);
 long long cg_dstd_tail_ws_floats(int C);
 
+/* ---- stacked pointwise maps of one input: the first convolutions of the Map2Adj towers of a block, CISTGCN.py:138-163 applied
+ * to the normalised block input by :183-186 (up to four 1x1 convolutions of the same (B,C,T,V) tensor).  Forward: every y_i =
+ * W_i x from one read of x, with the f64 channel sums of y_i (train-mode BatchNorm behind it).  Backward: dx = sum_i W_i^T dy_i and
+ * every dW_i = dy_i x^T from one read of x and of each dy_i.  x (B,Cin,P) contiguous, P = T*V with P % 4 == 0, Cin <= 64,
+ * M_i <= 64, sum of ceil16(M_i) <= 128; other shapes: CG_ESHAPE (the caller uses cg_contract_many). */
+#define CG_PWM_MAXN 4
+typedef struct CgPwMaps {
+  int B, Cin, P, n;
+  const float* x;
+  const float* W[CG_PWM_MAXN]; int M[CG_PWM_MAXN];       /* (M_i, Cin) */
+  float* y[CG_PWM_MAXN];                                 /* (B, M_i, P) */
+  double* stats[CG_PWM_MAXN];                            /* all null, or [CG_STAT_REPLICAS][M_i][2] each, zero on entry */
+  const float* dy[CG_PWM_MAXN];
+  float* dx;                                             /* (B, Cin, P) */
+  float* dW[CG_PWM_MAXN];
+  float* dW_ws;                                          /* cg_pointwise_maps_ws_floats(Cin) zeroed floats */
+} CgPwMaps;
+int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream);
+int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream);
+long long cg_pointwise_maps_ws_floats(int Cin);
+
 /* ---- tail of the interpretability map, Map2Adj.forward CISTGCN.py:183-189 (expansor :165-170) ------------------------
  * s (B,V,T), q (B,T,V): outputs of the joint / time towers.  Seed o = s (x) q (space: o[b,v,t,u] = s[b,v,t] q[b,u,v];
  * time: o[b,t,v,w] = s[b,v,t] q[b,t,w]) -> conv W0 over the slab axis -> BatchNorm -> Dropout -> PReLU -> conv W4 = Adj.
