@@ -226,6 +226,7 @@ class CISTGCN(nn.Module):
         self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
         self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
+        self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
@@ -391,7 +392,10 @@ class CISTGCN(nn.Module):
         tower_in = [c for a in maps for c in (a.time_compress[0], a.joint_compress[0])]
         tower_w = [c.weight.view(c.out_channels, c.in_channels) for c in tower_in]
         # the four tower convolutions read the block input in one pass, forward and backward (csrc/tower_maps.hip)
-        stacked = self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(xn0, tower_w)
+        # (both stackings below pay off once the block input is worth the two or three extra small launches: measured break-even
+        # between the B=16 / C=8 and the B=256 / C=64 workloads)
+        big = xn0.numel() >= self.stack_min_elements
+        stacked = big and self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(xn0, tower_w)
         xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (0 if has_res else 2) + (0 if has_bres else 1)))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
         k = 4
@@ -402,7 +406,16 @@ class CISTGCN(nn.Module):
         x_bres = xa[-1] if not has_bres else None
         stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
         # 1. every first-level map of xn
-        items = [_rows_item(xn, m.conv_s[0], tr), _rows_item(xn, m.conv_t[0], tr)]
+        cs, ct = m.conv_s[0], m.conv_t[0]
+        # the two gate paths start with the same (T,1) convolution shape on the same input: one contraction of the stacked weights
+        # (the block input travels once instead of twice, forward and in both gradients)
+        gates = big and self.fused_maps and cs.weight.shape == ct.weight.shape and cs.bias is None and ct.bias is None
+        if gates:
+            O = cs.out_channels
+            w2 = ops.cat_channels([cs.weight.view(1, O, -1), ct.weight.view(1, O, -1)]).view(2 * O, cs.in_channels, xn.shape[2])
+            items = [(("och,bchw->bow", w2, xn, None, None, None), None)]
+        else:
+            items = [_rows_item(xn, cs, tr), _rows_item(xn, ct, tr)]
         if not stacked:
             for a in maps:
                 items += [_pw_item(xn, a.time_compress[0], tr), _pw_item(xn, a.joint_compress[0], tr)]
@@ -411,6 +424,8 @@ class CISTGCN(nn.Module):
         if has_bres:
             items.append(_pw_item(xn, m.residual[0], tr))
         o = _run_items(items)
+        if gates:
+            o = [(g.unsqueeze(2), None) for g in ops.split_channels(o[0][0], (O, O))] + o[1:]
         if stacked:
             o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
         gs, gt, tc = o[0], o[1], o[2:6]

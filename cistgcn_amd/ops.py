@@ -1666,3 +1666,40 @@ def pointwise_maps(x, weights, want_stats=False):
     out = _PointwiseMaps.apply(bool(want_stats), x, *weights)
     n = len(weights)
     return [(out[i], out[n + i] if want_stats else None) for i in range(n)]
+
+
+class _SplitChannels(torch.autograd.Function):
+    """Inverse of `cat_channels`: channel ranges of one tensor as views (no copy); backward gathers the pieces' gradients."""
+
+    @staticmethod
+    def forward(ctx, sizes, y):
+        ctx.set_materialize_grads(False)
+        ctx.sizes, ctx.shape = sizes, tuple(y.shape)
+        outs, c0 = [], 0
+        for c in sizes:
+            outs.append(y.narrow(1, c0, c))
+            c0 += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        dev = next(g for g in gs if g is not None).device
+        dy = torch.empty(ctx.shape, dtype=torch.float32, device=dev)
+        c0, items = 0, []
+        for c, g in zip(ctx.sizes, gs):
+            dst = dy.narrow(1, c0, c)
+            c0 += c
+            if g is None:
+                raise RuntimeError("split_channels: every piece needs a gradient")
+            it = _lib.CopyItem()
+            it.y, it.yv, it.a, it.av = dst.data_ptr(), _view4(dst), g.data_ptr(), _view4(g)
+            items.append(it)
+        for i0 in range(0, len(items), 4):
+            chunk = items[i0:i0 + 4]
+            _lib.call("cg_copy_many", (_lib.CopyItem * len(chunk))(*chunk), len(chunk), _stream(dy))
+        return None, dy
+
+
+def split_channels(y, sizes):
+    """Views of consecutive channel ranges of y (B,C,...), differentiable (the gradients are gathered by one copy launch)."""
+    return _SplitChannels.apply(tuple(int(s) for s in sizes), y)

@@ -564,7 +564,7 @@ def _attr(net, dotted):
     return obj
 
 
-def build_pair(C, T, V, device, state=None, seed=0, fused=True, staged=True, **cfg_kw):
+def build_pair(C, T, V, device, state=None, seed=0, fused=True, staged=True, stack_all=False, **cfg_kw):
     from cistgcn_amd.models import CISTGCN_0
     torch.manual_seed(seed)
     ora = O.CISTGCN(*make_cfg(C, T, V, **cfg_kw))
@@ -575,16 +575,18 @@ def build_pair(C, T, V, device, state=None, seed=0, fused=True, staged=True, **c
     net.load_state_dict(ora.state_dict(), strict=True)
     net.fused_domain = fused
     net.staged = staged
+    if stack_all:                      # stacked first-level maps (tower_maps.hip, stacked gate convolutions) at any size
+        net.stack_min_elements = 0
     return net.to(device), ora
 
 
-def check_model_golden(device, name, modes=("eval", "train"), fused=True, staged=True):
+def check_model_golden(device, name, modes=("eval", "train"), fused=True, staged=True, stack_all=False):
     """Product model vs the vectors the real reference produced (tests/golden, tools/gen_golden.py)."""
     from helpers import grad_summary
     rec = load_case(name)
     C, T, V, B = [int(v) for v in rec["meta"]]
     for mode in modes:
-        net, _ = build_pair(C, T, V, device, state_of(rec), fused=fused, staged=staged)
+        net, _ = build_pair(C, T, V, device, state_of(rec), fused=fused, staged=staged, stack_all=stack_all)
         net.train(mode == "train")
         x = torch.from_numpy(rec["x"]).to(device).requires_grad_(True)
         tgt = torch.from_numpy(rec["target"]).to(device)

@@ -20,7 +20,7 @@ def _emulated_kernels():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", ["eval"])          # train mode: the strict test below
 def test_tiny_model_matches_oracle(mode):
-    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=2, txc=1)
+    checks.check_model_vs_oracle("cpu", 4, 4, 5, 2, mode, To=8, hidden=8, blocks=2, txc=1, stack_all=True)
 
 
 @pytest.mark.timeout(900)

@@ -41,6 +41,13 @@ def test_model_alternative_launch_plans(mode, fused, staged):
     checks.check_model_golden("cuda", "h36m_c8_t10_v22", modes=(mode,), fused=fused, staged=staged)
 
 
+@pytest.mark.parametrize("name", ["h36m_c8_t50_v22", "amass_c16_t10_v18"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_model_stacked_first_level_maps(name, mode):
+    # the stacked tower / gate convolutions (one read of the block input) are switched on by size; here at the golden sizes too
+    checks.check_model_golden("cuda", name, modes=(mode,), stack_all=True)
+
+
 @pytest.mark.parametrize("cfg", [(64, 10, 22, 8), (32, 50, 25, 4), (16, 10, 18, 6), (64, 50, 22, 4)], ids=str)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_model_matches_oracle_wide(cfg, mode):
