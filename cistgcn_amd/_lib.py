@@ -110,6 +110,12 @@ class PwMaps(ctypes.Structure):
                 ("dy", c_void_p * 4), ("dx", c_void_p), ("dW", c_void_p * 4), ("dW_ws", c_void_p)]
 
 
+class FpnConv(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("O", c_int), ("H", c_int), ("W", c_int), ("n", c_int), ("dil", c_int * 3), ("pad", c_int),
+                ("x", c_void_p), ("xs", c_longlong * 3), ("w", c_void_p * 3), ("bias", c_void_p * 3), ("y", c_void_p * 3),
+                ("dy", c_void_p * 3), ("dx", c_void_p), ("dw", c_void_p * 3), ("db", c_void_p * 3), ("ws", c_void_p)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -151,6 +157,10 @@ _SIGNATURES = {
     "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_bwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_ws_floats": [c_int],
+    "cg_fpn_conv_fwd": [POINTER(FpnConv), P],
+    "cg_fpn_conv_bwd": [POINTER(FpnConv), P],
+    "cg_fpn_conv_supported": [c_int, c_int, c_int, c_int, c_int],
+    "cg_fpn_conv_ws_floats": [c_int, c_int, c_int],
     "cg_pointwise_maps_fwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_bwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_ws_floats": [c_int],

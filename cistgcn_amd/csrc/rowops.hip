@@ -120,25 +120,29 @@ extern "C" int cg_chan_stats(const float* x, const CgView4* xv, const float* pre
   return cg_chan_stats_many(&a, 1, stream_);
 }
 
-// per-channel plain sum in f32 output (bias gradients): out[c] = sum_{b,p} x
-__global__ void cg_chan_sum_kernel(const float* __restrict__ x, CgView4 xv, float* __restrict__ out) {
+// per-channel plain sum (bias gradients): out[c] += sum_{b,p} x, `out` zero on entry.  A workgroup per (channel, batch slice):
+// f64 inside the workgroup, one f32 atomic per workgroup.
+__global__ void cg_chan_sum_kernel(const float* __restrict__ x, CgView4 xv, float* __restrict__ out, int rb) {
   __shared__ double red[16];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, b0 = blockIdx.y * rb, b1 = min((int)xv.n[0], b0 + rb);
   const long long P = xv.n[2] * xv.n[3];
   double s = 0.0;
-  for (int b = 0; b < xv.n[0]; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const long long base = cg_row_base(xv, b, c);
     CG_ROW_LOOP(P, p) { CG_POS(xv, p) s += (double)x[base + CG_OFF(xv)]; }
   }
   s = cg_block_sum(s, red);
-  if (threadIdx.x == 0) out[c] = (float)s;
+  if (threadIdx.x == 0) atomicAdd(&out[c], (float)s);
 }
 
 extern "C" int cg_chan_sum(const float* x, const CgView4* xv, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!x || !xv || !out) return CG_EARG;
-  if (xv->n[1] <= 0) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_chan_sum_kernel, dim3((unsigned)xv->n[1]), dim3(256), 0, stream, x, *xv, out);
+  if (xv->n[1] <= 0 || xv->n[0] <= 0) return CG_ESHAPE;
+  long long nb = 1024 / xv->n[1];                       // ~1024 workgroups
+  nb = nb < 1 ? 1 : (nb > xv->n[0] ? xv->n[0] : nb);
+  const int rb = (int)((xv->n[0] + nb - 1) / nb);
+  hipLaunchKernelGGL(cg_chan_sum_kernel, dim3((unsigned)xv->n[1], (unsigned)((xv->n[0] + rb - 1) / rb)), dim3(256), 0, stream, x, *xv, out, rb);
   return cg_launch_status();
 }
 

@@ -426,6 +426,13 @@ def _sum_keep(t, labels, keep):
     rest = "".join(l for l in labels if l not in keep)
     if not rest:
         return t
+    if t.dim() == 4 and keep == labels[1]:
+        # bias gradient of a convolution: a plain channel sum (the contraction took 170 us for a 5.6 MB tensor: split-K with
+        # one output column)
+        out, _ = _zeros(t.shape[1], t.device)
+        v = _view4(t)
+        _lib.call("cg_chan_sum", _ptr(t), ctypes.byref(v), _ptr(out), _stream(t))
+        return out
     sizes = {l: n for l, n in zip(labels, t.shape)}
     return _contract_raw("%s,%s->%s" % (labels, rest, keep), t, one, sizes=sizes, sx={l: 0 for l in rest})
 
@@ -1086,7 +1093,70 @@ def dilated_convs(x, convs):
     wb = []
     for c in convs:
         wb += [c.weight, c.bias]
+    B, C, H, W = x.shape
+    O = convs[0].out_channels
+    # (one workgroup per sample: below ~64 samples the chip is mostly idle and the generic contraction is faster)
+    if (_FPN_KERNELS and B >= _FPN_MIN_BATCH and x.stride(3) == 1 and all(c.out_channels == O and c.bias is not None for c in convs)
+            and _lib.lib().cg_fpn_conv_supported(B, C, O, H, W)):
+        return _FpnConvs.apply(x, dils, *wb)
     return _DilatedConvs.apply(x, dils, *wb)
+
+
+_FPN_KERNELS = __import__("os").environ.get("CISTGCN_FPN_KERNELS", "1") != "0"     # 0: the generic contraction (tuning aid)
+_FPN_MIN_BATCH = int(__import__("os").environ.get("CISTGCN_FPN_MIN_BATCH", "64"))
+
+
+class _FpnConvs(torch.autograd.Function):
+    """The dilated convolutions of one FPN block on whole samples in LDS (csrc/fpn_conv.hip); same contract as _DilatedConvs."""
+
+    @staticmethod
+    def _block(x, dils, ws):
+        B, C, H, W = x.shape
+        t = _lib.FpnConv()
+        t.B, t.C, t.O, t.H, t.W, t.n = B, C, ws[0].shape[0], H, W, len(dils)
+        t.x = x.data_ptr()
+        t.xs[0], t.xs[1], t.xs[2] = x.stride(0), x.stride(1), x.stride(2)
+        for i, d in enumerate(dils):
+            t.dil[i], t.w[i] = d, ws[i].data_ptr()
+        return t
+
+    @staticmethod
+    def forward(ctx, x, dils, *wb):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        ws = [w if w.is_contiguous() else _copy(w) for w in wb[0::2]]
+        t = _FpnConvs._block(x, dils, ws)
+        B, C, H, W = x.shape
+        ys = [torch.empty(B, w.shape[0], H, W, dtype=torch.float32, device=x.device) for w in ws]
+        for i in range(len(dils)):
+            t.bias[i], t.y[i] = wb[2 * i + 1].data_ptr(), ys[i].data_ptr()
+        _lib.call("cg_fpn_conv_fwd", ctypes.byref(t), _stream(x))
+        ctx.dils = dils
+        ctx.save_for_backward(x, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *ws = ctx.saved_tensors
+        n = len(ctx.dils)
+        if any(d is None for d in dys):
+            raise RuntimeError("dilated_convs: every output needs a gradient")
+        dys = [d if d.is_contiguous() else _copy(d) for d in dys]
+        t = _FpnConvs._block(x, ctx.dils, ws)
+        dev = x.device
+        dx = torch.empty(x.shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in ws]
+        zb, _ = _zeros(int(_lib.lib().cg_fpn_conv_ws_floats(x.shape[1], ws[0].shape[0], n)), dev)
+        for i in range(n):
+            t.dy[i], t.dw[i], t.db[i] = dys[i].data_ptr(), dws[i].data_ptr(), dbs[i].data_ptr()
+        t.dx, t.ws = _ptr(dx), zb.data_ptr()
+        _lib.call("cg_fpn_conv_bwd", ctypes.byref(t), _stream(x))
+        del dys
+        grads = []
+        for i in range(n):
+            grads += [dws[i] if ctx.needs_input_grad[2 + 2 * i] else None, dbs[i] if ctx.needs_input_grad[3 + 2 * i] else None]
+        return (dx, None) + tuple(grads)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -87,7 +87,7 @@ long long cg_contract_kred_ws_floats(int G, int M, int N);
 int cg_chan_stats(const float* x, const CgView4* xv, const float* pre, double* stats, void* stream);
 typedef struct CgStatsArgs { const float* x; CgView4 xv; const float* pre; double* stats; } CgStatsArgs;
 int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream);   /* up to 6 tensors per launch */
-/* out[c] = sum over batch and positions (bias gradients of the convolutions). */
+/* out[c] += sum over batch and positions (bias gradients of the convolutions); `out` (C floats) zero on entry. */
 int cg_chan_sum(const float* x, const CgView4* xv, float* out, void* stream);
 
 /* y = PReLU( Dropout( (x*pre)*scale + shift ) [+ add] ) [+ add if add_post]
@@ -229,6 +229,26 @@ typedef struct CgDstdTail {
 int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream);
 int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream);
 long long cg_dstd_tail_ws_floats(int C);
+
+/* ---- dilated 3x3 convolutions of the time extrapolator, FPN CISTGCN.py:54-79: n <= 3 convolutions with padding = dilation =
+ * dil[i] of ONE input (B,C,H,W) = (batch, frames, channels, joints).  A sample fits in LDS with its halo: forward, input gradient
+ * (summed over the convolutions) and weight / bias gradients each walk whole samples.  Shapes outside cg_fpn_conv_supported:
+ * CG_ESHAPE (the caller uses cg_contract_many). */
+typedef struct CgFpnConv {
+  int B, C, O, H, W, n;
+  int dil[3]; int pad;
+  const float* x; long long xs[3];     /* element strides of x: batch, channel, row; unit stride along W */
+  const float* w[3]; const float* bias[3];
+  float* y[3];
+  const float* dy[3];
+  float* dx;
+  float* dw[3]; float* db[3];
+  float* ws;                     /* cg_fpn_conv_ws_floats(C, O, n) zeroed floats */
+} CgFpnConv;
+int cg_fpn_conv_fwd(const CgFpnConv* t, void* stream);
+int cg_fpn_conv_bwd(const CgFpnConv* t, void* stream);
+int cg_fpn_conv_supported(int B, int C, int O, int H, int W);
+long long cg_fpn_conv_ws_floats(int C, int O, int n);
 
 /* ---- stacked pointwise maps of one input: the first convolutions of the Map2Adj towers of a block, CISTGCN.py:138-163 applied
  * to the normalised block input by :183-186 (up to four 1x1 convolutions of the same (B,C,T,V) tensor).  Forward: every y_i =

@@ -462,9 +462,18 @@ def check_copies(device):
     _run(lambda t: sum(ops.fanout(t, 2)), lambda t: 2.0 * t, [_rand(g, 3, 6)], device, what="fanout 2-D")
 
 
-def check_dilated_convs(device):
+def check_dilated_convs(device, shapes=((2, 5, 4, 10, 7), (3, 6, 5, 4, 6), (2, 25, 25, 10, 22), (2, 50, 25, 10, 22))):
+    """(B, Cin, Cout, H, W): H * W % 4 != 0 takes the generic contraction, the others the whole-sample kernels (csrc/fpn_conv.hip)"""
+    floor, ops._FPN_MIN_BATCH = ops._FPN_MIN_BATCH, 1          # the whole-sample kernels are switched on by batch size in production
+    try:
+        for shape in shapes:
+            _check_dilated_convs(device, *shape)
+    finally:
+        ops._FPN_MIN_BATCH = floor
+
+
+def _check_dilated_convs(device, B, Cin, Cout, H, W):
     g = _gen(5)
-    B, Cin, Cout, H, W = 2, 5, 4, 10, 7
     convs_ref = [nn.Conv2d(Cin, Cout, 3, padding=d, dilation=d) for d in (1, 2, 3)]
     convs_dev = [nn.Conv2d(Cin, Cout, 3, padding=d, dilation=d) for d in (1, 2, 3)]
     for r, d in zip(convs_ref, convs_dev):
@@ -472,7 +481,7 @@ def check_dilated_convs(device):
         d.to(device)
     base = _rand(g, B, H, Cin, W)          # consumed through a permuted (NTCV-style) view
     _run(lambda t: torch.cat(ops.dilated_convs(t.permute(0, 2, 1, 3), convs_dev), 1),
-         lambda t: torch.cat([c(t.permute(0, 2, 1, 3)) for c in convs_ref], 1), [base], device, what="dilated convs")
+         lambda t: torch.cat([c(t.permute(0, 2, 1, 3)) for c in convs_ref], 1), [base], device, what="dilated convs %s" % ((B, Cin, Cout, H, W),))
     for r, d in zip(convs_ref, convs_dev):
         assert_close(d.weight.grad, r.weight.grad, "dilated dW", rel=2e-5, floor=float(r.weight.grad.abs().max()))
         assert_close(d.bias.grad, r.bias.grad, "dilated db", rel=2e-5, floor=float(r.bias.grad.abs().max()))

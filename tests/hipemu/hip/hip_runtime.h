@@ -19,6 +19,7 @@ struct dim3 {
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 struct uint4 { unsigned x, y, z, w; } __attribute__((aligned(16)));
+struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 extern thread_local dim3 threadIdx;

@@ -21,6 +21,8 @@ def test_operator(check):
         check("cpu", quick=True)
     elif check is checks.check_dstd_tail:
         check("cpu", shapes=((3, 20, 7, 9),))
+    elif check is checks.check_dilated_convs:
+        check("cpu", shapes=((2, 5, 4, 10, 7), (3, 6, 5, 4, 6), (2, 20, 10, 6, 6)))
     elif check is checks.check_pointwise_maps:
         check("cpu", shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 33), 6, 6)))
     elif check is checks.check_map2adj_tail:
