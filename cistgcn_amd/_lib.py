@@ -160,7 +160,7 @@ _SIGNATURES = {
     "cg_fpn_conv_fwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_bwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_supported": [c_int, c_int, c_int, c_int, c_int],
-    "cg_fpn_conv_ws_floats": [c_int, c_int, c_int],
+    "cg_fpn_conv_ws_floats": [c_int, c_int, c_int, c_int],
     "cg_pointwise_maps_fwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_bwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_ws_floats": [c_int],

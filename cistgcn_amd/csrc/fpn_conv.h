@@ -14,5 +14,5 @@ struct CgFpnConv {
   const float* dy[3];
   float* dx;                                    // optional: sum over the convolutions
   float* dw[3]; float* db[3];                   // optional each
-  float* ws;                                    // cg_fpn_conv_ws_floats(C, O, n) zeroed floats
+  float* ws;                                    // cg_fpn_conv_ws_floats(B, C, O, n) floats of scratch
 };

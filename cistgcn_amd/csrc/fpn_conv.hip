@@ -14,7 +14,6 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
 #define CG_FPN_THREADS 256
 #define CG_FPN_PAD 3
-#define CG_FPN_REPLICAS 8
 
 struct CgFpnGeom {
   int HP, WP, IMG;              // halo image of one channel: (H + 6) x (W + 6), floats per channel
@@ -139,22 +138,30 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dx_kernel(CgFpnArgs a) 
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < CG_FPN_DXT; ++u) {
-      const int id = u * nw + wave;
-      if (id < PT * CT) {
-        const int pt = id / CT, ct = id - pt * CT;
-        const int pa = sPos[16 * pt + l15];
-        const float* wp = sW + (16 * ct + l15) * g.KS2 + 4 * slot;
-        cg_f32x4 c0 = acc[u];
+    for (int u = 0; u < CG_FPN_DXT; u += 2) {                      // two tiles at a time: independent MFMA chains
+      const int id0 = u * nw + wave, id1 = (u + 1) * nw + wave;
+      if (id0 < PT * CT) {
+        const bool two = id1 < PT * CT;
+        const int pt0 = id0 / CT, ct0 = id0 - pt0 * CT, pt1 = two ? id1 / CT : pt0, ct1 = two ? id1 - pt1 * CT : ct0;
+        const int pa = sPos[16 * pt0 + l15], pb = sPos[16 * pt1 + l15];
+        const float* wp0 = sW + (16 * ct0 + l15) * g.KS2 + 4 * slot;
+        const float* wp1 = sW + (16 * ct1 + l15) * g.KS2 + 4 * slot;
+        cg_f32x4 c0 = acc[u], c1 = acc[u + 1];
+#pragma unroll 3
         for (int k0 = 0; k0 < g.KP2; k0 += 16) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wp + k0);
+          const float4 w0 = *reinterpret_cast<const float4*>(wp0 + k0), w1 = *reinterpret_cast<const float4*>(wp1 + k0);
           const int4 t4 = *reinterpret_cast<const int4*>(sTap + k0 + 4 * slot);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[pa + t4.x], w4.x, c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[pa + t4.y], w4.y, c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[pa + t4.z], w4.z, c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sD[pa + t4.w], w4.w, c0, 0, 0, 0);
+          const float a0[4] = {sD[pa + t4.x], sD[pa + t4.y], sD[pa + t4.z], sD[pa + t4.w]};
+          const float a1[4] = {sD[pb + t4.x], sD[pb + t4.y], sD[pb + t4.z], sD[pb + t4.w]};
+          const float v0[4] = {w0.x, w0.y, w0.z, w0.w}, v1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], v0[s4], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], v1[s4], c1, 0, 0, 0);
+          }
         }
         acc[u] = c0;
+        if (two) acc[u + 1] = c1;
       }
     }
   }
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dw_kernel(CgFpnArgs a) 
   cg_f32x4 acc[CG_FPN_DWT];
 #pragma unroll
   for (int u = 0; u < CG_FPN_DWT; ++u) acc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  float bsum = 0.f, bsum1 = 0.f;                  // bias gradient shares of outputs l15 and 16 + l15 (O <= 32)
   for (int k = tid; k < g.KP; k += CG_FPN_THREADS) {
     const int c = k / 9, ij = k - 9 * c, i = ij / 3, j = ij - 3 * i;
     sTap[k] = k < g.K ? c * g.IMG + d * (i - 1) * g.WP + d * (j - 1) : 0;
@@ -207,34 +214,43 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dw_kernel(CgFpnArgs a) 
       *reinterpret_cast<float4*>(sD + o * DS + p) = *reinterpret_cast<const float4*>(dyb + (long long)o * g.P + p);
     }
     __syncthreads();
-    if (tid < t.O) {
-      float s = 0.f;
-      for (int p = 0; p < g.P; ++p) s += sD[tid * DS + p];
-      bsum += s;
-    }
 #pragma unroll
-    for (int u = 0; u < CG_FPN_DWT; ++u) {
-      const int id = u * nw + wave;
-      if (id < OT * KT) {
-        const int ot = id / KT, kt = id - ot * KT;
-        const int tap = sTap[16 * kt + l15];
-        const float* dp = sD + (16 * ot + l15) * DS + 4 * slot;
-        cg_f32x4 c0 = acc[u];
+    for (int u = 0; u < CG_FPN_DWT; u += 2) {                      // two tiles at a time: independent MFMA chains
+      const int id0 = u * nw + wave, id1 = (u + 1) * nw + wave;
+      if (id0 < OT * KT) {
+        const bool two = id1 < OT * KT;
+        const int ot0 = id0 / KT, kt0 = id0 - ot0 * KT, ot1 = two ? id1 / KT : ot0, kt1 = two ? id1 - ot1 * KT : kt0;
+        const int tap0 = sTap[16 * kt0 + l15], tap1 = sTap[16 * kt1 + l15];
+        const float* dp0 = sD + (16 * ot0 + l15) * DS + 4 * slot;
+        const float* dp1 = sD + (16 * ot1 + l15) * DS + 4 * slot;
+        cg_f32x4 c0 = acc[u], c1 = acc[u + 1];
+        float bs0 = 0.f, bs1 = 0.f;
+#pragma unroll 2
         for (int p0 = 0; p0 < g.PM; p0 += 16) {
-          const float4 d4 = *reinterpret_cast<const float4*>(dp + p0);
+          const float4 d0 = *reinterpret_cast<const float4*>(dp0 + p0), d1 = *reinterpret_cast<const float4*>(dp1 + p0);
           const int4 q4 = *reinterpret_cast<const int4*>(sPos + p0 + 4 * slot);
           // positions beyond P carry dy = 0 (their image offset is position 0's: any finite value)
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.x, sX[tap + q4.x], c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.y, sX[tap + q4.y], c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.z, sX[tap + q4.z], c0, 0, 0, 0);
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d4.w, sX[tap + q4.w], c0, 0, 0, 0);
+          const float x0[4] = {sX[tap0 + q4.x], sX[tap0 + q4.y], sX[tap0 + q4.z], sX[tap0 + q4.w]};
+          const float x1[4] = {sX[tap1 + q4.x], sX[tap1 + q4.y], sX[tap1 + q4.z], sX[tap1 + q4.w]};
+          const float e0[4] = {d0.x, d0.y, d0.z, d0.w}, e1[4] = {d1.x, d1.y, d1.z, d1.w};
+          bs0 += (d0.x + d0.y) + (d0.z + d0.w); bs1 += (d1.x + d1.y) + (d1.z + d1.w);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[s4], x0[s4], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[s4], x1[s4], c1, 0, 0, 0);
+          }
         }
         acc[u] = c0;
+        if (two) acc[u + 1] = c1;
+        // the owner of tile (ot, 0) also holds, per lane, a quarter of sum_p dy[o = 16 ot + l15][p]: the bias gradient
+        if (kt0 == 0) { if (ot0) bsum1 += bs0; else bsum += bs0; }
+        if (two && kt1 == 0) { if (ot1) bsum1 += bs1; else bsum += bs1; }
       }
     }
   }
-  // [replica][dilation][O * K + O] accumulators
-  float* ws = t.ws + ((long long)(blockIdx.x % CG_FPN_REPLICAS) * t.n + di) * (t.O * g.K + t.O);
+  // this workgroup's partial sums, plain stores: [workgroup][dilation][O * K + O]; cg_fpn_fold_kernel adds the workgroups up
+  // (float atomics into shared replicas cost ~60 us here: 510 workgroups x 5650 words)
+  float* ws = t.ws + ((long long)blockIdx.x * t.n + di) * (t.O * g.K + t.O);
 #pragma unroll
   for (int u = 0; u < CG_FPN_DWT; ++u) {
     const int id = u * nw + wave;
@@ -243,19 +259,36 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dw_kernel(CgFpnArgs a) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int o = 16 * ot + 4 * slot + q;
-        if (o < t.O && k < g.K) atomicAdd(&ws[o * g.K + k], acc[u][q]);
+        if (o < t.O && k < g.K) ws[o * g.K + k] = acc[u][q];
       }
     }
   }
-  if (tid < t.O) atomicAdd(&ws[t.O * g.K + tid], bsum);
+  // bias: four lanes (slots) of the owner wave hold quarters of an output's sum
+  bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+  bsum1 += __shfl_xor(bsum1, 16, 64); bsum1 += __shfl_xor(bsum1, 32, 64);
+  float* sB = reinterpret_cast<float*>(cg_dyn_lds);                // [2][nw][16] (the image is no longer needed)
+  __syncthreads();
+  if (slot == 0) { sB[wave * 16 + l15] = bsum; sB[(nw + wave) * 16 + l15] = bsum1; }
+  __syncthreads();
+  if (tid < 32 && tid < t.O) {
+    float s0 = 0.f;
+    for (int w = 0; w < nw; ++w) s0 += sB[((tid >> 4) * nw + w) * 16 + (tid & 15)];
+    ws[t.O * g.K + tid] = s0;
+  }
 }
 
-__global__ void cg_fpn_fold_kernel(CgFpnArgs a) {
+// dW / db of one dilation = sum of the workgroups' partials: 64 elements x 4 slices of the workgroup list per block
+__global__ void cg_fpn_fold_kernel(CgFpnArgs a, int nwg) {
+  __shared__ float red[4][64];
   const CgFpnConv& t = a.t; const CgFpnGeom& g = a.g;
-  const int di = blockIdx.y, n = t.O * g.K + t.O;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < CG_FPN_REPLICAS; ++r) s += t.ws[((long long)r * t.n + di) * n + e];
+  const int di = blockIdx.y, n = t.O * g.K + t.O, e = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float s = 0.f;
+  if (e < n)
+    for (int w = part; w < nwg; w += 4) s += t.ws[((long long)w * t.n + di) * n + e];
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && e < n) {
+    s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     if (e < t.O * g.K) { if (t.dw[di]) t.dw[di][e] = s; }
     else if (t.db[di]) t.db[di][e - t.O * g.K] = s;
   }
@@ -291,7 +324,8 @@ extern "C" int cg_fpn_conv_supported(int B, int C, int O, int H, int W) {
   const size_t cap = 160 * 1024;
   return cg_fpn_lds_fwd(&t, g) <= cap && cg_fpn_lds_dx(&t, g) <= cap && cg_fpn_lds_dw(&t, g) <= cap;
 }
-extern "C" long long cg_fpn_conv_ws_floats(int C, int O, int n) { return (long long)CG_FPN_REPLICAS * n * (O * C * 9 + O); }
+// scratch of the backward (per-workgroup partial weight / bias gradients; no zeroing needed)
+extern "C" long long cg_fpn_conv_ws_floats(int B, int C, int O, int n) { return (long long)(B < 170 ? B : 170) * n * (O * C * 9 + O); }
 
 // include/cistgcn_hip.h : cg_fpn_conv_fwd / cg_fpn_conv_bwd
 extern "C" int cg_fpn_conv_fwd(const CgFpnConv* t, void* stream_) {
@@ -334,6 +368,7 @@ extern "C" int cg_fpn_conv_bwd(const CgFpnConv* t, void* stream_) {
   hipLaunchKernelGGL(cg_fpn_dw_kernel, dim3((unsigned)nwg, (unsigned)t->n), dim3(CG_FPN_THREADS), lds, stream, a);
   st = cg_launch_status();
   if (st != CG_OK) return st;
-  hipLaunchKernelGGL(cg_fpn_fold_kernel, dim3(16, (unsigned)t->n), dim3(256), 0, stream, a);
+  const int nel = t->O * a.g.K + t->O;
+  hipLaunchKernelGGL(cg_fpn_fold_kernel, dim3((unsigned)((nel + 63) / 64), (unsigned)t->n), dim3(256), 0, stream, a, nwg);
   return cg_launch_status();
 }

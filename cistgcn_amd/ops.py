@@ -1147,7 +1147,7 @@ class _FpnConvs(torch.autograd.Function):
         dx = torch.empty(x.shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         dws = [torch.empty_like(w) for w in ws]
         dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in ws]
-        zb, _ = _zeros(int(_lib.lib().cg_fpn_conv_ws_floats(x.shape[1], ws[0].shape[0], n)), dev)
+        zb = torch.empty(int(_lib.lib().cg_fpn_conv_ws_floats(x.shape[0], x.shape[1], ws[0].shape[0], n)), dtype=torch.float32, device=dev)
         for i in range(n):
             t.dy[i], t.dw[i], t.db[i] = dys[i].data_ptr(), dws[i].data_ptr(), dbs[i].data_ptr()
         t.dx, t.ws = _ptr(dx), zb.data_ptr()

@@ -243,12 +243,12 @@ typedef struct CgFpnConv {
   const float* dy[3];
   float* dx;
   float* dw[3]; float* db[3];
-  float* ws;                     /* cg_fpn_conv_ws_floats(C, O, n) zeroed floats */
+  float* ws;                     /* cg_fpn_conv_ws_floats(B, C, O, n) floats of scratch */
 } CgFpnConv;
 int cg_fpn_conv_fwd(const CgFpnConv* t, void* stream);
 int cg_fpn_conv_bwd(const CgFpnConv* t, void* stream);
 int cg_fpn_conv_supported(int B, int C, int O, int H, int W);
-long long cg_fpn_conv_ws_floats(int C, int O, int n);
+long long cg_fpn_conv_ws_floats(int B, int C, int O, int n);
 
 /* ---- stacked pointwise maps of one input: the first convolutions of the Map2Adj towers of a block, CISTGCN.py:138-163 applied
  * to the normalised block input by :183-186 (up to four 1x1 convolutions of the same (B,C,T,V) tensor).  Forward: every y_i =
