@@ -116,6 +116,12 @@ class FpnConv(ctypes.Structure):
                 ("dy", c_void_p * 3), ("dx", c_void_p), ("dw", c_void_p * 3), ("db", c_void_p * 3), ("ws", c_void_p)]
 
 
+class RowsConv(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("T", c_int), ("V", c_int), ("O", c_int), ("pad", c_int),
+                ("x", c_void_p), ("W", c_void_p), ("y", c_void_p), ("stats", c_void_p),
+                ("dy", c_void_p), ("dx", c_void_p), ("dW", c_void_p), ("ws", c_void_p)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -157,6 +163,9 @@ _SIGNATURES = {
     "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_bwd": [POINTER(DstdTail), c_int, P],
     "cg_dstd_tail_ws_floats": [c_int],
+    "cg_collapse_rows_fwd": [POINTER(RowsConv), P],
+    "cg_collapse_rows_bwd": [POINTER(RowsConv), P],
+    "cg_collapse_rows_ws_floats": [c_int, c_int, c_int],
     "cg_fpn_conv_fwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_bwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_supported": [c_int, c_int, c_int, c_int, c_int],

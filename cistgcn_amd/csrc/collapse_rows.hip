@@ -1,0 +1,241 @@
+// Collapsing convolution over the frame axis (reference: nn.Conv2d(C, O, (T, 1)) of the gate paths, CISTGCN.py:331-336, and of
+// Map2Adj.time_compress, :138-150): y[b,o,v] = sum_{c,t} W[o,c,t] x[b,c,t,v].  Per sample this is Y_b (O x V) = W (O x K) X_b (K x V)
+// with K = C*T and X_b = x[b] as it lies in memory; the tensors are 36-72 MB, the outputs a few hundred KB.  The generic
+// contraction needed split-K with atomics and strided gathers for it (0.3 TB/s); here
+//   forward   one 512-thread workgroup per sample: eight waves split K, feed the matrix cores straight from global memory
+//             (W rows as float4 along k, x rows as 16-lane pieces along v), partial tiles are added in LDS
+//   backward  a workgroup owns 64 rows k of W for a slice of the samples: dx[b,k,v] = sum_o W[o,k] dy[b,o,v] is written as one
+//             contiguous 64 x V piece per sample, dW[o,k] += sum_v dy[b,o,v] x[b,k,v] stays in registers over the slice
+#include "cg_common.h"
+#include "cg_phase.h"
+#include "collapse_rows.h"
+
+HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
+
+#define CG_ROWS_FWD_THREADS 512
+#define CG_ROWS_BWD_THREADS 256
+#define CG_ROWS_KB 64            // rows of W per backward workgroup
+#define CG_ROWS_REPLICAS 8
+
+struct CgRowsGeom { int K, OT, slices, per, kranges; };
+struct CgRowsArgs { CgRowsConv t; CgRowsGeom g; };
+
+// ======================================================================================================================
+// forward
+// ======================================================================================================================
+__global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRowsArgs a) {
+  const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
+  const int b = blockIdx.x, K = g.K, V = t.V;
+  float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][33] partial sums of the eight waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ROWS_FWD_THREADS / 64;
+  for (int e = tid; e < 16 * g.OT * 33; e += CG_ROWS_FWD_THREADS) sY[e] = 0.f;
+  __syncthreads();
+  const float* xb = t.x + (long long)b * K * V;
+  cg_f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  // groups of 16 consecutive k: lane (l15, slot) takes k = k0 + 4 slot + s in MFMA step s (both operands agree, a sum does not
+  // care about the order)
+  const int ngroups = (K + 15) >> 4;
+  const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
+#pragma unroll 2
+  for (int gi = wave; gi < ngroups; gi += nw) {
+    const int k = 16 * gi + 4 * slot;
+    float4 wv[4];
+    float x0[4], x1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = 16 * i + l15;
+      wv[i] = (i < g.OT && o < t.O && k < K) ? *reinterpret_cast<const float4*>(t.W + (long long)o * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool kok = k + s < K;
+      x0[s] = (kok && v0ok) ? xb[(long long)(k + s) * V + l15] : 0.f;
+      x1[s] = (kok && v1ok) ? xb[(long long)(k + s) * V + 16 + l15] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < g.OT) {
+        const float w4[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], x0[s], acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], x1[s], acc[i][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < g.OT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = 16 * i + 4 * slot + q;
+        atomicAdd(&sY[o * 33 + l15], acc[i][0][q]);
+        atomicAdd(&sY[o * 33 + 16 + l15], acc[i][1][q]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < t.O * V; e += CG_ROWS_FWD_THREADS) {
+    const int o = e / V, v = e - o * V;
+    t.y[(long long)b * t.O * V + e] = sY[o * 33 + v];
+  }
+  if (t.stats) {                                       // f64 channel sums for the BatchNorm behind the convolution
+    for (int o = tid; o < t.O; o += CG_ROWS_FWD_THREADS) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int v = 0; v < V; ++v) { const double y = (double)sY[o * 33 + v]; s1 += y; s2 += y * y; }
+      double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * t.O + o) * 2;
+      atomicAdd(&rep[0], s1); atomicAdd(&rep[1], s2);
+    }
+  }
+}
+
+// ======================================================================================================================
+// backward: workgroup = (64 rows k of W, slice of the samples)
+// ======================================================================================================================
+__global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRowsArgs a) {
+  const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
+  const int K = g.K, V = t.V, O = t.O;
+  const int kr = blockIdx.x, sl = blockIdx.y, k0 = kr * CG_ROWS_KB;
+  const int b0 = sl * g.per, b1 = min(t.B, b0 + g.per);
+  if (b0 >= t.B) return;
+  float* sW = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][KB + 4]  W[o][k0 ..]
+  float* sDY = sW + 16 * g.OT * (CG_ROWS_KB + 4);                 // [2][16 * OT][36]   dy of the current / next sample, v padded with zeros
+  const int WS = CG_ROWS_KB + 4, DS = 36;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  for (int e = tid; e < 16 * g.OT * WS; e += CG_ROWS_BWD_THREADS) {
+    const int o = e / WS, kk = e - o * WS;
+    sW[e] = (o < O && kk < CG_ROWS_KB && k0 + kk < K) ? t.W[(long long)o * K + k0 + kk] : 0.f;
+  }
+  for (int e = tid; e < 2 * 16 * g.OT * DS; e += CG_ROWS_BWD_THREADS) sDY[e] = 0.f;
+  __syncthreads();
+  auto stage_dy = [&](int b, int buf) {
+    const float* src = t.dy + (long long)b * O * V;
+    float* dst = sDY + buf * 16 * g.OT * DS;
+    for (int e = tid; e < O * V; e += CG_ROWS_BWD_THREADS) { const int o = e / V, v = e - o * V; dst[o * DS + v] = src[e]; }
+  };
+  stage_dy(b0, 0);
+  // a wave owns the 16 rows k = k0 + 16 wave + .. of the range: dW tiles [o][k] in registers over the slice
+  cg_f32x4 wacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kw = k0 + 16 * wave;                                 // first row of this wave
+  const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
+    if (b + 1 < b1) stage_dy(b + 1, buf ^ 1);
+    const float* dyb = sDY + buf * 16 * g.OT * DS;
+    const float* xb = t.x + (long long)b * K * V;
+    float* dxb = t.dx + (long long)b * K * V;
+    // this lane's share of x[b][kw + l15][:]: four consecutive v per slot (v = 4 slot + s) and the second half (16 + ..)
+    const int krow = kw + l15;
+    float xa[4], xc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int v = 4 * slot + s;
+      xa[s] = (krow < K && v < V) ? xb[(long long)krow * V + v] : 0.f;
+      xc[s] = (krow < K && 16 + v < V) ? xb[(long long)krow * V + 16 + v] : 0.f;
+    }
+    // dx[k][v] = sum_o W[o][k] dy[o][v]: rows k of this wave, both halves of v
+    cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    for (int oc = 0; oc < 16 * g.OT; oc += 16) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int o = oc + 4 * slot + s;
+        const float w = sW[o * WS + 16 * wave + l15];              // A[i = k][kk = o]
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, dyb[o * DS + l15], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, dyb[o * DS + 16 + l15], c1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = kw + 4 * slot + q;
+      if (k < K) {
+        if (v0ok) dxb[(long long)k * V + l15] = c0[q];
+        if (v1ok) dxb[(long long)k * V + 16 + l15] = c1[q];
+      }
+    }
+    // dW[o][k] += sum_v dy[o][v] x[k][v]: A[i = o][kk = v] from LDS (float4 along v), B[kk = v][j = k] = this lane's x values
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < g.OT) {
+        const float4 d0 = *reinterpret_cast<const float4*>(dyb + (16 * i + l15) * DS + 4 * slot);
+        const float4 d1 = *reinterpret_cast<const float4*>(dyb + (16 * i + l15) * DS + 16 + 4 * slot);
+        const float e0[4] = {d0.x, d0.y, d0.z, d0.w}, e1[4] = {d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e0[s], xa[s], wacc[i], 0, 0, 0);
+          wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e1[s], xc[s], wacc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < g.OT) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int o = 16 * i + 4 * slot + q, k = kw + l15;
+        if (o < O && k < K) atomicAdd(&ws[(long long)o * K + k], wacc[i][q]);
+      }
+    }
+  }
+}
+
+__global__ void cg_rows_fold_kernel(CgRowsArgs a) {
+  const CgRowsConv& t = a.t;
+  const long long n = (long long)t.O * a.g.K;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < CG_ROWS_REPLICAS; ++r) s += t.ws[r * n + e];
+    t.dW[e] = s;
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static int cg_rows_geometry(const CgRowsConv* t, CgRowsGeom* g) {
+  if (!t || !t->x || !t->W) return CG_EARG;
+  if (t->B <= 0 || t->C <= 0 || t->T <= 0 || t->V <= 0 || t->V > 32 || t->O <= 0 || t->O > 64) return CG_ESHAPE;
+  const long long K = (long long)t->C * t->T;
+  if (K > (1 << 20) || (K & 3)) return CG_ESHAPE;
+  g->K = (int)K; g->OT = (t->O + 15) / 16;
+  g->kranges = (g->K + CG_ROWS_KB - 1) / CG_ROWS_KB;
+  int slices = 768 / g->kranges;                        // ~768 backward workgroups
+  slices = slices < 1 ? 1 : (slices > t->B ? t->B : slices);
+  g->per = (t->B + slices - 1) / slices;
+  g->slices = (t->B + g->per - 1) / g->per;
+  return CG_OK;
+}
+
+extern "C" long long cg_collapse_rows_ws_floats(int C, int T, int O) { return (long long)CG_ROWS_REPLICAS * O * C * T; }
+
+// include/cistgcn_hip.h : cg_collapse_rows_fwd / cg_collapse_rows_bwd
+extern "C" int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream_) {
+  CgRowsArgs a;
+  int st = cg_rows_geometry(t, &a.g);
+  if (st != CG_OK) return st;
+  if (!t->y) return CG_EARG;
+  a.t = *t;
+  const size_t lds = (size_t)16 * a.g.OT * 33 * sizeof(float);
+  hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3((unsigned)t->B), dim3(CG_ROWS_FWD_THREADS), lds, (hipStream_t)stream_, a);
+  return cg_launch_status();
+}
+
+extern "C" int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream_) {
+  CgRowsArgs a;
+  int st = cg_rows_geometry(t, &a.g);
+  if (st != CG_OK) return st;
+  if (!t->dy || !t->dx || !t->dW || !t->ws) return CG_EARG;
+  a.t = *t;
+  const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * 36) * sizeof(float);
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(cg_rows_bwd_kernel, dim3((unsigned)a.g.kranges, (unsigned)a.g.slices), dim3(CG_ROWS_BWD_THREADS), lds, stream, a);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  hipLaunchKernelGGL(cg_rows_fold_kernel, dim3(128), dim3(256), 0, stream, a);
+  return cg_launch_status();
+}

@@ -396,24 +396,32 @@ class CISTGCN(nn.Module):
         # between the B=16 / C=8 and the B=256 / C=64 workloads)
         big = xn0.numel() >= self.stack_min_elements
         stacked = big and self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(xn0, tower_w)
-        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (0 if has_res else 2) + (0 if has_bres else 1)))
+        cs, ct = m.conv_s[0], m.conv_t[0]
+        gates = big and self.fused_maps and cs.weight.shape == ct.weight.shape and cs.bias is None and ct.bias is None
+        rows_gate = gates and 2 * cs.out_channels <= 64 and ops.collapse_rows_ok(xn0, cs.weight.view(cs.out_channels, cs.in_channels, -1))
+        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (0 if has_res else 2) + (0 if has_bres else 1)))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
         k = 4
-        x_maps = None
+        x_maps = x_gates = None
         if stacked:
             x_maps, k = xa[4], 5
+        if rows_gate:
+            x_gates, k = xa[k], k + 1
         x_res = xa[k:k + 2] if not has_res else None
         x_bres = xa[-1] if not has_bres else None
         stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
         # 1. every first-level map of xn
-        cs, ct = m.conv_s[0], m.conv_t[0]
-        # the two gate paths start with the same (T,1) convolution shape on the same input: one contraction of the stacked weights
+        # the two gate paths start with the same (T,1) convolution shape on the same input: one convolution of the stacked weights
         # (the block input travels once instead of twice, forward and in both gradients)
-        gates = big and self.fused_maps and cs.weight.shape == ct.weight.shape and cs.bias is None and ct.bias is None
+        gate_rows = None
         if gates:
             O = cs.out_channels
             w2 = ops.cat_channels([cs.weight.view(1, O, -1), ct.weight.view(1, O, -1)]).view(2 * O, cs.in_channels, xn.shape[2])
-            items = [(("och,bchw->bow", w2, xn, None, None, None), None)]
+            if x_gates is not None:
+                gate_rows = ops.collapse_rows(x_gates, w2)[0]            # whole-sample kernel (csrc/collapse_rows.hip)
+                items = []
+            else:
+                items = [(("och,bchw->bow", w2, xn, None, None, None), None)]
         else:
             items = [_rows_item(xn, cs, tr), _rows_item(xn, ct, tr)]
         if not stacked:
@@ -423,9 +431,10 @@ class CISTGCN(nn.Module):
             items += [_pw_item(xn, d.residual[0], tr) for d in doms]
         if has_bres:
             items.append(_pw_item(xn, m.residual[0], tr))
-        o = _run_items(items)
+        o = _run_items(items) if items else []
         if gates:
-            o = [(g.unsqueeze(2), None) for g in ops.split_channels(o[0][0], (O, O))] + o[1:]
+            yg = gate_rows if gate_rows is not None else o.pop(0)[0]
+            o = [(g.unsqueeze(2), None) for g in ops.split_channels(yg, (O, O))] + o
         if stacked:
             o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
         gs, gt, tc = o[0], o[1], o[2:6]
@@ -446,9 +455,23 @@ class CISTGCN(nn.Module):
         bres = r[-1] if has_bres else x_bres
         # 3. collapsing convolutions
         items = [_cols_item(gs, m.conv_s[4], tr), _cols_item(gt, m.conv_t[4], tr)]
+        rows3 = {}
         for i, a in enumerate(maps):
-            items += [_rows_item(t1[2 * i], a.time_compress[3], tr), _cols_item(t1[2 * i + 1], a.joint_compress[3], tr)]
+            c3 = a.time_compress[3]
+            x3 = t1[2 * i][0] if isinstance(t1[2 * i], tuple) else t1[2 * i]
+            w3 = c3.weight.view(c3.out_channels, c3.in_channels, -1)
+            if big and c3.bias is None and ops.collapse_rows_ok(x3, w3):
+                y3, st3 = ops.collapse_rows(x3, w3, tr)                  # whole-sample kernel (csrc/collapse_rows.hip)
+                rows3[i] = (y3.unsqueeze(2), st3)
+            else:
+                items.append(_rows_item(t1[2 * i], c3, tr))
+            items.append(_cols_item(t1[2 * i + 1], a.joint_compress[3], tr))
         o = _run_items(items)
+        if rows3:                                                        # back into the order gates | (time, joint) per tower
+            rest, o = o[2:], o[:2]
+            for i in range(len(maps)):
+                o.append(rows3[i] if i in rows3 else rest.pop(0))
+                o.append(rest.pop(0))
         # 4. BatchNorm tails
         calls = [dict(x=o[0], bn=m.conv_s[5], drop=True, prelu=m.conv_s[7]), dict(x=o[1], bn=m.conv_t[5], drop=True, prelu=m.conv_t[7])]
         for i, a in enumerate(maps):

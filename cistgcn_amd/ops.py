@@ -1773,3 +1773,63 @@ class _SplitChannels(torch.autograd.Function):
 def split_channels(y, sizes):
     """Views of consecutive channel ranges of y (B,C,...), differentiable (the gradients are gathered by one copy launch)."""
     return _SplitChannels.apply(tuple(int(s) for s in sizes), y)
+
+
+_ROWS_KERNELS = __import__("os").environ.get("CISTGCN_ROWS_KERNELS", "1") != "0"     # 0: the generic contraction (tuning aid)
+
+
+def collapse_rows_ok(x, w):
+    """True when `collapse_rows` takes the (T,1) convolution `w` (O,C,T) of x (B,C,T,V)."""
+    if not _ROWS_KERNELS or x.dim() != 4 or not x.is_contiguous() or w.dim() != 3:
+        return False
+    B, C, T, V = x.shape
+    return w.shape[1] == C and w.shape[2] == T and V <= 32 and w.shape[0] <= 64 and (C * T) % 4 == 0
+
+
+class _CollapseRows(torch.autograd.Function):
+    """y[b,o,v] = sum_{c,t} w[o,c,t] x[b,c,t,v] (nn.Conv2d(C, O, (T,1)), CISTGCN.py:138-150 / :331-336), see csrc/collapse_rows.hip"""
+
+    @staticmethod
+    def _block(x, w):
+        B, C, T, V = x.shape
+        t = _lib.RowsConv()
+        t.B, t.C, t.T, t.V, t.O = B, C, T, V, w.shape[0]
+        t.x, t.W = x.data_ptr(), w.data_ptr()
+        return t
+
+    @staticmethod
+    def forward(ctx, want_stats, x, w):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        w = w if w.is_contiguous() else _copy(w)
+        B, C, T, V = x.shape
+        O = w.shape[0]
+        t = _CollapseRows._block(x, w)
+        y = torch.empty(B, O, V, dtype=torch.float32, device=x.device)
+        stats = _arena(x.device).take(2 * O * _lib.STAT_REPLICAS) if want_stats else None
+        t.y, t.stats = y.data_ptr(), _ptr(stats)
+        _lib.call("cg_collapse_rows_fwd", ctypes.byref(t), _stream(x))
+        ctx.save_for_backward(x, w)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _=None):
+        x, w = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
+        dy = dy if dy.is_contiguous() else _copy(dy)
+        B, C, T, V = x.shape
+        t = _CollapseRows._block(x, w)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        zb, _z = _zeros(int(_lib.lib().cg_collapse_rows_ws_floats(C, T, w.shape[0])), x.device)
+        t.dy, t.dx, t.dW, t.ws = dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), zb.data_ptr()
+        _lib.call("cg_collapse_rows_bwd", ctypes.byref(t), _stream(x))
+        return None, dx if ctx.needs_input_grad[1] else None, dw if ctx.needs_input_grad[2] else None
+
+
+def collapse_rows(x, w, want_stats=False):
+    """(y (B,O,V), f64 channel sums or None) of the frame-collapsing convolution w (O,C,T) of x (B,C,T,V)."""
+    return _CollapseRows.apply(bool(want_stats), x, w)

@@ -230,6 +230,21 @@ int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream);
 int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream);
 long long cg_dstd_tail_ws_floats(int C);
 
+/* ---- frame-collapsing convolution nn.Conv2d(C, O, (T, 1)) (no bias): first convolution of the gate paths CISTGCN.py:331-336 and
+ * second convolution of Map2Adj.time_compress :138-150.  y[b,o,v] = sum_{c,t} W[o,c,t] x[b,c,t,v]; x (B,C,T,V) contiguous, W (O, C*T),
+ * y (B,O,V); V <= 32, O <= 64, C*T % 4 == 0 (else CG_ESHAPE: cg_contract_many).  Forward: one workgroup per sample; backward:
+ * dx and dW from one pass (workgroup = 64 rows of W x a slice of the samples). */
+typedef struct CgRowsConv {
+  int B, C, T, V, O, pad;
+  const float* x; const float* W;
+  float* y; double* stats;          /* stats: optional [CG_STAT_REPLICAS][O][2] f64 sums of y, zero on entry */
+  const float* dy; float* dx; float* dW;
+  float* ws;                        /* cg_collapse_rows_ws_floats(C, T, O) zeroed floats */
+} CgRowsConv;
+int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream);
+int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream);
+long long cg_collapse_rows_ws_floats(int C, int T, int O);
+
 /* ---- dilated 3x3 convolutions of the time extrapolator, FPN CISTGCN.py:54-79: n <= 3 convolutions with padding = dilation =
  * dil[i] of ONE input (B,C,H,W) = (batch, frames, channels, joints).  A sample fits in LDS with its halo: forward, input gradient
  * (summed over the convolutions) and weight / bias gradients each walk whole samples.  Shapes outside cg_fpn_conv_supported:
