@@ -117,6 +117,37 @@ def _call_bytes(name, args):
         if name.endswith("fwd"):
             return "fused ST-GCN stage fwd (cg_stgcn_domain_fwd)", 4 * (x + adj + y + co * ci + co)
         return "fused ST-GCN stage bwd (cg_stgcn_domain_bwd)", 4 * (2 * x + 2 * adj + y + 2 * co * ci)
+    if name in ("cg_dstd_tail_fwd", "cg_dstd_tail_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.DstdTail)).contents
+        n = 4 * t.B * t.C * t.T * t.V                    # one (B,C,T,V) tensor
+        # tensor passes of each phase (section 4 of DESIGN.md): F1 y,r x2 | F2 y,r x2 -> h0 | F3 h0 | F4 h0,bres -> out;
+        # K1 dout,h0 | K2 dout,h0 | K3 dout,h0,y,r x2 -> gp x2 | K4 y,r,gp x2 -> dr x2 | K5 y,dr x2 -> dy x2
+        passes = {1: 4, 2: 5, 3: 1, 4: 3} if name.endswith("fwd") else {1: 2, 2: 2, 3: 8, 4: 8, 5: 6}
+        return "DSTD_GC tail phases (cg_dstd_tail_fwd/bwd)", n * passes.get(args[1], 0)
+    if name in ("cg_map2adj_tail_fwd", "cg_map2adj_tail_bwd"):
+        items, n, phase = args[0], args[1], args[2]
+        e = sum(4 * items[i].B * items[i].Kc * items[i].J * items[i].J for i in range(n))      # one (B,Kc,J,J) tensor per tower
+        passes = {1: 1, 2: 2} if name.endswith("fwd") else {1: 3, 2: 2}
+        return "Map2Adj tail phases (cg_map2adj_tail_fwd/bwd)", e * passes.get(phase, 0)
+    if name in ("cg_pointwise_maps_fwd", "cg_pointwise_maps_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.PwMaps)).contents
+        x, ys = 4 * t.B * t.Cin * t.P, sum(4 * t.B * t.M[i] * t.P for i in range(t.n))
+        return "stacked tower maps (cg_pointwise_maps_fwd/bwd)", (x + ys) if name.endswith("fwd") else (2 * x + ys)
+    if name in ("cg_collapse_rows_fwd", "cg_collapse_rows_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.RowsConv)).contents
+        x = 4 * t.B * t.C * t.T * t.V
+        return "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)", x if name.endswith("fwd") else 2 * x
+    if name in ("cg_fpn_conv_fwd", "cg_fpn_conv_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.FpnConv)).contents
+        x, y = 4 * t.B * t.C * t.H * t.W, 4 * t.B * t.O * t.H * t.W
+        return "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)", (x + t.n * y) if name.endswith("fwd") else (3 * x + 2 * t.n * y)
+    if name in ("cg_dstd_stats_fwd", "cg_dstd_stats_bwd"):
+        B, C, T, V = args[-5:-1]
+        return "block statistics (cg_dstd_stats_fwd/bwd)", 4 * B * C * T * V * (1 if name.endswith("fwd") else 3)
     return "other (%s)" % name, 0
 
 
@@ -190,7 +221,7 @@ def family_rooflines(net, x, tgt, reps=3):
         f["GBps"] = f["algorithmic_bytes"] / max(f["us"], 1e-9) / 1e3
         f["frac"] = f["GBps"] / HBM_PEAK_GBS
         out[k] = f
-    out["other entry points (statistics, cat / sum copies, SE, FPN pooling, tail)"] = other
+    out["other entry points (cat / sum / zero copies, SE gates, pooling, MPJPE, feature lift)"] = other
     return out
 
 

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
   // care about the order)
   const int ngroups = (K + 15) >> 4;
   const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
-#pragma unroll 2
+#pragma unroll 4
   for (int gi = wave; gi < ngroups; gi += nw) {
     const int k = 16 * gi + 4 * slot;
     float4 wv[4];
@@ -123,22 +123,26 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
   for (int i = 0; i < 4; ++i) wacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   const int kw = k0 + 16 * wave;                                 // first row of this wave
   const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
-  for (int b = b0; b < b1; ++b) {
-    const int buf = (b - b0) & 1;
-    __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
-    if (b + 1 < b1) stage_dy(b + 1, buf ^ 1);
-    const float* dyb = sDY + buf * 16 * g.OT * DS;
+  // this lane's share of x[b][kw + l15][:]: four consecutive v per slot (v = 4 slot + s) and the second half (16 + ..);
+  // the next sample's values are requested before the current sample's matrix work
+  const int krow = kw + l15;
+  auto load_x = [&](int b, float xa_[4], float xc_[4]) {
     const float* xb = t.x + (long long)b * K * V;
-    float* dxb = t.dx + (long long)b * K * V;
-    // this lane's share of x[b][kw + l15][:]: four consecutive v per slot (v = 4 slot + s) and the second half (16 + ..)
-    const int krow = kw + l15;
-    float xa[4], xc[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int v = 4 * slot + s;
-      xa[s] = (krow < K && v < V) ? xb[(long long)krow * V + v] : 0.f;
-      xc[s] = (krow < K && 16 + v < V) ? xb[(long long)krow * V + 16 + v] : 0.f;
+      xa_[s] = (krow < K && v < V) ? xb[(long long)krow * V + v] : 0.f;
+      xc_[s] = (krow < K && 16 + v < V) ? xb[(long long)krow * V + 16 + v] : 0.f;
     }
+  };
+  float xa[4], xc[4], xna[4], xnc[4];
+  load_x(b0, xa, xc);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
+    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xna, xnc); }
+    const float* dyb = sDY + buf * 16 * g.OT * DS;
+    float* dxb = t.dx + (long long)b * K * V;
     // dx[k][v] = sum_o W[o][k] dy[o][v]: rows k of this wave, both halves of v
     cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
     for (int oc = 0; oc < 16 * g.OT; oc += 16) {
@@ -172,6 +176,8 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
         }
       }
     }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { xa[s] = xna[s]; xc[s] = xnc[s]; }
   }
   float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
 #pragma unroll
