@@ -311,6 +311,11 @@ class CISTGCN(nn.Module):
         h = self._na(self._lin(_pointwise, o, e[0]), bn=e[1], drop=True, prelu=e[3])
         return _pointwise(h, e[4])[0]
 
+    def _fused_stage_ok(self, conv):
+        """The fused graph-product + channel-mix kernel takes layers up to 128 channels (its LDS image); wider layers (any
+        `model_complexity` is legal in the reference) go through the two generic contractions."""
+        return self.fused_domain and conv.in_channels <= 128 and conv.out_channels <= 128
+
     # ---- Domain_GCNN_layer.forward, CISTGCN.py:259-269 -------------------------------------------
     def _domain(self, layer, xn):
         res = xn if isinstance(layer.residual, nn.Identity) else self._na(self._lin(_pointwise, xn, layer.residual[0]), bn=layer.residual[1])
@@ -318,7 +323,7 @@ class CISTGCN(nn.Module):
         if layer.interpretable:
             adj = self._adjacency(layer, xn)
             layer.Adj = adj
-            if self.fused_domain:
+            if self._fused_stage_ok(conv):
                 w = conv.weight.view(conv.out_channels, conv.in_channels)
                 y = ops.stgcn_domain(xn, adj, w, conv.bias, 0 if layer.domain == "space" else 1, self.training)
             else:
@@ -519,7 +524,7 @@ class CISTGCN(nn.Module):
         for i, d in enumerate(doms):
             d.Adj = adj[i][0]
             conv = d.tcn[0]
-            if self.fused_domain:
+            if self._fused_stage_ok(conv):
                 wmat = conv.weight.view(conv.out_channels, conv.in_channels)
                 ys.append(ops.stgcn_domain(x_dom[i], d.Adj, wmat, conv.bias, 0 if d.domain == "space" else 1, tr))
             else:

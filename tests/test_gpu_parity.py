@@ -48,9 +48,10 @@ def test_model_stacked_first_level_maps(name, mode):
     checks.check_model_golden("cuda", name, modes=(mode,), stack_all=True)
 
 
-@pytest.mark.parametrize("cfg", [(64, 10, 22, 8), (32, 50, 25, 4), (16, 10, 18, 6), (64, 50, 22, 4)], ids=str)
+@pytest.mark.parametrize("cfg", [(64, 10, 22, 8), (32, 50, 25, 4), (16, 10, 18, 6), (64, 50, 22, 4), (144, 10, 22, 4)], ids=str)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_model_matches_oracle_wide(cfg, mode):
+    # (144, ...): wider than the fused stage / tail / stacked-map kernels take: every layer falls back to the generic contractions
     C, T, V, B = cfg
     checks.check_model_vs_oracle("cuda", C, T, V, B, mode)
 

@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of prebuilt library variants (variants/*.so) on one box, two rounds to see the noise.
 set -u
+cp cistgcn_amd/libcistgcn_hip.so /tmp/libcistgcn_hip.so.built
+trap 'cp /tmp/libcistgcn_hip.so.built cistgcn_amd/libcistgcn_hip.so' EXIT      # leave the library that was built from the tree
 for round in 1 2; do
 for v in variants/*.so; do
   cp "$v" cistgcn_amd/libcistgcn_hip.so
