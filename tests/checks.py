@@ -667,6 +667,8 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
     assert_close(pd, po, "pred")
     assert_close(ld, lo, "loss")
 
+    worst = [0.0, ""]
+
     def as_accurate_as_cpu(got, cpu32, ref64, what):
         """The HIP result must be as close to the fp64 truth as the reference's own fp32 CPU path is (x8 slack),
         or within 2e-4 relative (floor 1e-2) of it."""
@@ -675,12 +677,15 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
         e_cpu = float((cpu32.detach().double() - ref64).abs().max())
         bound = max(8.0 * e_cpu, 2e-4 * max(1e-2, float(ref64.abs().max())))
         assert e_hip <= bound, "%s: HIP err vs fp64 %.3e > bound %.3e (CPU fp32 err vs fp64 %.3e)" % (what, e_hip, bound, e_cpu)
+        if e_hip / max(bound, 1e-30) > worst[0]:
+            worst[0], worst[1] = e_hip / max(bound, 1e-30), what
 
     gd, g64 = dict(net.named_parameters()), dict(ora64.named_parameters())
     if smooth:
         as_accurate_as_cpu(xd.grad, xo.grad, x64.grad, "dL/dx")
         for k, p in ora.named_parameters():
             as_accurate_as_cpu(gd[k].grad, p.grad, g64[k].grad, "grad " + k)
+        print("accuracy vs fp64, worst error / bound: %.3f (%s)" % (worst[0], worst[1]))
     else:
         assert_close(xd.grad, xo.grad, "dL/dx", floor=1e-1)
         assert_grads_close({k: p.grad for k, p in gd.items()}, {k: p.grad for k, p in ora.named_parameters()}, "vs oracle")
