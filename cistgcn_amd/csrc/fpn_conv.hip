@@ -12,7 +12,7 @@
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
-#define CG_FPN_THREADS 256
+#define CG_FPN_THREADS 512
 #define CG_FPN_PAD 3
 
 struct CgFpnGeom {
