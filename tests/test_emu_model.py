@@ -31,6 +31,7 @@ def test_tiny_model_every_gradient_strict():
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.skipif(os.environ.get("CISTGCN_EMU_FULL", "0") != "1", reason="a minute of emulation; the same test runs on the MI355X (test_gpu_parity.py::test_model_survives_jit_trace); CISTGCN_EMU_FULL=1 enables it here")
 def test_model_survives_jit_trace():
     """`writer.add_graph(model, batch)` (train.py:137) = `torch.jit.trace` with its default self-check, model in train mode
     with dropout on: the hot path appears as one opaque node, the seed is not advanced while tracing (the tracer's check run

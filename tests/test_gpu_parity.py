@@ -48,7 +48,7 @@ def test_model_stacked_first_level_maps(name, mode):
     checks.check_model_golden("cuda", name, modes=(mode,), stack_all=True)
 
 
-@pytest.mark.parametrize("cfg", [(64, 10, 22, 8), (32, 50, 25, 6), (16, 10, 18, 6), (64, 50, 22, 4), (144, 10, 22, 4)], ids=str)
+@pytest.mark.parametrize("cfg", [(64, 50, 22, 4), (144, 10, 22, 4)], ids=str)      # the other shapes: strict tests below
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_model_matches_oracle_wide(cfg, mode):
     # (144, ...): wider than the fused stage / tail / stacked-map kernels take: every layer falls back to the generic contractions
@@ -412,3 +412,14 @@ def test_device_input_pipeline_matches_reference():
     for raw, out in zip(batches, got):                       # same draws, no overlap: must be identical
         ref = aug(torch.from_numpy(raw).cuda(), 10)
         assert all(torch.equal(out[k], ref[k]) for k in ref)
+
+
+def test_model_survives_jit_trace():
+    """`writer.add_graph(model, batch)` (train.py:137) = `torch.jit.trace` with its default self-check, model in train mode
+    with dropout on: the hot path appears as one opaque node, the seed is not advanced while tracing (the tracer's check run
+    draws the same masks) and the traced module replays to the same prediction."""
+    net, _ = checks.build_pair(8, 10, 22, "cuda", dropout=0.1)
+    net.train()
+    x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=torch.Generator().manual_seed(3))).cuda()
+    traced = torch.jit.trace(net, x)
+    assert any(n.kind() == "prim::PythonOp" for n in traced.graph.nodes())
