@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for M in ${MASKS:-0 1 2 3 8 11 16 27}; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/adj_abl_$M
   rm -rf $OUT; mkdir -p $OUT
-  CG_ADJ_DBG=$M timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/prof_adj.py > $OUT/log.txt 2>&1
+  CISTGCN_ABLATION=1 CG_ADJ_DBG=$M timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/prof_adj.py > $OUT/log.txt 2>&1
   python3 - $OUT $M <<'PY'
 import csv, glob, sys
 out, m = sys.argv[1], sys.argv[2]
