@@ -22,3 +22,17 @@ int cg_domm_bwd_launch(const float* x, const float* adj, const float* W, const f
                        int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);
 int cg_domm_fwd_launch(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                        int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);
+
+// geometry of the plane kernels (stgcn_domain_planes.hip)
+struct CgDomP {
+  int B, Cin, Cout, T, V, TV;
+  int NG, J;                 // groups per sample (joints | frames), contraction length (frames | joints)
+  int JS, GSTR;              // LDS image sZ[group][16][JS]: row stride (== 2 mod 4), group stride
+  int NOC, KS, WS;           // chunks of 16 output channels, MFMA steps over the input channels, row stride of the weight image
+  int JSTEPS, zfloats;       // MFMA steps over the contraction axis, floats of sZ
+  int VW, VWB, NL;           // floats per lane of a plane access | of an adjacency row access, adjacency accesses per step
+  unsigned magicV, magicNQ;  // ceil(2^32 / d) for the divisions by V and by T*V / VW
+};
+int cg_domp_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V, int domain);
+int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
+                       int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);

@@ -22,6 +22,14 @@
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
+// Kernel-generation switches for A/B runs (tools/bench_domain*.py).  They are honoured only in a process started with
+// CISTGCN_ABLATION=1 (read once); a production process never calls getenv() per launch and a stray variable cannot change
+// which kernel runs.  INTEGRATION.md lists them.
+static const char* cg_dom_env(const char* name) {
+  static const bool ablation = getenv("CISTGCN_ABLATION") != nullptr;
+  return ablation ? getenv(name) : nullptr;
+}
+
 struct CgDomainGeom {
   int B, Cin, Cout, T, V;
   int GT, ntiles;      // groups per tile, tiles per sample
@@ -551,7 +559,7 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   // (fewer than 1024 single-group tiles) instead aim at one wave of ~256 workgroups: one round on the 256 CUs.
   const long long tiles1 = (long long)B * g.NG;
   const int want_wgs = tiles1 < 1024 ? 256 : 1024;
-  const char* env_gt = getenv("CG_DOM_GT");          // tuning aid (tools/bench_domain.py); unset in production
+  const char* env_gt = cg_dom_env("CG_DOM_GT");          // tuning aid (tools/bench_domain.py); unset in production
   int best = 0;
   for (int gt = 1; gt <= g.NG; ++gt) {
     g.GT = gt; g.PP = gt * g.Jp;
@@ -579,7 +587,7 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   // space-domain forward: more tiles in flight per XCD than its 4 MiB L2 can hold let partially written y lines
   // escape to HBM (PMC: 91 MB written per launch instead of 53 MB) -> one tile per workgroup there
   if (domain == 0 && !bwd) per = 1;
-  const char* env_per = getenv("CG_DOM_PER");        // tuning aid
+  const char* env_per = cg_dom_env("CG_DOM_PER");        // tuning aid
   if (env_per) per = atoi(env_per) > 0 ? atoi(env_per) : per;
   g.per = (int)per;
   return CG_OK;
@@ -591,24 +599,29 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   CgDomainGeom g;
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
+  // wide layers, third generation: plane kernels (stgcn_domain_planes.hip) - whole plane rows in HBM, LDS as the transposer
+  if ((Cin >= 16 || Cout >= 16) && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+    st = cg_domp_fwd_launch(x, adj, W, bias, y, ystats, B, Cin, Cout, T, V, domain, (hipStream_t)stream_);
+    if (st != CG_ESHAPE) return st;
+  }
   // wide layers: both products on the matrix cores with the shared staging of stgcn_domain_mfma.hip (CG_DOM_FWD_OLD=1: the
   // first-generation kernels below, kept for A/B runs)
   // (measured at 64->64, B=256, T=50, V=22: time domain 146 vs 173 us; in the space domain both generations sit at ~280 us,
   // bound by the 4-byte-column accesses of x and y - DESIGN.md section 4 - so the first-generation kernel stays there)
-  if ((Cin >= 16 || Cout >= 16) && domain == 1 && V <= 64 && getenv("CG_DOM_FWD_OLD") == nullptr) {
+  if ((Cin >= 16 || Cout >= 16) && domain == 1 && V <= 64 && cg_dom_env("CG_DOM_FWD_OLD") == nullptr) {
     st = cg_domm_fwd_launch(x, adj, W, bias, y, ystats, B, Cin, Cout, T, V, domain, (hipStream_t)stream_);
     if (st != CG_ESHAPE) return st;
   }
   // matrix cores pay off in the time domain (164 vs 243 us at C=64, B=256); in the space domain the kernel is bound by
   // its 4-byte-column accesses, the MFMA variant is no faster there and measured 1.7x the HBM write traffic (PMC)
-  const bool mfma = Cin >= 16 && Cout >= 16 && domain == 1 && getenv("CG_DOM_NO_MFMA") == nullptr;
+  const bool mfma = Cin >= 16 && Cout >= 16 && domain == 1 && cg_dom_env("CG_DOM_NO_MFMA") == nullptr;
   if (mfma) {
     // matrix-core path: its own LDS images; fit the tile to 64 KiB where possible
     while (g.GT > 1 && cg_dom_mfma_lds_bytes(g) > 64 * 1024) { --g.GT; g.PP = g.GT * g.Jp; }
     g.ntiles = (g.NG + g.GT - 1) / g.GT;
     if (cg_dom_mfma_lds_bytes(g) > 160 * 1024 - 256) return CG_ESHAPE;
     const long long total = (long long)B * g.ntiles;
-    if (getenv("CG_DOM_PER") == nullptr) { long long per = total / 2048; g.per = (int)(per < 1 ? 1 : (per > 16 ? 16 : per)); }
+    if (cg_dom_env("CG_DOM_PER") == nullptr) { long long per = total / 2048; g.per = (int)(per < 1 ? 1 : (per > 16 ? 16 : per)); }
     const size_t lds = cg_dom_mfma_lds_bytes(g);
     const long long nwg = (total + g.per - 1) / g.per;
     dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
@@ -654,7 +667,7 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   }
   // wide layers: every product on the matrix cores (stgcn_domain_mfma.hip); narrow ones (C <= 10 on both sides: CISTGCN-8,
   // the output block) stay on the VALU kernel below, where a 16-wide MFMA tile would be mostly padding
-  if ((Cin >= 16 || Cout >= 16) && (domain == 1 ? V : T) <= 64 && getenv("CG_DOM_BWD_VALU") == nullptr) {
+  if ((Cin >= 16 || Cout >= 16) && (domain == 1 ? V : T) <= 64 && cg_dom_env("CG_DOM_BWD_VALU") == nullptr) {
     st = cg_domm_bwd_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, domain, stream);
     if (st != CG_ESHAPE) {
       if (st != CG_OK) return st;
