@@ -6,6 +6,13 @@
 
 #define CG_WAVE 64
 
+// Makes a per-lane value opaque to the optimiser (no instruction is emitted).  Used at the top of long loop bodies so that the
+// address arithmetic derived from it is recomputed per iteration instead of being hoisted into dozens of live registers.
+// The CPU test shim (tests/hipemu) defines it as a no-op before this header is read.
+#ifndef CG_OPAQUE_V
+#define CG_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
 // ---- status codes returned through the C ABI (0 = ok, >0 = hipError_t, <0 = argument check) ----
 #define CG_OK 0
 #define CG_EARG (-1)

@@ -32,7 +32,15 @@ struct CgDomP {
   int JSTEPS, zfloats;       // MFMA steps over the contraction axis, floats of sZ
   int VW, VWB, NL;           // floats per lane of a plane access | of an adjacency row access, adjacency accesses per step
   unsigned magicV, magicNQ;  // ceil(2^32 / d) for the divisions by V and by T*V / VW
+  // backward of the space domain
+  int NTC, TC;               // chunks of frames per sample, frames per chunk (<= 16)
+  int CinR, XS;              // rows / row stride of the x piece sX[CinR][XS] (and of sdZ[16][XS])
+  int GZ, GY, YS;            // sZ[V][16][16] group stride; sY[V][16][YS] group / row stride
+  int zfl, yfl, bwd_floats;  // floats of sZ, sY, the whole LDS image
+  int VWP, VWY, VWA;         // floats per lane: x piece / dx rows, dY pieces, slab rows
 };
 int cg_domp_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V, int domain);
+int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
+                       int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);
 int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                        int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);

@@ -665,6 +665,16 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
     const int zs = cg_zero_fill(ws, (long long)CG_DOM_REPLICAS * (n_w + n_b) * (long long)sizeof(float), stream);
     if (zs != CG_OK) return zs;
   }
+  // wide layers, space domain: plane backward (stgcn_domain_planes.hip)
+  if ((Cin >= 16 || Cout >= 16) && domain == 0 && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+    st = cg_domp_bwd_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, domain, stream);
+    if (st != CG_ESHAPE) {
+      if (st != CG_OK) return st;
+      hipLaunchKernelGGL(cg_dom_fold_replicas_kernel, dim3((unsigned)((n_w + n_b + 255) / 256)), dim3(256), 0, stream, ws, CG_DOM_REPLICAS,
+                         n_w, n_b, dW, dbias);
+      return cg_launch_status();
+    }
+  }
   // wide layers: every product on the matrix cores (stgcn_domain_mfma.hip); narrow ones (C <= 10 on both sides: CISTGCN-8,
   // the output block) stay on the VALU kernel below, where a 16-wide MFMA tile would be mostly padding
   if ((Cin >= 16 || Cout >= 16) && (domain == 1 ? V : T) <= 64 && cg_dom_env("CG_DOM_BWD_VALU") == nullptr) {

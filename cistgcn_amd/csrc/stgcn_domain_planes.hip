@@ -244,6 +244,319 @@ __global__ __launch_bounds__(CG_DOMP_THREADS, 2) void cg_stgcn_planes_fwd_kernel
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// backward, space domain (Adj (B,V,T,T), one T x T slab per joint)
+//
+// With Z = W . x and y = Z (*) Adj + bias:
+//   dZ[o,t,v] = sum_q dY[o,q,v] A[v,t,q]        dA[v,t,q] = sum_o Z[o,t,v] dY[o,q,v]
+//   dx[c,t,v] = sum_o W[o,c] dZ[o,t,v]          dW[o,c] = sum_{b,t,v} dZ[o,t,v] x[c,t,v]        db[o] = sum dY[o,.,.]
+// Every result that is indexed by the frame t of x needs only rows t of the slabs, so a workgroup owns (sample b, chunk
+// of TC <= 16 frames): its piece of x ([Cin][TC*V], whole plane rows) stays in LDS, dY[b] streams through LDS in pieces
+// of [16 output channels][16 frames q][V] (whole plane rows again; the NTC workgroups of a sample share them through L2),
+// rows t of the slabs come straight from HBM/L2 as matrix-core operands, and dA / dx accumulate in registers over the
+// stream.  Nothing is touched as a 4-byte column; HBM sees x, dY and Adj once and dx, dA once.
+//
+//   per chunk oc of 16 output channels:
+//     S2  Z[o,p] = W[oc+o,:] . sX[:,p]                              -> sZ[v][o][t]
+//     per piece qc (16 frames q):
+//       S4  per joint v (a wave owns joints v = wave, wave + 8, ...):
+//             dA_v[t, q] += sum_o sZ[v][o][t] sY[v][o][q]           (register tiles, persistent)
+//             dZ_v[o, t] += sum_q sY[v][o][q] A_v[t0 + t, q]        (register tiles, per oc)
+//     S5  dZ -> sdZ[o][p]
+//     S6  waves 0-3: dW[oc+o, c] += sum_p sdZ[o][p] sX[c][p]  -> fp32 atomics into a replica of (dW, db)
+//         waves 4-7: dx[c, p]    += sum_o W[oc+o, c] sdZ[o][p]      (register tiles, persistent)
+//   S7  dA tiles -> HBM (64-byte runs of slab rows); dx through sX -> HBM (whole plane rows)
+// ---------------------------------------------------------------------------------------------------------------------
+#define CG_DOMPB_THREADS 512
+#define CG_DOMPB_NW 8
+#define CG_DOMPB_NDX 10      // dx tiles per wave
+#define CG_DOMPB_NOC 4       // chunks of 16 output channels (dW tiles per wave)
+
+template <int VWP, int VWY, int VWA, int NJW, int PF>
+__global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
+                                                                  const float* __restrict__ W, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, float* __restrict__ dadj,
+                                                                  float* __restrict__ ws, int replicas, CgDomP g) {
+  float* sX = reinterpret_cast<float*>(cg_dyn_lds);       // [CinR][XS]
+  float* sdZ = sX + g.CinR * g.XS;                        // [16][XS]
+  float* sZ = sdZ + 16 * g.XS;                            // [V][GZ]   ([16 o][16 t] per joint)
+  float* sY = sZ + g.zfl;                                 // [V][GY]   ([16 o][YS q] per joint)
+  float* sW = sY + g.yfl;                                 // [16][WS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int sb = sidx / g.NTC, tc = sidx - sb * g.NTC, b = sb * 8 + xcd;
+  if (b >= g.B) return;
+  const int T = g.T, V = g.V, Cin = g.Cin, Cout = g.Cout, XS = g.XS, GZ = g.GZ, GY = g.GY, YS = g.YS, WS = g.WS;
+  const int t0 = tc * g.TC, TCn = min(g.TC, T - t0), Pn = TCn * V, NPT = (Pn + 15) / 16;
+  const int NQC = (T + 15) / 16;
+  const long long TV = g.TV;
+
+  for (int e = tid; e < g.bwd_floats; e += CG_DOMPB_THREADS) sX[e] = 0.f;
+  __syncthreads();
+  {   // the workgroup's piece of x: rows [t0, t0 + TCn) of every plane
+    const float* xb = x + (long long)b * Cin * TV + (long long)t0 * V;
+    const int nvp = Pn / VWP;
+    for (int e = tid; e < Cin * nvp; e += CG_DOMPB_THREADS) {
+      const int c = e / nvp, i = e - c * nvp;
+      float v[VWP];
+      cg_domp_ld<VWP>(xb + (long long)c * TV + i * VWP, true, v);
+      cg_domp_st<VWP>(sX + c * XS + i * VWP, v);
+    }
+  }
+
+  // a piece of dY: [16 channels][QCn frames][V] = 16 runs of QCn * V floats; thread (o = tid / 32, k = tid % 32 + 32 i)
+  // moves vector k of run o
+  float pf[PF][VWY];
+  const int po = tid >> 5, pk = tid & 31;
+  auto piece_load = [&](int oc, int qc) {
+    const int q0 = 16 * qc, runv = min(16, T - q0) * V / VWY, co = oc * 16 + po;
+    const float* src = dy + ((long long)(b * Cout + co) * T + q0) * V;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = pk + 32 * i;
+      if (k < runv) cg_domp_ld<VWY>(src + k * VWY, co < Cout, pf[i]);
+    }
+  };
+  auto piece_store = [&](int qc) {
+    const int QCn = min(16, T - 16 * qc), runv = QCn * V / VWY;
+    float* dst = sY + po * YS;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int k = pk + 32 * i;
+      if (k < runv) {
+#pragma unroll
+        for (int jj = 0; jj < VWY; ++jj) {
+          const int idx = k * VWY + jj, q = (int)cg_domp_div((unsigned)idx, g.magicV), v = idx - q * V;
+          dst[v * GY + q] = pf[i][jj];
+        }
+      }
+    }
+    if (QCn < 16) {                                   // last piece: frames beyond T read as zero
+      const int nz = (16 - QCn) * V;
+      for (int r = pk; r < nz; r += 32) {
+        const int q = (int)cg_domp_div((unsigned)r, g.magicV), v = r - q * V;
+        dst[v * GY + QCn + q] = 0.f;
+      }
+    }
+  };
+
+  cg_f32x4 dAacc[NJW][4];
+#pragma unroll
+  for (int a = 0; a < NJW; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dAacc[a][q] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  cg_f32x4 dxacc[CG_DOMPB_NDX];
+#pragma unroll
+  for (int i = 0; i < CG_DOMPB_NDX; ++i) dxacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  cg_f32x4 dWacc[CG_DOMPB_NOC];
+#pragma unroll
+  for (int i = 0; i < CG_DOMPB_NOC; ++i) dWacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int MTc = g.CinR / 16, ndx = MTc * NPT;
+  // dW: wave -> (channel tile ct, slice ks of the position chunks)
+  const int nks = CG_DOMPB_NW / MTc, wct = wave % MTc, wks = wave / MTc;
+  float* wsr = ws + (long long)(blockIdx.x % replicas) * ((long long)Cout * Cin + Cout);
+
+  piece_load(0, 0);
+  const int l15_ = lane & 15, slot_ = lane >> 4;
+#pragma nounroll
+  for (int oc = 0; oc < g.NOC; ++oc) {
+    // the lane coordinates are made opaque per iteration: otherwise every LDS address of the body is hoisted out of the loop
+    // (they do not depend on oc) and ~100 registers of addresses push the accumulators into scratch
+    int l15 = l15_, slot = slot_;
+    CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
+    __syncthreads();                                  // B0: the previous chunk's readers of sW / sZ / sY / sdZ are done
+    for (int e = tid; e < 16 * WS; e += CG_DOMPB_THREADS) {
+      const int o = e / WS, c = e - o * WS;
+      sW[e] = (oc * 16 + o < Cout && c < Cin) ? W[(long long)(oc * 16 + o) * Cin + c] : 0.f;
+    }
+    piece_store(0);
+    cg_f32x4 dZacc[NJW];
+#pragma unroll
+    for (int a = 0; a < NJW; ++a) dZacc[a] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbp = 0.f;
+    __syncthreads();                                  // B1
+
+    // S2
+    for (int pt = wave; pt < NPT; pt += CG_DOMPB_NW) {
+      cg_f32x4 acc = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* ap = sW + l15 * WS + slot;
+      const float* bp = sX + slot * XS + 16 * pt + l15;
+      for (int st = 0; st < g.KS; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], bp[4 * st * XS], acc, 0, 0, 0);
+      const int pp = 16 * pt + l15;
+      if (pp < Pn) {
+        const int t = (int)cg_domp_div((unsigned)pp, g.magicV), v = pp - t * V;
+        float* dst = sZ + v * GZ + 4 * slot * 16 + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r * 16] = acc[r];
+      }
+    }
+    __syncthreads();                                  // B2
+
+#pragma nounroll
+    for (int qc = 0; qc < NQC; ++qc) {
+      {
+        if (qc + 1 < NQC) piece_load(oc, qc + 1);
+        else if (oc + 1 < g.NOC) piece_load(oc + 1, 0);
+        // S4
+        const int q0 = 16 * qc;
+        float ar[NJW][4];
+#pragma unroll
+        for (int a = 0; a < NJW; ++a) {
+          const int v = wave + CG_DOMPB_NW * a;
+          const float* rowp = adj + (((long long)b * V + v) * T + t0 + l15) * T + q0 + 4 * slot;
+#pragma unroll
+          for (int s0 = 0; s0 < 4; s0 += VWA) {
+            float tmp[VWA];
+            cg_domp_ld<VWA>(rowp + s0, v < V && l15 < TCn && q0 + 4 * slot + s0 < T, tmp);
+#pragma unroll
+            for (int i = 0; i < VWA; ++i) ar[a][s0 + i] = tmp[i];
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < NJW; ++a) {
+          const int v = wave + CG_DOMPB_NW * a;
+          if (v < V) {                                // uniform
+            const float* zp = sZ + v * GZ + slot * 16 + l15;
+            const float* yp = sY + v * GY + slot * YS + l15;
+            cg_f32x4 part = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; ++st) part = __builtin_amdgcn_mfma_f32_16x16x4f32(zp[4 * st * 16], yp[4 * st * YS], part, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (qc == k) dAacc[a][k] += part;       // register tiles need compile-time indices
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < NJW; ++a) {
+          const int v = wave + CG_DOMPB_NW * a;
+          if (v < V) {
+            const float* yq = sY + v * GY + l15 * YS + 4 * slot;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+              const float yv = yq[s2];
+              dbp += yv;
+              dZacc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, ar[a][s2], dZacc[a], 0, 0, 0);
+            }
+          }
+        }
+        if (qc + 1 < NQC) {
+          __syncthreads();
+          piece_store(qc + 1);
+          __syncthreads();
+        }
+      }
+    }
+
+    // S5
+#pragma unroll
+    for (int a = 0; a < NJW; ++a) {
+      const int v = wave + CG_DOMPB_NW * a;
+      if (v < V && l15 < TCn) {
+        float* dst = sdZ + 4 * slot * XS + l15 * V + v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r * XS] = dZacc[a][r];
+      }
+    }
+    if (tc == 0) {                                    // the bias gradient is counted by one chunk of frames per sample
+      dbp += __shfl_xor(dbp, 16, 64);
+      dbp += __shfl_xor(dbp, 32, 64);
+      if (slot == 0 && oc * 16 + l15 < Cout) atomicAdd(&wsr[(long long)Cout * Cin + oc * 16 + l15], dbp);
+    }
+    __syncthreads();                                  // B3
+
+    // S6: dW (a slice of the positions per wave) and dx (tiles dealt to the waves)
+    if (wks < nks) {
+      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* ap = sdZ + l15 * XS + 4 * slot;
+      const float* bp = sX + (16 * wct + l15) * XS + 4 * slot;
+      for (int kc = wks; kc < NPT; kc += nks) {
+        const cg_f32x4 a0 = *reinterpret_cast<const cg_f32x4*>(ap + 16 * kc), b0 = *reinterpret_cast<const cg_f32x4*>(bp + 16 * kc);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b0[s2], c0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < CG_DOMPB_NOC; ++k)
+        if (oc == k) dWacc[k] += c0;
+    }
+#pragma unroll
+    for (int i = 0; i < CG_DOMPB_NDX; ++i) {
+      const int id = wave + CG_DOMPB_NW * i;
+      if (id < ndx) {                                 // uniform
+        const int pt = id / MTc, ct = id - pt * MTc;
+        const float* ap = sW + slot * WS + 16 * ct + l15;
+        const float* bp = sdZ + slot * XS + 16 * pt + l15;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) dxacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st * WS], bp[4 * st * XS], dxacc[i], 0, 0, 0);
+      }
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles' operands in flight, not all ten (register budget)
+    }
+  }
+
+  // S7
+  const int l15 = l15_, slot = slot_;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < CG_DOMPB_NDX; ++i) {
+    const int id = wave + CG_DOMPB_NW * i;
+    if (id < ndx) {
+      const int pt = id / MTc, ct = id - pt * MTc;
+      float* dst = sX + (16 * ct + 4 * slot) * XS + 16 * pt + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[r * XS] = dxacc[i][r];
+    }
+  }
+  // dW: the slices ks > 0 hand their tiles over through LDS (the sZ / sY images are free now)
+  float* sPart = sZ;                                  // [wave][NOC][64 lanes][4]
+  if (wks > 0 && wks < nks) {
+#pragma unroll
+    for (int k = 0; k < CG_DOMPB_NOC; ++k) *reinterpret_cast<cg_f32x4*>(sPart + ((wave * CG_DOMPB_NOC + k) * 64 + lane) * 4) = dWacc[k];
+  }
+#pragma unroll
+  for (int a = 0; a < NJW; ++a) {
+    const int v = wave + CG_DOMPB_NW * a;
+    if (v < V) {
+#pragma unroll
+      for (int qc = 0; qc < 4; ++qc) {
+        const int q = 16 * qc + l15;
+        if (qc < NQC && q < T) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = 4 * slot + r;
+            if (t < TCn) dadj[(((long long)b * V + v) * T + t0 + t) * T + q] = dAacc[a][qc][r];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wks == 0) {
+#pragma unroll
+    for (int k = 0; k < CG_DOMPB_NOC; ++k) {
+      if (k < g.NOC) {
+        cg_f32x4 sum = dWacc[k];
+        for (int ks = 1; ks < nks; ++ks)
+          sum += *reinterpret_cast<const cg_f32x4*>(sPart + (((wct + ks * MTc) * CG_DOMPB_NOC + k) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = k * 16 + 4 * slot + r, c = 16 * wct + l15;
+          if (co < Cout && c < Cin) atomicAdd(&wsr[(long long)co * Cin + c], sum[r]);
+        }
+      }
+    }
+  }
+  {
+    float* dxb = dx + (long long)b * Cin * TV + (long long)t0 * V;
+    const int nvp = Pn / VWP;
+    for (int e = tid; e < Cin * nvp; e += CG_DOMPB_THREADS) {
+      const int c = e / nvp, i = e - c * nvp;
+      float v[VWP];
+#pragma unroll
+      for (int jj = 0; jj < VWP; ++jj) v[jj] = sX[c * XS + i * VWP + jj];
+      cg_domp_st<VWP>(dxb + (long long)c * TV + i * VWP, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 static unsigned cg_domp_magic(int d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
@@ -297,5 +610,67 @@ int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const f
   CG_DOMP_FWD(1, 4, 2, 1)      // V = 22 / 18, time
   CG_DOMP_FWD(1, 2, 1, 2)      // V = 25
 #undef CG_DOMP_FWD
+  return CG_ESHAPE;
+}
+
+// geometry of the backward: frames per chunk, LDS images
+int cg_domp_bwd_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V) {
+  int st = cg_domp_geom(g, B, Cin, Cout, T, V, 0);
+  if (st != CG_OK) return st;
+  if (Cin > 64 || Cout > 16 * CG_DOMPB_NOC || T > 64) return CG_ESHAPE;       // register tiles: dx, dW, 4 pieces of 16 frames
+  g.CinR = cg_domp_up(Cin, 16);
+  g.YS = 18; g.GZ = 16 * 16 + 1; g.GY = 16 * g.YS + 2;
+  g.zfl = cg_domp_up(V * g.GZ, 4); g.yfl = cg_domp_up(V * g.GY, 4);
+  g.WS = cg_domp_up(g.WS, 2);
+  const size_t limit = 160 * 1024 - 1024;
+  for (int ntc = (T + 15) / 16; ntc <= T; ++ntc) {
+    const int tc0 = (T + ntc - 1) / ntc;
+    int best = 0, best_al = 0;
+    for (int tc = tc0; tc <= 16 && tc <= tc0 + 2; ++tc) {
+      if ((long long)(ntc - 1) * tc >= T) continue;                 // the last chunk would be empty
+      const int last = T - (ntc - 1) * tc;
+      const int al = ((tc * V) % 4 == 0 && (last * V) % 4 == 0 && g.TV % 4 == 0) ? 4 : ((tc * V) % 2 == 0 && (last * V) % 2 == 0 && g.TV % 2 == 0) ? 2 : 1;
+      const int xs = cg_domp_up(tc * V, 16);
+      const size_t bytes = ((size_t)(g.CinR + 16) * xs + g.zfl + g.yfl + 16 * (size_t)g.WS) * sizeof(float);
+      if (bytes > limit || (g.CinR / 16) * (xs / 16) > CG_DOMPB_NDX * CG_DOMPB_NW) continue;
+      if (al > best_al) { best = tc; best_al = al; }
+    }
+    if (best) {
+      g.NTC = ntc; g.TC = best; g.VWP = best_al;
+      g.XS = cg_domp_up(best * V, 16);
+      g.bwd_floats = (g.CinR + 16) * g.XS + g.zfl + g.yfl + 16 * g.WS;
+      const int lastq = T - 16 * ((T + 15) / 16 - 1);
+      g.VWY = (g.TV % 4 == 0 && (lastq * V) % 4 == 0) ? 4 : (g.TV % 2 == 0 && (lastq * V) % 2 == 0) ? 2 : 1;
+      g.VWA = T % 4 == 0 ? 4 : T % 2 == 0 ? 2 : 1;
+      return CG_OK;
+    }
+  }
+  return CG_ESHAPE;
+}
+
+// launches the backward kernel; `ws` holds `replicas` zeroed copies of (dW, db), folded by the caller
+int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
+                       int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream) {
+  if (domain != 0) return CG_ESHAPE;
+  CgDomP g;
+  int st = cg_domp_bwd_geom(g, B, Cin, Cout, T, V);
+  if (st != CG_OK) return st;
+  const size_t lds = (size_t)g.bwd_floats * sizeof(float);
+  const int njw = (V + CG_DOMPB_NW - 1) / CG_DOMPB_NW;
+  dim3 grid((unsigned)(8 * ((B + 7) / 8) * g.NTC)), block(CG_DOMPB_THREADS);
+  const int pfn = (16 * V / g.VWY + 31) / 32;          // vectors per thread of one dY piece
+  if (g.zfl + g.yfl < CG_DOMPB_NW * CG_DOMPB_NOC * 256) return CG_ESHAPE;       // hand-over buffer of the dW slices
+#define CG_DOMP_BWD(VWP_, VWY_, VWA_, NJW_, PF_)                                                                                   \
+  if (g.VWP == VWP_ && g.VWY == VWY_ && g.VWA == VWA_ && njw <= NJW_ && pfn <= PF_) {                                             \
+    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_>,                      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    if (e != hipSuccess) return (int)e;                                                                                            \
+    hipLaunchKernelGGL((cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_>), grid, block, lds, stream, x, adj, W, dy, dx,    \
+                       dadj, ws, replicas, g);                                                                                     \
+    return cg_launch_status();                                                                                                     \
+  }
+  CG_DOMP_BWD(4, 4, 2, 3, 3)      // T*V % 4 == 0, T even, V <= 24  (H3.6M 22 joints, AMASS 18)
+  CG_DOMP_BWD(2, 2, 2, 4, 7)      // V = 25
+#undef CG_DOMP_BWD
   return CG_ESHAPE;
 }

@@ -25,6 +25,9 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 extern thread_local dim3 threadIdx;
 extern dim3 blockIdx, blockDim, gridDim;
 
+#define CG_OPAQUE_V(x) ((void)(x))
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+struct float2 { float x, y; } __attribute__((aligned(8)));
 #define __global__
 #define __device__
 #define __host__
