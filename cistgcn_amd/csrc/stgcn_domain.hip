@@ -600,7 +600,10 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   int st = cg_dom_geom(g, B, Cin, Cout, T, V, domain, false);
   if (st != CG_OK) return st;
   // wide layers, third generation: plane kernels (stgcn_domain_planes.hip) - whole plane rows in HBM, LDS as the transposer
-  if ((Cin >= 16 || Cout >= 16) && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+  // (a grid of fewer than 256 workgroups - small batches - leaves most CUs idle: the tile kernels split a sample finer; the
+  // time-domain variant for odd V reads its slabs one float per lane and measured no faster than the tile kernel)
+  if ((Cin >= 16 || Cout >= 16) && (long long)B * ((Cout + 15) / 16) >= 256 && !(domain == 1 && (V & 1)) &&
+      cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
     st = cg_domp_fwd_launch(x, adj, W, bias, y, ystats, B, Cin, Cout, T, V, domain, (hipStream_t)stream_);
     if (st != CG_ESHAPE) return st;
   }
@@ -666,7 +669,9 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
     if (zs != CG_OK) return zs;
   }
   // wide layers, space domain: plane backward (stgcn_domain_planes.hip)
-  if ((Cin >= 16 || Cout >= 16) && domain == 0 && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+  // (narrow inputs: the channel-mix-first order makes the graph products as wide as the OUTPUT, the tile kernels keep them
+  // as wide as the input - 229 vs 279 us at 10 -> 64; small batches: as in the forward)
+  if (Cin >= 16 && domain == 0 && (long long)B * ((T + 15) / 16) >= 256 && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
     st = cg_domp_bwd_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, domain, stream);
     if (st != CG_ESHAPE) {
       if (st != CG_OK) return st;

@@ -33,6 +33,13 @@ typedef float cg_f32x2 __attribute__((vector_size(8)));
 #define CG_DOMP_THREADS 256
 #define CG_DOMP_NW (CG_DOMP_THREADS / 64)
 
+// Column swizzle of the dY image sY[joint][16 channels o][16 frames q] (row stride 16 floats).  The image is read two ways by the
+// matrix cores: (q across the 16 lanes of a row, o across the four lane rows) for dA and (o across lanes, q across rows) for dZ.
+// Rows of opposite parity sit in opposite halves of the 32 banks (stride 16), which makes the first pattern conflict free; the
+// XOR below spreads the 8 rows of one parity over all 16 columns of their half for the second one: a lane row reads columns
+// {q, q ^ 4}, so the swizzle must differ between rows in the bits other than bit 2.
+__device__ __forceinline__ int cg_domp_swz(int o) { const int h = o >> 1; return (h & 3) | ((h & 4) << 1); }
+
 __device__ __forceinline__ unsigned cg_domp_div(unsigned n, unsigned magic) {     // n / d, magic = ceil(2^32 / d), 0 for d = 1; n < 2^20
   return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n;
 }
@@ -76,7 +83,7 @@ __device__ __forceinline__ void cg_domp_split(const CgDomP& g, int p, int& grp, 
 template <int DOMAIN, int VW>
 __device__ __forceinline__ void cg_domp_mix_planes(const CgDomP& g, const float* __restrict__ xb, long long cs, int Cin, int KS,
                                                    const float* sW, int WS, float* sZ, int pbeg, int pend, int jshift) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l15 = lane & 15, slot = lane >> 4;
   const int nunits = (pend - pbeg + 16 * VW - 1) / (16 * VW);
   const float* wrow = sW + l15 * WS + slot;
   for (int u = wave; u < nunits; u += CG_DOMP_NW) {
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(CG_DOMP_THREADS, 2) void cg_stgcn_planes_fwd_kernel
   float* sZ = reinterpret_cast<float*>(cg_dyn_lds);
   float* sW = sZ + g.zfloats;
   double* sStat = reinterpret_cast<double*>(sW + 16 * g.WS);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   // placement: the NOC chunks of a sample sit next to each other in the dispatch order of one XCD
   const int xcd = blockIdx.x & 7, s = blockIdx.x >> 3;
   const int sb = s / g.NOC, oc = s - sb * g.NOC, b = sb * 8 + xcd;
@@ -266,12 +273,28 @@ __global__ __launch_bounds__(CG_DOMP_THREADS, 2) void cg_stgcn_planes_fwd_kernel
 //         waves 4-7: dx[c, p]    += sum_o W[oc+o, c] sdZ[o][p]      (register tiles, persistent)
 //   S7  dA tiles -> HBM (64-byte runs of slab rows); dx through sX -> HBM (whole plane rows)
 // ---------------------------------------------------------------------------------------------------------------------
+// Diagnostic build only (tools/stamps_planes.py compiles a private copy of the library with -DCG_DOMP_STAMPS): thread 0 of every
+// workgroup stores the shader clock at the phase boundaries into a buffer of its own; no result depends on it and no stamp
+// executes in the shipped library.
+#ifdef CG_DOMP_STAMPS
+__device__ unsigned long long* cg_domp_stamp_buf = nullptr;
+extern "C" int cg_domp_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(cg_domp_stamp_buf), &p, sizeof(p)); }
+#define CG_STAMP()                                                                                      \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && cg_domp_stamp_buf && nst < 255) cg_domp_stamp_buf[blockIdx.x * 256 + (++nst)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define CG_STAMP_END() do { if (threadIdx.x == 0 && cg_domp_stamp_buf) cg_domp_stamp_buf[blockIdx.x * 256] = nst; } while (0)
+#else
+#define CG_STAMP() do { } while (0)
+#define CG_STAMP_END() do { } while (0)
+#endif
+
 #define CG_DOMPB_THREADS 512
 #define CG_DOMPB_NW 8
-#define CG_DOMPB_NDX 10      // dx tiles per wave
+#define CG_DOMPB_NDX 10      // dx tiles per wave (upper bound over the instantiations)
 #define CG_DOMPB_NOC 4       // chunks of 16 output channels (dW tiles per wave)
 
-template <int VWP, int VWY, int VWA, int NJW, int PF>
+template <int VWP, int VWY, int VWA, int NJW, int PF, int NDX>
 __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kernel(const float* __restrict__ x, const float* __restrict__ adj,
                                                                   const float* __restrict__ W, const float* __restrict__ dy,
                                                                   float* __restrict__ dx, float* __restrict__ dadj,
@@ -281,7 +304,8 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   float* sZ = sdZ + 16 * g.XS;                            // [V][GZ]   ([16 o][16 t] per joint)
   float* sY = sZ + g.zfl;                                 // [V][GY]   ([16 o][YS q] per joint)
   float* sW = sY + g.yfl;                                 // [16][WS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform for the compiler: scalar address arithmetic
+  const int l15_ = lane & 15, slot_ = lane >> 4;
   const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
   const int sb = sidx / g.NTC, tc = sidx - sb * g.NTC, b = sb * 8 + xcd;
   if (b >= g.B) return;
@@ -290,16 +314,35 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   const int NQC = (T + 15) / 16;
   const long long TV = g.TV;
 
-  for (int e = tid; e < g.bwd_floats; e += CG_DOMPB_THREADS) sX[e] = 0.f;
-  __syncthreads();
-  {   // the workgroup's piece of x: rows [t0, t0 + TCn) of every plane
+  int nst = 0; (void)nst;
+  CG_STAMP();                                         // 1: start
+  {   // the workgroup's piece of x: rows [t0, t0 + TCn) of every plane.  A wave moves 8 vectors per round: 4 planes x 2 vectors
+      // per lane (128 vectors per plane row cover nvp <= 128); all requests of a round are in flight before the first LDS store,
+      // and the first round travels while the LDS image is zeroed
     const float* xb = x + (long long)b * Cin * TV + (long long)t0 * V;
     const int nvp = Pn / VWP;
-    for (int e = tid; e < Cin * nvp; e += CG_DOMPB_THREADS) {
-      const int c = e / nvp, i = e - c * nvp;
-      float v[VWP];
-      cg_domp_ld<VWP>(xb + (long long)c * TV + i * VWP, true, v);
-      cg_domp_st<VWP>(sX + c * XS + i * VWP, v);
+    float xr[8][VWP];
+    auto x_load = [&](int c0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + (u >> 1), i = lane + 64 * (u & 1);
+        cg_domp_ld<VWP>(xb + ((long long)c * TV + i * VWP), c < Cin && i < nvp, xr[u]);
+      }
+    };
+    auto x_store = [&](int c0) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + (u >> 1), i = lane + 64 * (u & 1);
+        if (c < Cin && i < nvp) cg_domp_st<VWP>(sX + c * XS + i * VWP, xr[u]);
+      }
+    };
+    x_load(4 * wave);
+    for (int e = tid; e < g.bwd_floats; e += CG_DOMPB_THREADS) sX[e] = 0.f;
+    __syncthreads();
+    CG_STAMP();                                       // 2: LDS zeroed
+    for (int c0 = 4 * wave; c0 < Cin; c0 += 4 * CG_DOMPB_NW) {
+      x_store(c0);
+      if (c0 + 4 * CG_DOMPB_NW < Cin) x_load(c0 + 4 * CG_DOMPB_NW);
     }
   }
 
@@ -309,32 +352,35 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   const int po = tid >> 5, pk = tid & 31;
   auto piece_load = [&](int oc, int qc) {
     const int q0 = 16 * qc, runv = min(16, T - q0) * V / VWY, co = oc * 16 + po;
-    const float* src = dy + ((long long)(b * Cout + co) * T + q0) * V;
+    const float* src = dy + ((long long)(b * Cout + oc * 16) * T + q0) * V;        // uniform
+    const int voff = po * g.TV + pk * VWY;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int k = pk + 32 * i;
-      if (k < runv) cg_domp_ld<VWY>(src + k * VWY, co < Cout, pf[i]);
+      if (k < runv) cg_domp_ld<VWY>(src + (voff + 32 * i * VWY), co < Cout, pf[i]);
     }
   };
+  // LDS offsets of the PF * VWY elements a thread moves per piece: they do not depend on the piece (a short last piece uses a
+  // prefix of them).  Frames beyond T keep the finite values of an earlier piece: the dZ product multiplies them with slab rows
+  // that are masked to zero, the dA product only fills columns q >= T that are never stored, the bias gradient masks them.
+  int pso[PF][VWY];
+  {
+    const int sw = cg_domp_swz(po);
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+#pragma unroll
+      for (int jj = 0; jj < VWY; ++jj) {
+        const int idx = (pk + 32 * i) * VWY + jj, q = (int)cg_domp_div((unsigned)idx, g.magicV), v = idx - q * V;
+        pso[i][jj] = v * GY + po * 16 + ((q & 15) ^ sw);
+      }
+  }
   auto piece_store = [&](int qc) {
-    const int QCn = min(16, T - 16 * qc), runv = QCn * V / VWY;
-    float* dst = sY + po * YS;
+    const int runv = min(16, T - 16 * qc) * V / VWY;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-      const int k = pk + 32 * i;
-      if (k < runv) {
+      if (pk + 32 * i < runv) {
 #pragma unroll
-        for (int jj = 0; jj < VWY; ++jj) {
-          const int idx = k * VWY + jj, q = (int)cg_domp_div((unsigned)idx, g.magicV), v = idx - q * V;
-          dst[v * GY + q] = pf[i][jj];
-        }
-      }
-    }
-    if (QCn < 16) {                                   // last piece: frames beyond T read as zero
-      const int nz = (16 - QCn) * V;
-      for (int r = pk; r < nz; r += 32) {
-        const int q = (int)cg_domp_div((unsigned)r, g.magicV), v = r - q * V;
-        dst[v * GY + QCn + q] = 0.f;
+        for (int jj = 0; jj < VWY; ++jj) sY[pso[i][jj]] = pf[i][jj];
       }
     }
   };
@@ -344,109 +390,204 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   for (int a = 0; a < NJW; ++a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) dAacc[a][q] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-  cg_f32x4 dxacc[CG_DOMPB_NDX];
+  cg_f32x4 dxacc[NDX];
 #pragma unroll
-  for (int i = 0; i < CG_DOMPB_NDX; ++i) dxacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-  cg_f32x4 dWacc[CG_DOMPB_NOC];
-#pragma unroll
-  for (int i = 0; i < CG_DOMPB_NOC; ++i) dWacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NDX; ++i) dxacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  cg_f32x4 dWhold = cg_f32x4{0.f, 0.f, 0.f, 0.f};          // slice 0 of the dW tile of the previous chunk, flushed behind the next barrier
   const int MTc = g.CinR / 16, ndx = MTc * NPT;
   // dW: wave -> (channel tile ct, slice ks of the position chunks)
   const int nks = CG_DOMPB_NW / MTc, wct = wave % MTc, wks = wave / MTc;
   float* wsr = ws + (long long)(blockIdx.x % replicas) * ((long long)Cout * Cin + Cout);
+  float* sPart = sW + 16 * WS;                            // [wave][64 lanes][4]: dW tiles of the position slices ks > 0
+  // adds the slices of output chunk `ocp` (slice 0 in dWhold, the others in sPart) into the replica; call behind a barrier
+  auto dw_flush = [&](int ocp) {
+    if (wks == 0) {
+      cg_f32x4 sum = dWhold;
+      for (int ks = 1; ks < nks; ++ks) sum += *reinterpret_cast<const cg_f32x4*>(sPart + ((wct + ks * MTc) * 64 + lane) * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = ocp * 16 + 4 * slot_ + r, c = 16 * wct + l15_;
+        if (co < Cout && c < Cin) atomicAdd(&wsr[(long long)co * Cin + c], sum[r]);
+      }
+    }
+  };
 
+  // rows [t0, t0 + TCn) of the slabs of this wave's joints, 16 columns q of piece qc: the B operand of the dZ product
+  auto rows_load = [&](int qc, float (&dst)[NJW][4]) {
+    const int q0 = 16 * qc;
+#pragma unroll
+    for (int a = 0; a < NJW; ++a) {
+      const int v = wave + CG_DOMPB_NW * a;
+      const float* rowb = adj + (((long long)b * V + v) * T + t0) * T + q0;              // uniform
+      const int voff = l15_ * T + 4 * slot_;
+#pragma unroll
+      for (int s0 = 0; s0 < 4; s0 += VWA) {
+        float tmp[VWA];
+        cg_domp_ld<VWA>(rowb + (voff + s0), v < V && l15_ < TCn && q0 + 4 * slot_ + s0 < T, tmp);
+#pragma unroll
+        for (int i = 0; i < VWA; ++i) dst[a][s0 + i] = tmp[i];
+      }
+    }
+  };
+  float ar[NJW][4];
+  rows_load(0, ar);
   piece_load(0, 0);
-  const int l15_ = lane & 15, slot_ = lane >> 4;
+  // weights of the next chunk of output channels travel in registers while the current chunk computes
+  float wq[3];
+  auto w_load = [&](int oc) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int e = tid + i * CG_DOMPB_THREADS, o = e / WS, c = e - o * WS;
+      wq[i] = (e < 16 * WS && oc * 16 + o < Cout && c < Cin) ? W[(long long)(oc * 16 + o) * Cin + c] : 0.f;
+    }
+  };
+  w_load(0);
 #pragma nounroll
   for (int oc = 0; oc < g.NOC; ++oc) {
-    // the lane coordinates are made opaque per iteration: otherwise every LDS address of the body is hoisted out of the loop
-    // (they do not depend on oc) and ~100 registers of addresses push the accumulators into scratch
     int l15 = l15_, slot = slot_;
-    CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
+    CG_STAMP();                                       // oc+0: before B0 (first chunk: setup + x piece issued)
     __syncthreads();                                  // B0: the previous chunk's readers of sW / sZ / sY / sdZ are done
-    for (int e = tid; e < 16 * WS; e += CG_DOMPB_THREADS) {
-      const int o = e / WS, c = e - o * WS;
-      sW[e] = (oc * 16 + o < Cout && c < Cin) ? W[(long long)(oc * 16 + o) * Cin + c] : 0.f;
-    }
+    CG_STAMP();                                       // oc+1: after B0
+    if (oc > 0) dw_flush(oc - 1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (tid + i * CG_DOMPB_THREADS < 16 * WS) sW[tid + i * CG_DOMPB_THREADS] = wq[i];
+    if (oc + 1 < g.NOC) w_load(oc + 1);
     piece_store(0);
     cg_f32x4 dZacc[NJW];
 #pragma unroll
     for (int a = 0; a < NJW; ++a) dZacc[a] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
     float dbp = 0.f;
+    CG_STAMP();                                       // oc+2: sW + piece 0 stored
     __syncthreads();                                  // B1
+    CG_STAMP();                                       // oc+3
 
-    // S2
-    for (int pt = wave; pt < NPT; pt += CG_DOMPB_NW) {
-      cg_f32x4 acc = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    // S2: two position tiles per pass share the weight fragments; four K steps of operands are in flight at a time
+    // (the lane coordinates are made opaque per phase: the LDS addresses derived from them are then recomputed where they are
+    // used - a few integer operations - instead of being hoisted out of the loops into ~60 registers that push the accumulators
+    // into scratch; scratch reloads count in vmcnt and would make every phase wait for the global prefetches in flight)
+    CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
+    for (int pt = wave; pt < NPT; pt += 2 * CG_DOMPB_NW) {
+      const int pt1 = pt + CG_DOMPB_NW < NPT ? pt + CG_DOMPB_NW : pt;     // (recomputes the same tile when there is no partner)
+      cg_f32x4 acc0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       const float* ap = sW + l15 * WS + slot;
-      const float* bp = sX + slot * XS + 16 * pt + l15;
-      for (int st = 0; st < g.KS; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st], bp[4 * st * XS], acc, 0, 0, 0);
-      const int pp = 16 * pt + l15;
-      if (pp < Pn) {
-        const int t = (int)cg_domp_div((unsigned)pp, g.magicV), v = pp - t * V;
-        float* dst = sZ + v * GZ + 4 * slot * 16 + t;
+      const float* bp0 = sX + slot * XS + 16 * pt + l15;
+      const float* bp1 = sX + slot * XS + 16 * pt1 + l15;
+      // the images are zero padded to a multiple of four steps; the operands of the next four steps are read while the
+      // matrix cores work on the current ones
+      float fa[12], fb[12];
+      auto s2_ld = [&](int k0, float (&f)[12]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[r * 16] = acc[r];
+        for (int s2 = 0; s2 < 4; ++s2) { f[s2] = ap[4 * (k0 + s2)]; f[4 + s2] = bp0[4 * (k0 + s2) * XS]; f[8 + s2] = bp1[4 * (k0 + s2) * XS]; }
+      };
+      auto s2_mm = [&](const float (&f)[12]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[4 + s2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], acc1, 0, 0, 0);
+        }
+      };
+      s2_ld(0, fa);
+      for (int k0 = 0; k0 < g.KS; k0 += 8) {
+        if (k0 + 4 < g.KS) s2_ld(k0 + 4, fb);
+        s2_mm(fa);
+        if (k0 + 4 < g.KS) {
+          if (k0 + 8 < g.KS) s2_ld(k0 + 8, fa);
+          s2_mm(fb);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pp = 16 * (h ? pt1 : pt) + l15;
+        if (pp < Pn && (h == 0 || pt1 != pt)) {
+          const int t = (int)cg_domp_div((unsigned)pp, g.magicV), v = pp - t * V;
+          float* dst = sZ + v * GZ + 4 * slot * 16 + t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[r * 16] = h ? acc1[r] : acc0[r];
+        }
       }
     }
+    CG_STAMP();                                       // oc+4: S2 done
     __syncthreads();                                  // B2
+    CG_STAMP();                                       // oc+5
 
 #pragma nounroll
     for (int qc = 0; qc < NQC; ++qc) {
       {
         if (qc + 1 < NQC) piece_load(oc, qc + 1);
         else if (oc + 1 < g.NOC) piece_load(oc + 1, 0);
+        CG_STAMP();                                   // fine: piece_load issued
         // S4
         const int q0 = 16 * qc;
-        float ar[NJW][4];
+        CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
+        // no branches around the joints: the three (four) products of a wave interleave on the matrix pipe.  A joint index
+        // beyond V (last round of some waves) is clamped: its tiles are computed from joint V - 1 and never stored.
+        {
+          cg_f32x4 part[NJW];
+          {
+            float za[NJW][4], ya[NJW][4];
 #pragma unroll
-        for (int a = 0; a < NJW; ++a) {
-          const int v = wave + CG_DOMPB_NW * a;
-          const float* rowp = adj + (((long long)b * V + v) * T + t0 + l15) * T + q0 + 4 * slot;
+            for (int a = 0; a < NJW; ++a) {
+              const int v = min(wave + CG_DOMPB_NW * a, V - 1);
+              const float* zp = sZ + v * GZ + slot * 16 + l15;
+              const float* yp = sY + v * GY + slot * 16;
 #pragma unroll
-          for (int s0 = 0; s0 < 4; s0 += VWA) {
-            float tmp[VWA];
-            cg_domp_ld<VWA>(rowp + s0, v < V && l15 < TCn && q0 + 4 * slot + s0 < T, tmp);
+              for (int st = 0; st < 4; ++st) {
+                za[a][st] = zp[4 * st * 16];
+                ya[a][st] = yp[4 * st * 16 + (l15 ^ cg_domp_swz(slot + 4 * st))];      // row o = slot + 4 st
+              }
+            }
 #pragma unroll
-            for (int i = 0; i < VWA; ++i) ar[a][s0 + i] = tmp[i];
+            for (int a = 0; a < NJW; ++a) part[a] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+              for (int a = 0; a < NJW; ++a) part[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a][st], ya[a][st], part[a], 0, 0, 0);
           }
-        }
+          CG_STAMP();                                 // fine: dA issued
+          {
+            float yb[NJW][4];
+            const int sw = cg_domp_swz(l15);
 #pragma unroll
-        for (int a = 0; a < NJW; ++a) {
-          const int v = wave + CG_DOMPB_NW * a;
-          if (v < V) {                                // uniform
-            const float* zp = sZ + v * GZ + slot * 16 + l15;
-            const float* yp = sY + v * GY + slot * YS + l15;
-            cg_f32x4 part = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < NJW; ++a) {
+              const int v = min(wave + CG_DOMPB_NW * a, V - 1);
+              const float* yq = sY + v * GY + l15 * 16;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) part = __builtin_amdgcn_mfma_f32_16x16x4f32(zp[4 * st * 16], yp[4 * st * YS], part, 0, 0, 0);
+              for (int st = 0; st < 4; ++st) yb[a][st] = yq[(4 * slot + st) ^ sw];
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+              for (int a = 0; a < NJW; ++a) {
+                dZacc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(yb[a][st], ar[a][st], dZacc[a], 0, 0, 0);
+                dbp += (q0 + 4 * slot + st < T && wave + CG_DOMPB_NW * a < V) ? yb[a][st] : 0.f;
+              }
+          }
+          CG_STAMP();                                 // fine: dZ issued
+#pragma unroll
+          for (int a = 0; a < NJW; ++a)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (qc == k) dAacc[a][k] += part;       // register tiles need compile-time indices
-          }
+              if (qc == k) dAacc[a][k] += part[a];    // register tiles need compile-time indices
         }
-#pragma unroll
-        for (int a = 0; a < NJW; ++a) {
-          const int v = wave + CG_DOMPB_NW * a;
-          if (v < V) {
-            const float* yq = sY + v * GY + l15 * YS + 4 * slot;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-              const float yv = yq[s2];
-              dbp += yv;
-              dZacc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(yv, ar[a][s2], dZacc[a], 0, 0, 0);
-            }
-          }
-        }
+        CG_STAMP();                                   // fine: accumulated
+        // slab rows of the next piece: requested behind the dY piece (vmcnt retires in order: the piece is waited for first, by
+        // piece_store, and these rows are not needed before the next S4 has done its dA products)
+        rows_load(qc + 1 < NQC ? qc + 1 : 0, ar);
+        CG_STAMP();                                   // q+0: S4 done
         if (qc + 1 < NQC) {
           __syncthreads();
+          CG_STAMP();                                 // q+1
           piece_store(qc + 1);
+          CG_STAMP();                                 // q+2: piece stored (includes the wait for its loads)
           __syncthreads();
+          CG_STAMP();                                 // q+3
         }
       }
     }
 
     // S5
+    CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
 #pragma unroll
     for (int a = 0; a < NJW; ++a) {
       const int v = wave + CG_DOMPB_NW * a;
@@ -461,54 +602,66 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
       dbp += __shfl_xor(dbp, 32, 64);
       if (slot == 0 && oc * 16 + l15 < Cout) atomicAdd(&wsr[(long long)Cout * Cin + oc * 16 + l15], dbp);
     }
+    CG_STAMP();                                       // S5 done
     __syncthreads();                                  // B3
+    CG_STAMP();
 
     // S6: dW (a slice of the positions per wave) and dx (tiles dealt to the waves)
+    CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
     if (wks < nks) {
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f};
       const float* ap = sdZ + l15 * XS + 4 * slot;
       const float* bp = sX + (16 * wct + l15) * XS + 4 * slot;
       for (int kc = wks; kc < NPT; kc += nks) {
-        const cg_f32x4 a0 = *reinterpret_cast<const cg_f32x4*>(ap + 16 * kc), b0 = *reinterpret_cast<const cg_f32x4*>(bp + 16 * kc);
+        cg_f32x4 a0 = *reinterpret_cast<const cg_f32x4*>(ap + 16 * kc);
+        const cg_f32x4 b0 = *reinterpret_cast<const cg_f32x4*>(bp + 16 * kc);
+        if (16 * kc + 16 > Pn) {                      // beyond the chunk's positions the row stride wraps into the next row
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) a0[s2] = (16 * kc + 4 * slot + s2 < Pn) ? a0[s2] : 0.f;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b0[s2], c0, 0, 0, 0);
       }
-#pragma unroll
-      for (int k = 0; k < CG_DOMPB_NOC; ++k)
-        if (oc == k) dWacc[k] += c0;
+      if (wks == 0) dWhold = c0;
+      else *reinterpret_cast<cg_f32x4*>(sPart + (wave * 64 + lane) * 4) = c0;
     }
+    {
+      // dx: the channel tile of a wave is fixed (8 % MTc == 0), its weight fragments are read once per chunk
+      const int ct = wave % MTc;
+      const float* ap = sW + slot * WS + 16 * ct + l15;
+      float aw[4];
 #pragma unroll
-    for (int i = 0; i < CG_DOMPB_NDX; ++i) {
-      const int id = wave + CG_DOMPB_NW * i;
-      if (id < ndx) {                                 // uniform
-        const int pt = id / MTc, ct = id - pt * MTc;
-        const float* ap = sW + slot * WS + 16 * ct + l15;
-        const float* bp = sdZ + slot * XS + 16 * pt + l15;
+      for (int st = 0; st < 4; ++st) aw[st] = ap[4 * st * WS];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) dxacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * st * WS], bp[4 * st * XS], dxacc[i], 0, 0, 0);
+      for (int i = 0; i < NDX; ++i) {
+        const int id = wave + CG_DOMPB_NW * i;
+        if (id < ndx) {                               // uniform
+          const float* bp = sdZ + slot * XS + 16 * (id / MTc) + l15;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) dxacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[st], bp[4 * st * XS], dxacc[i], 0, 0, 0);
+        }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // four tiles' operands in flight, not all ten (register budget)
       }
-      if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles' operands in flight, not all ten (register budget)
     }
   }
 
   // S7
   const int l15 = l15_, slot = slot_;
+  CG_STAMP();                                         // last S6 done
   __syncthreads();
+  CG_STAMP();
+  dw_flush(g.NOC - 1);
 #pragma unroll
-  for (int i = 0; i < CG_DOMPB_NDX; ++i) {
+  for (int i = 0; i < NDX; ++i) {
     const int id = wave + CG_DOMPB_NW * i;
     if (id < ndx) {
       const int pt = id / MTc, ct = id - pt * MTc;
       float* dst = sX + (16 * ct + 4 * slot) * XS + 16 * pt + l15;
+      if (16 * pt + l15 < Pn) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[r * XS] = dxacc[i][r];
+        for (int r = 0; r < 4; ++r) dst[r * XS] = dxacc[i][r];
+      }
     }
-  }
-  // dW: the slices ks > 0 hand their tiles over through LDS (the sZ / sY images are free now)
-  float* sPart = sZ;                                  // [wave][NOC][64 lanes][4]
-  if (wks > 0 && wks < nks) {
-#pragma unroll
-    for (int k = 0; k < CG_DOMPB_NOC; ++k) *reinterpret_cast<cg_f32x4*>(sPart + ((wave * CG_DOMPB_NOC + k) * 64 + lane) * 4) = dWacc[k];
   }
 #pragma unroll
   for (int a = 0; a < NJW; ++a) {
@@ -518,42 +671,45 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
       for (int qc = 0; qc < 4; ++qc) {
         const int q = 16 * qc + l15;
         if (qc < NQC && q < T) {
+          float* db_ = dadj + (((long long)b * V + v) * T + t0) * T;                     // uniform
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int t = 4 * slot + r;
-            if (t < TCn) dadj[(((long long)b * V + v) * T + t0 + t) * T + q] = dAacc[a][qc][r];
+            if (t < TCn) db_[t * T + q] = dAacc[a][qc][r];
           }
         }
       }
     }
   }
   __syncthreads();
-  if (wks == 0) {
-#pragma unroll
-    for (int k = 0; k < CG_DOMPB_NOC; ++k) {
-      if (k < g.NOC) {
-        cg_f32x4 sum = dWacc[k];
-        for (int ks = 1; ks < nks; ++ks)
-          sum += *reinterpret_cast<const cg_f32x4*>(sPart + (((wct + ks * MTc) * CG_DOMPB_NOC + k) * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = k * 16 + 4 * slot + r, c = 16 * wct + l15;
-          if (co < Cout && c < Cin) atomicAdd(&wsr[(long long)co * Cin + c], sum[r]);
-        }
-      }
-    }
-  }
   {
     float* dxb = dx + (long long)b * Cin * TV + (long long)t0 * V;
     const int nvp = Pn / VWP;
-    for (int e = tid; e < Cin * nvp; e += CG_DOMPB_THREADS) {
-      const int c = e / nvp, i = e - c * nvp;
-      float v[VWP];
+    for (int c0 = 4 * wave; c0 < Cin; c0 += 4 * CG_DOMPB_NW) {
+      float xr[8][VWP];
 #pragma unroll
-      for (int jj = 0; jj < VWP; ++jj) v[jj] = sX[c * XS + i * VWP + jj];
-      cg_domp_st<VWP>(dxb + (long long)c * TV + i * VWP, v);
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + (u >> 1), i = lane + 64 * (u & 1);
+        if (c < Cin && i < nvp) {
+          if constexpr (VWP == 4) {
+            const cg_f32x4 t = *reinterpret_cast<const cg_f32x4*>(sX + c * XS + i * VWP);
+#pragma unroll
+            for (int jj = 0; jj < VWP; ++jj) xr[u][jj] = t[jj];
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < VWP; ++jj) xr[u][jj] = sX[c * XS + i * VWP + jj];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + (u >> 1), i = lane + 64 * (u & 1);
+        if (c < Cin && i < nvp) cg_domp_st<VWP>(dxb + ((long long)c * TV + i * VWP), xr[u]);
+      }
     }
   }
+  CG_STAMP();
+  CG_STAMP_END();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -613,13 +769,17 @@ int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const f
   return CG_ESHAPE;
 }
 
+// row stride of the x piece and of sdZ: == 4 (mod 8) floats, so that the 16 rows of a float4 fragment read (dW product) start in 16
+// different 4-bank groups; tiles that reach beyond the chunk's positions wrap into the next row and are masked where that matters
+static int cg_domp_xs(int p) { int xs = cg_domp_up(p, 4); return (xs % 8 == 4) ? xs : xs + 4; }
+
 // geometry of the backward: frames per chunk, LDS images
 int cg_domp_bwd_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V) {
   int st = cg_domp_geom(g, B, Cin, Cout, T, V, 0);
   if (st != CG_OK) return st;
-  if (Cin > 64 || Cout > 16 * CG_DOMPB_NOC || T > 64) return CG_ESHAPE;       // register tiles: dx, dW, 4 pieces of 16 frames
+  if (Cin > 64 || T > 64) return CG_ESHAPE;       // register tiles: dx, 4 pieces of 16 frames
   g.CinR = cg_domp_up(Cin, 16);
-  g.YS = 18; g.GZ = 16 * 16 + 1; g.GY = 16 * g.YS + 2;
+  g.YS = 16; g.GZ = 16 * 16 + 1; g.GY = 16 * 16 + 1;
   g.zfl = cg_domp_up(V * g.GZ, 4); g.yfl = cg_domp_up(V * g.GY, 4);
   g.WS = cg_domp_up(g.WS, 2);
   const size_t limit = 160 * 1024 - 1024;
@@ -630,15 +790,15 @@ int cg_domp_bwd_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V) {
       if ((long long)(ntc - 1) * tc >= T) continue;                 // the last chunk would be empty
       const int last = T - (ntc - 1) * tc;
       const int al = ((tc * V) % 4 == 0 && (last * V) % 4 == 0 && g.TV % 4 == 0) ? 4 : ((tc * V) % 2 == 0 && (last * V) % 2 == 0 && g.TV % 2 == 0) ? 2 : 1;
-      const int xs = cg_domp_up(tc * V, 16);
-      const size_t bytes = ((size_t)(g.CinR + 16) * xs + g.zfl + g.yfl + 16 * (size_t)g.WS) * sizeof(float);
-      if (bytes > limit || (g.CinR / 16) * (xs / 16) > CG_DOMPB_NDX * CG_DOMPB_NW) continue;
+      const int xs = cg_domp_xs(tc * V);
+      const size_t bytes = ((size_t)(g.CinR + 16) * xs + g.zfl + g.yfl + 16 * (size_t)g.WS + CG_DOMPB_NW * 256 + 64) * sizeof(float);
+      if (bytes > limit || (g.CinR / 16) * ((tc * V + 15) / 16) > CG_DOMPB_NDX * CG_DOMPB_NW || tc * V > 128 * al) continue;      // x piece: two vectors per lane and plane row
       if (al > best_al) { best = tc; best_al = al; }
     }
     if (best) {
       g.NTC = ntc; g.TC = best; g.VWP = best_al;
-      g.XS = cg_domp_up(best * V, 16);
-      g.bwd_floats = (g.CinR + 16) * g.XS + g.zfl + g.yfl + 16 * g.WS;
+      g.XS = cg_domp_xs(best * V);
+      g.bwd_floats = (g.CinR + 16) * g.XS + g.zfl + g.yfl + 16 * g.WS + CG_DOMPB_NW * 256 + 64;
       const int lastq = T - 16 * ((T + 15) / 16 - 1);
       g.VWY = (g.TV % 4 == 0 && (lastq * V) % 4 == 0) ? 4 : (g.TV % 2 == 0 && (lastq * V) % 2 == 0) ? 2 : 1;
       g.VWA = T % 4 == 0 ? 4 : T % 2 == 0 ? 2 : 1;
@@ -659,18 +819,19 @@ int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const f
   const int njw = (V + CG_DOMPB_NW - 1) / CG_DOMPB_NW;
   dim3 grid((unsigned)(8 * ((B + 7) / 8) * g.NTC)), block(CG_DOMPB_THREADS);
   const int pfn = (16 * V / g.VWY + 31) / 32;          // vectors per thread of one dY piece
-  if (g.zfl + g.yfl < CG_DOMPB_NW * CG_DOMPB_NOC * 256) return CG_ESHAPE;       // hand-over buffer of the dW slices
-#define CG_DOMP_BWD(VWP_, VWY_, VWA_, NJW_, PF_)                                                                                   \
-  if (g.VWP == VWP_ && g.VWY == VWY_ && g.VWA == VWA_ && njw <= NJW_ && pfn <= PF_) {                                             \
-    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_>,                      \
+  if (CG_DOMPB_NW % (g.CinR / 16) != 0 || 16 * g.WS > 3 * CG_DOMPB_THREADS) return CG_ESHAPE;      // a wave keeps one channel tile of dx; weight chunk in three registers per thread
+  const int ndxw = ((g.CinR / 16) * ((g.TC * V + 15) / 16) + CG_DOMPB_NW - 1) / CG_DOMPB_NW;      // dx tiles per wave
+#define CG_DOMP_BWD(VWP_, VWY_, VWA_, NJW_, PF_, NDX_)                                                                             \
+  if (g.VWP == VWP_ && g.VWY == VWY_ && g.VWA == VWA_ && njw <= NJW_ && pfn <= PF_ && ndxw <= NDX_) {                             \
+    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_, NDX_>,                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
     if (e != hipSuccess) return (int)e;                                                                                            \
-    hipLaunchKernelGGL((cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_>), grid, block, lds, stream, x, adj, W, dy, dx,    \
-                       dadj, ws, replicas, g);                                                                                     \
+    hipLaunchKernelGGL((cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_, NDX_>), grid, block, lds, stream, x, adj, W, dy,  \
+                       dx, dadj, ws, replicas, g);                                                                                 \
     return cg_launch_status();                                                                                                     \
   }
-  CG_DOMP_BWD(4, 4, 2, 3, 3)      // T*V % 4 == 0, T even, V <= 24  (H3.6M 22 joints, AMASS 18)
-  CG_DOMP_BWD(2, 2, 2, 4, 7)      // V = 25
+  CG_DOMP_BWD(4, 4, 2, 3, 3, 10)     // T*V % 4 == 0, T even, V <= 24  (H3.6M 22 joints, AMASS 18), up to 64 input channels
+  CG_DOMP_BWD(2, 2, 2, 4, 7, 6)      // V = 25, up to 32 input channels
 #undef CG_DOMP_BWD
   return CG_ESHAPE;
 }

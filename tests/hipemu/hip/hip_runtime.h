@@ -27,6 +27,7 @@ extern dim3 blockIdx, blockDim, gridDim;
 
 #define CG_OPAQUE_V(x) ((void)(x))
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // only ever applied to wave-uniform values
 struct float2 { float x, y; } __attribute__((aligned(8)));
 #define __global__
 #define __device__
