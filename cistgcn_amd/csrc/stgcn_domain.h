@@ -42,5 +42,7 @@ struct CgDomP {
 int cg_domp_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V, int domain);
 int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
                        int replicas, int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);
+int cg_domp_bwd_time_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
+                            int replicas, int B, int Cin, int Cout, int T, int V, hipStream_t stream);
 int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                        int B, int Cin, int Cout, int T, int V, int domain, hipStream_t stream);

@@ -29,6 +29,11 @@ static const char* cg_dom_env(const char* name) {
   static const bool ablation = getenv("CISTGCN_ABLATION") != nullptr;
   return ablation ? getenv(name) : nullptr;
 }
+// grid size from which the plane kernels fill the chip (CG_DOM_PLANES_MIN_WGS overrides it in ablation / test runs)
+static long long cg_dom_planes_min_wgs() {
+  const char* e = cg_dom_env("CG_DOM_PLANES_MIN_WGS");
+  return e ? atoll(e) : 256;
+}
 
 struct CgDomainGeom {
   int B, Cin, Cout, T, V;
@@ -602,7 +607,7 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   // wide layers, third generation: plane kernels (stgcn_domain_planes.hip) - whole plane rows in HBM, LDS as the transposer
   // (a grid of fewer than 256 workgroups - small batches - leaves most CUs idle: the tile kernels split a sample finer; the
   // time-domain variant for odd V reads its slabs one float per lane and measured no faster than the tile kernel)
-  if ((Cin >= 16 || Cout >= 16) && (long long)B * ((Cout + 15) / 16) >= 256 && !(domain == 1 && (V & 1)) &&
+  if ((Cin >= 16 || Cout >= 16) && (long long)B * ((Cout + 15) / 16) >= cg_dom_planes_min_wgs() && !(domain == 1 && (V & 1)) &&
       cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
     st = cg_domp_fwd_launch(x, adj, W, bias, y, ystats, B, Cin, Cout, T, V, domain, (hipStream_t)stream_);
     if (st != CG_ESHAPE) return st;
@@ -671,8 +676,18 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   // wide layers, space domain: plane backward (stgcn_domain_planes.hip)
   // (narrow inputs: the channel-mix-first order makes the graph products as wide as the OUTPUT, the tile kernels keep them
   // as wide as the input - 229 vs 279 us at 10 -> 64; small batches: as in the forward)
-  if (Cin >= 16 && domain == 0 && (long long)B * ((T + 15) / 16) >= 256 && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+  if (Cin >= 16 && domain == 0 && (long long)B * ((T + 15) / 16) >= cg_dom_planes_min_wgs() && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
     st = cg_domp_bwd_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, domain, stream);
+    if (st != CG_ESHAPE) {
+      if (st != CG_OK) return st;
+      hipLaunchKernelGGL(cg_dom_fold_replicas_kernel, dim3((unsigned)((n_w + n_b + 255) / 256)), dim3(256), 0, stream, ws, CG_DOM_REPLICAS,
+                         n_w, n_b, dW, dbias);
+      return cg_launch_status();
+    }
+  }
+  // wide layers, time domain: local plane backward (a chunk of frames per workgroup)
+  if (Cin >= 16 && domain == 1 && (long long)B * ((T + 7) / 8) >= cg_dom_planes_min_wgs() && cg_dom_env("CG_DOM_NO_PLANES") == nullptr) {
+    st = cg_domp_bwd_time_launch(x, adj, W, dy, dx, dadj, ws, CG_DOM_REPLICAS, B, Cin, Cout, T, V, stream);
     if (st != CG_ESHAPE) {
       if (st != CG_OK) return st;
       hipLaunchKernelGGL(cg_dom_fold_replicas_kernel, dim3((unsigned)((n_w + n_b + 255) / 256)), dim3(256), 0, stream, ws, CG_DOM_REPLICAS,

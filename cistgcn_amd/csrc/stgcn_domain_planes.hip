@@ -769,6 +769,308 @@ int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const f
   return CG_ESHAPE;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, time domain (Adj (B,T,V,V), one V x V slab per frame)
+//
+//   dZ[o,t,v] = sum_w dY[o,t,w] A[t,v,w]        dA[t,v,w] = sum_o Z[o,t,v] dY[o,t,w]        dx = W^T dZ   dW = dZ x^T   db = sum dY
+// Frames are independent and a chunk of frames is a contiguous piece of every (T,V) plane, so a workgroup owns (sample b, chunk
+// of TC = 8 frames) and everything it touches is local: the pieces of x and dY ([channels][TC*V], whole plane rows) and Z = W . x
+// sit in LDS, one wave owns one frame for the two slab products (dZ_t replaces Z_t in place, no barrier inside the phase), and
+// dx / dW read dZ back as matrix-core operands.  Four barriers per workgroup.
+//   P1  Z[o,p]   = W . sX                       -> sZ[o][p]
+//   P2  per frame t (one wave):  dA_t = Z_t^T . dY_t  -> HBM;   dZ_t = dY_t . A_t^T  -> sZ (over Z_t);   db from the dY fragments
+//   P3  dx[c,p]  = W^T . sZ                     -> sDY (dY is dead) -> HBM as whole plane rows
+//       dW[o,c] += sZ . sX^T                    -> fp32 atomics into a replica of (dW, db)
+// ---------------------------------------------------------------------------------------------------------------------
+#define CG_DOMPT_THREADS 512
+#define CG_DOMPT_NW 8
+
+template <int VWP, int VWA>
+__global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_kernel(const float* __restrict__ x, const float* __restrict__ adj,
+                                                                       const float* __restrict__ W, const float* __restrict__ dy,
+                                                                       float* __restrict__ dx, float* __restrict__ dadj,
+                                                                       float* __restrict__ ws, int replicas, CgDomP g) {
+  const int T = g.T, V = g.V, Cin = g.Cin, Cout = g.Cout, XS = g.XS, WS = g.WS, CinR = g.CinR, CoR = 16 * g.NOC;
+  const int DR = max(CinR, CoR);                          // the dY image takes dx in P3
+  float* sX = reinterpret_cast<float*>(cg_dyn_lds);       // [CinR][XS]
+  float* sDY = sX + CinR * XS;                            // [DR][XS]
+  float* sZ = sDY + DR * XS;                              // [CoR][XS]
+  float* sW = sZ + CoR * XS;                              // [CoR][WS]
+  float* sdb = sW + CoR * WS;                             // [CoR]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int sb = sidx / g.NTC, tc = sidx - sb * g.NTC, b = sb * 8 + xcd;
+  if (b >= g.B) return;
+  const int t0 = tc * g.TC, TCn = min(g.TC, T - t0), Pn = TCn * V, NPT = (Pn + 15) / 16;
+  const long long TV = g.TV;
+  const int MTc = CinR / 16, MTo = g.NOC;
+
+  // P0: pieces of x and dY (two planes per wave and round, every request of a round in flight before the first LDS store), W
+  {
+    const int nvp = Pn / VWP;            // vectors per plane row (<= 64: one per lane)
+    for (int e = tid; e < (CinR + DR + CoR) * XS + CoR * (WS + 1); e += CG_DOMPT_THREADS) sX[e] = 0.f;
+    __syncthreads();
+    const float* xb = x + (long long)b * Cin * TV + (long long)t0 * V;
+    const float* yb = dy + (long long)b * Cout * TV + (long long)t0 * V;
+    const int rows = Cin + Cout;
+    for (int r0 = 8 * wave; r0 < rows; r0 += 8 * CG_DOMPT_NW) {
+      float buf[8][VWP];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        const float* src = r < Cin ? xb + (long long)r * TV : yb + (long long)(r - Cin) * TV;
+        cg_domp_ld<VWP>(src + lane * VWP, r < rows && lane < nvp, buf[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        float* dst = r < Cin ? sX + r * XS : sDY + (r - Cin) * XS;
+        if (r < rows && lane < nvp) {                 // (the row stride is == 2 mod 4: no vector stores)
+#pragma unroll
+          for (int jj = 0; jj < VWP; ++jj) dst[lane * VWP + jj] = buf[u][jj];
+        }
+      }
+    }
+    for (int e = tid; e < Cout * Cin; e += CG_DOMPT_THREADS) {
+      const int o = e / Cin, c = e - o * Cin;
+      sW[o * WS + c] = W[e];
+    }
+  }
+  __syncthreads();
+
+  // P1: Z = W . sX, units of (two channel tiles, one position tile)
+  {
+    const int OP = (MTo + 1) / 2, nun = OP * NPT;
+    for (int u = wave; u < nun; u += CG_DOMPT_NW) {
+      const int pt = u / OP, op = u - pt * OP, ot0 = 2 * op, ot1 = ot0 + 1 < MTo ? ot0 + 1 : ot0;
+      cg_f32x4 a0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const float* ap0 = sW + (16 * ot0 + l15) * WS + slot;
+      const float* ap1 = sW + (16 * ot1 + l15) * WS + slot;
+      const float* bp = sX + slot * XS + 16 * pt + l15;
+      float f0[12], f1[12];
+      auto ld = [&](int k0, float (&f)[12]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { f[s2] = ap0[4 * (k0 + s2)]; f[4 + s2] = ap1[4 * (k0 + s2)]; f[8 + s2] = bp[4 * (k0 + s2) * XS]; }
+      };
+      auto mm = [&](const float (&f)[12]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[4 + s2], f[8 + s2], a1, 0, 0, 0);
+        }
+      };
+      const int KS4 = CinR / 4;                       // steps, multiple of 4 (rows of sX beyond Cin are zero)
+      ld(0, f0);
+      for (int k0 = 0; k0 < KS4; k0 += 8) {
+        if (k0 + 4 < KS4) ld(k0 + 4, f1);
+        mm(f0);
+        if (k0 + 4 < KS4) {
+          if (k0 + 8 < KS4) ld(k0 + 8, f0);
+          mm(f1);
+        }
+      }
+      if (16 * pt + l15 < Pn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sZ[(16 * ot0 + 4 * slot + r) * XS + 16 * pt + l15] = a0[r];
+          if (ot1 != ot0) sZ[(16 * ot1 + 4 * slot + r) * XS + 16 * pt + l15] = a1[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // P2: one wave per frame
+  for (int tl = wave; tl < TCn; tl += CG_DOMPT_NW) {
+    const int pb = tl * V;                            // first position of the frame inside the pieces
+    const int NVT = (V + 15) / 16;                    // 1 or 2 tiles of joints
+    // dA_t[v, w] = sum_o Z[o, pb + v] dY[o, pb + w]
+    {
+      cg_f32x4 acc[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* zp = sZ + slot * XS + pb + l15;
+      const float* yp = sDY + slot * XS + pb + l15;
+      for (int st = 0; st < CoR / 4; ++st) {
+        float zv[2], yv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { zv[i] = zp[4 * st * XS + 16 * i]; yv[i] = yp[4 * st * XS + 16 * i]; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (i < NVT && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], yv[j], acc[i][j], 0, 0, 0);
+      }
+      float* da = dadj + (((long long)b * T + t0 + tl) * V) * V;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int w = 16 * j + l15;
+          if (i < NVT && j < NVT && w < V) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int v = 16 * i + 4 * slot + r;
+              if (v < V) da[v * V + w] = acc[i][j][r];
+            }
+          }
+        }
+    }
+    // dZ_t[o, v] = sum_w dY[o, pb + w] A_t[v, w]; inside a chunk of 16 columns step s takes w = 16 kc + 4 slot + s on both operands
+    {
+      cg_f32x4 acc[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      float dbp[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* at = adj + (((long long)b * T + t0 + tl) * V) * V;
+      for (int kc = 0; kc < NVT; ++kc) {
+        const int w0 = 16 * kc + 4 * slot;
+        float bv[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int v = 16 * j + l15;
+#pragma unroll
+          for (int s0 = 0; s0 < 4; s0 += VWA) {
+            float tmp[VWA];
+            cg_domp_ld<VWA>(at + v * V + w0 + s0, j < NVT && v < V && w0 + s0 < V, tmp);
+#pragma unroll
+            for (int q = 0; q < VWA; ++q) bv[j][s0 + q] = tmp[q];
+          }
+        }
+        float av[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) av[i][s2] = (i < MTo && w0 + s2 < V) ? sDY[(16 * i + l15) * XS + pb + w0 + s2] : 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dbp[i] += av[i][s2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (i < MTo && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s2], bv[j][s2], acc[i][j], 0, 0, 0);
+          }
+      }
+      // every read of Z_t by this wave is behind us: dZ_t goes in place
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int v = 16 * j + l15;
+          if (i < MTo && j < NVT && v < V) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sZ[(16 * i + 4 * slot + r) * XS + pb + v] = acc[i][j][r];
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sdbp = dbp[i];
+        sdbp += __shfl_xor(sdbp, 16, 64);
+        sdbp += __shfl_xor(sdbp, 32, 64);
+        if (i < MTo && slot == 0) atomicAdd(&sdb[16 * i + l15], sdbp);
+      }
+    }
+  }
+  __syncthreads();
+
+  // P3: dx -> sDY (dY is dead), dW -> atomics
+  {
+    const int CP = (MTc + 1) / 2, nun = CP * NPT;
+    for (int u = wave; u < nun; u += CG_DOMPT_NW) {
+      const int pt = u / CP, cp = u - pt * CP, ct0 = 2 * cp, ct1 = ct0 + 1 < MTc ? ct0 + 1 : ct0;
+      cg_f32x4 a0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const float* ap0 = sW + slot * WS + 16 * ct0 + l15;
+      const float* ap1 = sW + slot * WS + 16 * ct1 + l15;
+      const float* bp = sZ + slot * XS + 16 * pt + l15;
+      float f0[12], f1[12];
+      auto ld = [&](int k0, float (&f)[12]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) { f[s2] = ap0[4 * (k0 + s2) * WS]; f[4 + s2] = ap1[4 * (k0 + s2) * WS]; f[8 + s2] = bp[4 * (k0 + s2) * XS]; }
+      };
+      auto mm = [&](const float (&f)[12]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[4 + s2], f[8 + s2], a1, 0, 0, 0);
+        }
+      };
+      const int KS4 = CoR / 4;
+      ld(0, f0);
+      for (int k0 = 0; k0 < KS4; k0 += 8) {
+        if (k0 + 4 < KS4) ld(k0 + 4, f1);
+        mm(f0);
+        if (k0 + 4 < KS4) {
+          if (k0 + 8 < KS4) ld(k0 + 8, f0);
+          mm(f1);
+        }
+      }
+      if (16 * pt + l15 < Pn) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sDY[(16 * ct0 + 4 * slot + r) * XS + 16 * pt + l15] = a0[r];
+          if (ct1 != ct0) sDY[(16 * ct1 + 4 * slot + r) * XS + 16 * pt + l15] = a1[r];
+        }
+      }
+    }
+    // dW[o, c] = sum_p dZ[o, p] x[c, p]: tiles dealt to the waves, two at a time sharing the dZ fragments
+    float* wsr = ws + (long long)(blockIdx.x % replicas) * ((long long)Cout * Cin + Cout);
+    const int CP2 = (MTc + 1) / 2;
+    for (int u = wave; u < MTo * CP2; u += CG_DOMPT_NW) {
+      const int ot = u / CP2, cp = u - ot * CP2, ct0 = 2 * cp, ct1 = ct0 + 1 < MTc ? ct0 + 1 : ct0;
+      cg_f32x4 a0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const float* ap = sZ + (16 * ot + l15) * XS + 4 * slot;
+      const float* bp0 = sX + (16 * ct0 + l15) * XS + 4 * slot;
+      const float* bp1 = sX + (16 * ct1 + l15) * XS + 4 * slot;
+      for (int kc = 0; kc < NPT; ++kc) {
+        float av[4], b0[4], b1[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          const bool ok = 16 * kc + 4 * slot + s2 < Pn;      // beyond the piece the row stride wraps into the next row
+          av[s2] = ok ? ap[16 * kc + s2] : 0.f; b0[s2] = bp0[16 * kc + s2]; b1[s2] = bp1[16 * kc + s2];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], b0[s2], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], b1[s2], a1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = 16 * ot + 4 * slot + r;
+        if (co < Cout && 16 * ct0 + l15 < Cin) atomicAdd(&wsr[(long long)co * Cin + 16 * ct0 + l15], a0[r]);
+        if (ct1 != ct0 && co < Cout && 16 * ct1 + l15 < Cin) atomicAdd(&wsr[(long long)co * Cin + 16 * ct1 + l15], a1[r]);
+      }
+    }
+    if (tid < Cout) atomicAdd(&wsr[(long long)Cout * Cin + tid], sdb[tid]);
+  }
+  __syncthreads();
+  {
+    float* dxb = dx + (long long)b * Cin * TV + (long long)t0 * V;
+    const int nvp = Pn / VWP;
+    for (int r0 = 8 * wave; r0 < Cin; r0 += 8 * CG_DOMPT_NW) {
+      float buf[8][VWP];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r < Cin && lane < nvp) {
+#pragma unroll
+          for (int jj = 0; jj < VWP; ++jj) buf[u][jj] = sDY[r * XS + lane * VWP + jj];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + u;
+        if (r < Cin && lane < nvp) cg_domp_st<VWP>(dxb + ((long long)r * TV + lane * VWP), buf[u]);
+      }
+    }
+  }
+}
+
 // row stride of the x piece and of sdZ: == 4 (mod 8) floats, so that the 16 rows of a float4 fragment read (dW product) start in 16
 // different 4-bank groups; tiles that reach beyond the chunk's positions wrap into the next row and are masked where that matters
 static int cg_domp_xs(int p) { int xs = cg_domp_up(p, 4); return (xs % 8 == 4) ? xs : xs + 4; }
@@ -833,5 +1135,43 @@ int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const f
   CG_DOMP_BWD(4, 4, 2, 3, 3, 10)     // T*V % 4 == 0, T even, V <= 24  (H3.6M 22 joints, AMASS 18), up to 64 input channels
   CG_DOMP_BWD(2, 2, 2, 4, 7, 6)      // V = 25, up to 32 input channels
 #undef CG_DOMP_BWD
+  return CG_ESHAPE;
+}
+
+// backward of the time domain: frames per chunk and LDS image
+int cg_domp_bwd_time_launch(const float* x, const float* adj, const float* W, const float* dy, float* dx, float* dadj, float* ws,
+                            int replicas, int B, int Cin, int Cout, int T, int V, hipStream_t stream) {
+  CgDomP g;
+  int st = cg_domp_geom(g, B, Cin, Cout, T, V, 1);
+  if (st != CG_OK) return st;
+  if (Cin > 64 || Cout > 64 || V > 32) return CG_ESHAPE;            // four channel tiles, two joint tiles per frame
+  g.CinR = cg_domp_up(Cin, 16);
+  const int CoR = 16 * g.NOC;
+  g.WS = cg_domp_up(g.CinR, 4) + 2;
+  g.TC = CG_DOMPT_NW;                                               // one frame per wave
+  if (g.TC > T) g.TC = T;
+  g.NTC = (T + g.TC - 1) / g.TC;
+  const int last = T - (g.NTC - 1) * g.TC;
+  g.VWP = ((g.TC * V) % 4 == 0 && (last * V) % 4 == 0 && g.TV % 4 == 0) ? 4 : ((g.TC * V) % 2 == 0 && (last * V) % 2 == 0 && g.TV % 2 == 0) ? 2 : 1;
+  if (g.TC * V > 64 * g.VWP) return CG_ESHAPE;                      // one vector per lane and plane row
+  g.VWA = V % 4 == 0 ? 4 : V % 2 == 0 ? 2 : 1;
+  g.XS = g.TC * V + ((2 - g.TC * V) & 3);                           // == 2 (mod 4): see JS
+  if (g.XS < cg_domp_up(g.TC * V, 16)) g.XS += 4 * ((cg_domp_up(g.TC * V, 16) - g.XS + 3) / 4);   // tiles reach up to a multiple of 16 positions
+  g.bwd_floats = (g.CinR + (g.CinR > CoR ? g.CinR : CoR) + CoR) * g.XS + CoR * (g.WS + 1) + 64;
+  const size_t lds = (size_t)g.bwd_floats * sizeof(float);
+  if (lds > 160 * 1024 - 512) return CG_ESHAPE;
+  dim3 grid((unsigned)(8 * ((B + 7) / 8) * g.NTC)), block(CG_DOMPT_THREADS);
+#define CG_DOMP_BWDT(VWP_, VWA_)                                                                                                   \
+  if (g.VWP == VWP_ && g.VWA == VWA_) {                                                                                            \
+    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_time_kernel<VWP_, VWA_>,                                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    if (e != hipSuccess) return (int)e;                                                                                            \
+    hipLaunchKernelGGL((cg_stgcn_planes_bwd_time_kernel<VWP_, VWA_>), grid, block, lds, stream, x, adj, W, dy, dx, dadj, ws,       \
+                       replicas, g);                                                                                               \
+    return cg_launch_status();                                                                                                     \
+  }
+  CG_DOMP_BWDT(4, 2)      // V = 22 / 18
+  CG_DOMP_BWDT(2, 1)      // V = 25
+#undef CG_DOMP_BWDT
   return CG_ESHAPE;
 }
