@@ -158,6 +158,7 @@ _SIGNATURES = {
     "cg_stgcn_domain_fwd": [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cg_stgcn_domain_bwd": [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "cg_stgcn_domain_bwd_ws_floats": [c_int, c_int],
+    "cg_stgcn_domain_planes_min_workgroups": [c_longlong],
     "cg_multi_copy": [P, P, P, P, P, c_int, P, c_int, c_float, P],
     "cg_scale": [P, LL, c_float, P],
     "cg_dstd_tail_fwd": [POINTER(DstdTail), c_int, P],
@@ -189,7 +190,7 @@ def declare(handle):
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(handle, name)     # AttributeError if the library does not export it
         fn.argtypes = argtypes
-        fn.restype = c_longlong if name.endswith(("_floats", "_doubles")) else c_int
+        fn.restype = c_longlong if name.endswith(("_floats", "_doubles", "_workgroups")) else c_int
     return handle
 
 

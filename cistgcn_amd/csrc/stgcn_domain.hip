@@ -29,10 +29,13 @@ static const char* cg_dom_env(const char* name) {
   static const bool ablation = getenv("CISTGCN_ABLATION") != nullptr;
   return ablation ? getenv(name) : nullptr;
 }
-// grid size from which the plane kernels fill the chip (CG_DOM_PLANES_MIN_WGS overrides it in ablation / test runs)
-static long long cg_dom_planes_min_wgs() {
-  const char* e = cg_dom_env("CG_DOM_PLANES_MIN_WGS");
-  return e ? atoll(e) : 256;
+// grid size from which the plane kernels fill the chip
+static long long cg_dom_planes_min = 256;
+static long long cg_dom_planes_min_wgs() { return cg_dom_planes_min; }
+extern "C" long long cg_stgcn_domain_planes_min_workgroups(long long n) {
+  const long long prev = cg_dom_planes_min;
+  if (n >= 0) cg_dom_planes_min = n;
+  return prev;
 }
 
 struct CgDomainGeom {

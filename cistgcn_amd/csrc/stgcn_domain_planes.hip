@@ -337,7 +337,17 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
       }
     };
     x_load(4 * wave);
-    for (int e = tid; e < g.bwd_floats; e += CG_DOMPB_THREADS) sX[e] = 0.f;
+    // zeroed once: the pad columns [Pn, XS) of sX and sdZ and the channel rows beyond Cin (operands of the dW product and of
+    // tiles that reach beyond the piece), sZ (frames beyond the chunk stay zero), sY (frames beyond T must stay finite)
+    {
+      const int padc = XS - Pn, nrow = g.CinR + 16;
+      for (int e = tid; e < nrow * padc; e += CG_DOMPB_THREADS) {
+        const int r = e / padc, c = e - r * padc;
+        sX[r * XS + Pn + c] = 0.f;
+      }
+      for (int e = tid; e < (g.CinR - Cin) * Pn; e += CG_DOMPB_THREADS) sX[(Cin + e / Pn) * XS + e % Pn] = 0.f;
+      for (int e = tid; e < g.zfl + g.yfl + 16 * WS + CG_DOMPB_NW * 256 + 64; e += CG_DOMPB_THREADS) sZ[e] = 0.f;
+    }
     __syncthreads();
     CG_STAMP();                                       // 2: LDS zeroed
     for (int c0 = 4 * wave; c0 < Cin; c0 += 4 * CG_DOMPB_NW) {
@@ -516,7 +526,6 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
       {
         if (qc + 1 < NQC) piece_load(oc, qc + 1);
         else if (oc + 1 < g.NOC) piece_load(oc + 1, 0);
-        CG_STAMP();                                   // fine: piece_load issued
         // S4
         const int q0 = 16 * qc;
         CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
@@ -544,7 +553,6 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
 #pragma unroll
               for (int a = 0; a < NJW; ++a) part[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(za[a][st], ya[a][st], part[a], 0, 0, 0);
           }
-          CG_STAMP();                                 // fine: dA issued
           {
             float yb[NJW][4];
             const int sw = cg_domp_swz(l15);
@@ -563,14 +571,12 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
                 dbp += (q0 + 4 * slot + st < T && wave + CG_DOMPB_NW * a < V) ? yb[a][st] : 0.f;
               }
           }
-          CG_STAMP();                                 // fine: dZ issued
 #pragma unroll
           for (int a = 0; a < NJW; ++a)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               if (qc == k) dAacc[a][k] += part[a];    // register tiles need compile-time indices
         }
-        CG_STAMP();                                   // fine: accumulated
         // slab rows of the next piece: requested behind the dY piece (vmcnt retires in order: the piece is waited for first, by
         // piece_store, and these rows are not needed before the next S4 has done its dA products)
         rows_load(qc + 1 < NQC ? qc + 1 : 0, ar);
@@ -805,30 +811,40 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
   const long long TV = g.TV;
   const int MTc = CinR / 16, MTo = g.NOC;
 
-  // P0: pieces of x and dY (two planes per wave and round, every request of a round in flight before the first LDS store), W
+  int nst = 0; (void)nst;
+  CG_STAMP();
+  // P0: pieces of x and dY: a wave owns 16 plane rows, all of their requests are in flight while the pads of the LDS image are
+  // zeroed (columns beyond the piece, rows beyond the channel counts, the weight image); one vector per lane and plane row
   {
-    const int nvp = Pn / VWP;            // vectors per plane row (<= 64: one per lane)
-    for (int e = tid; e < (CinR + DR + CoR) * XS + CoR * (WS + 1); e += CG_DOMPT_THREADS) sX[e] = 0.f;
-    __syncthreads();
+    const int nvp = Pn / VWP;            // vectors per plane row (<= 64)
     const float* xb = x + (long long)b * Cin * TV + (long long)t0 * V;
     const float* yb = dy + (long long)b * Cout * TV + (long long)t0 * V;
     const int rows = Cin + Cout;
-    for (int r0 = 8 * wave; r0 < rows; r0 += 8 * CG_DOMPT_NW) {
-      float buf[8][VWP];
+    float buf[16][VWP];
+    const int r0 = 16 * wave;                        // rows <= 128 = 16 rows x 8 waves
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + u;
-        const float* src = r < Cin ? xb + (long long)r * TV : yb + (long long)(r - Cin) * TV;
-        cg_domp_ld<VWP>(src + lane * VWP, r < rows && lane < nvp, buf[u]);
-      }
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + u;
+      const float* src = r < Cin ? xb + (long long)r * TV : yb + (long long)(r - Cin) * TV;
+      cg_domp_ld<VWP>(src + lane * VWP, r < rows && lane < nvp, buf[u]);
+    }
+    const int padc = XS - Pn, nrow = CinR + DR + CoR;
+    for (int e = tid; e < nrow * padc; e += CG_DOMPT_THREADS) {
+      const int r = e / padc, c = e - r * padc;
+      sX[r * XS + Pn + c] = 0.f;
+    }
+    for (int e = tid; e < (CinR - Cin) * Pn; e += CG_DOMPT_THREADS) sX[Cin * XS + (e / Pn) * XS + e % Pn] = 0.f;
+    for (int e = tid; e < (DR - Cout) * Pn; e += CG_DOMPT_THREADS) sDY[Cout * XS + (e / Pn) * XS + e % Pn] = 0.f;
+    for (int e = tid; e < CoR * (WS + 1); e += CG_DOMPT_THREADS) sW[e] = 0.f;
+    __syncthreads();
+    CG_STAMP();
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + u;
-        float* dst = r < Cin ? sX + r * XS : sDY + (r - Cin) * XS;
-        if (r < rows && lane < nvp) {                 // (the row stride is == 2 mod 4: no vector stores)
+    for (int u = 0; u < 16; ++u) {
+      const int r = r0 + u;
+      float* dst = r < Cin ? sX + r * XS : sDY + (r - Cin) * XS;
+      if (r < rows && lane < nvp) {                   // (the row stride is == 2 mod 4: no vector stores)
 #pragma unroll
-          for (int jj = 0; jj < VWP; ++jj) dst[lane * VWP + jj] = buf[u][jj];
-        }
+        for (int jj = 0; jj < VWP; ++jj) dst[lane * VWP + jj] = buf[u][jj];
       }
     }
     for (int e = tid; e < Cout * Cin; e += CG_DOMPT_THREADS) {
@@ -836,7 +852,9 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
       sW[o * WS + c] = W[e];
     }
   }
+  CG_STAMP();
   __syncthreads();
+  CG_STAMP();
 
   // P1: Z = W . sX, units of (two channel tiles, one position tile)
   {
@@ -878,12 +896,30 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
       }
     }
   }
+  CG_STAMP();
   __syncthreads();
+  CG_STAMP();
 
   // P2: one wave per frame
   for (int tl = wave; tl < TCn; tl += CG_DOMPT_NW) {
     const int pb = tl * V;                            // first position of the frame inside the pieces
     const int NVT = (V + 15) / 16;                    // 1 or 2 tiles of joints
+    // slab rows of the frame for the dZ product, requested before the dA product runs
+    const float* at = adj + (((long long)b * T + t0 + tl) * V) * V;
+    float bv[2][2][4];                               // [chunk of 16 columns w][tile of joints v][step]
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int v = 16 * j + l15, w0 = 16 * kc + 4 * slot;
+#pragma unroll
+        for (int s0 = 0; s0 < 4; s0 += VWA) {
+          float tmp[VWA];
+          cg_domp_ld<VWA>(at + v * V + w0 + s0, kc < NVT && j < NVT && v < V && w0 + s0 < V, tmp);
+#pragma unroll
+          for (int q = 0; q < VWA; ++q) bv[kc][j][s0 + q] = tmp[q];
+        }
+      }
     // dA_t[v, w] = sum_o Z[o, pb + v] dY[o, pb + w]
     {
       cg_f32x4 acc[2][2];
@@ -893,15 +929,31 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
         for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
       const float* zp = sZ + slot * XS + pb + l15;
       const float* yp = sDY + slot * XS + pb + l15;
-      for (int st = 0; st < CoR / 4; ++st) {
-        float zv[2], yv[2];
+      float fa[16], fb[16];                           // four steps x (two Z tiles, two dY tiles)
+      auto ld = [&](int k0, float (&f)[16]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { zv[i] = zp[4 * st * XS + 16 * i]; yv[i] = yp[4 * st * XS + 16 * i]; }
+        for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) { f[4 * s2 + i] = zp[4 * (k0 + s2) * XS + 16 * i]; f[4 * s2 + 2 + i] = yp[4 * (k0 + s2) * XS + 16 * i]; }
+      };
+      auto mm = [&](const float (&f)[16]) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
-            if (i < NVT && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(zv[i], yv[j], acc[i][j], 0, 0, 0);
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              if (i < NVT && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[4 * s2 + i], f[4 * s2 + 2 + j], acc[i][j], 0, 0, 0);
+      };
+      const int KS4 = CoR / 4;
+      ld(0, fa);
+      for (int k0 = 0; k0 < KS4; k0 += 8) {
+        if (k0 + 4 < KS4) ld(k0 + 4, fb);
+        mm(fa);
+        if (k0 + 4 < KS4) {
+          if (k0 + 8 < KS4) ld(k0 + 8, fa);
+          mm(fb);
+        }
       }
       float* da = dadj + (((long long)b * T + t0 + tl) * V) * V;
 #pragma unroll
@@ -926,35 +978,25 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
       float dbp[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* at = adj + (((long long)b * T + t0 + tl) * V) * V;
-      for (int kc = 0; kc < NVT; ++kc) {
-        const int w0 = 16 * kc + 4 * slot;
-        float bv[2][4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int v = 16 * j + l15;
+      for (int kc = 0; kc < 2; ++kc) {
+        if (kc < NVT) {
+          const int w0 = 16 * kc + 4 * slot;
+          float av[4][4];
 #pragma unroll
-          for (int s0 = 0; s0 < 4; s0 += VWA) {
-            float tmp[VWA];
-            cg_domp_ld<VWA>(at + v * V + w0 + s0, j < NVT && v < V && w0 + s0 < V, tmp);
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int q = 0; q < VWA; ++q) bv[j][s0 + q] = tmp[q];
-          }
+            for (int s2 = 0; s2 < 4; ++s2) av[i][s2] = (i < MTo && w0 + s2 < V) ? sDY[(16 * i + l15) * XS + pb + w0 + s2] : 0.f;
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              dbp[i] += av[i][s2];
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                if (i < MTo && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s2], bv[kc][j][s2], acc[i][j], 0, 0, 0);
+            }
         }
-        float av[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int s2 = 0; s2 < 4; ++s2) av[i][s2] = (i < MTo && w0 + s2 < V) ? sDY[(16 * i + l15) * XS + pb + w0 + s2] : 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            dbp[i] += av[i][s2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (i < MTo && j < NVT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s2], bv[j][s2], acc[i][j], 0, 0, 0);
-          }
       }
       // every read of Z_t by this wave is behind us: dZ_t goes in place
 #pragma unroll
@@ -976,7 +1018,9 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
       }
     }
   }
+  CG_STAMP();
   __syncthreads();
+  CG_STAMP();
 
   // P3: dx -> sDY (dY is dead), dW -> atomics
   {
@@ -1026,17 +1070,28 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
       const float* ap = sZ + (16 * ot + l15) * XS + 4 * slot;
       const float* bp0 = sX + (16 * ct0 + l15) * XS + 4 * slot;
       const float* bp1 = sX + (16 * ct1 + l15) * XS + 4 * slot;
-      for (int kc = 0; kc < NPT; ++kc) {
-        float av[4], b0[4], b1[4];
+      float fa[12], fb[12];
+      auto ld = [&](int kc, float (&f)[12]) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           const bool ok = 16 * kc + 4 * slot + s2 < Pn;      // beyond the piece the row stride wraps into the next row
-          av[s2] = ok ? ap[16 * kc + s2] : 0.f; b0[s2] = bp0[16 * kc + s2]; b1[s2] = bp1[16 * kc + s2];
+          f[s2] = ok ? ap[16 * kc + s2] : 0.f; f[4 + s2] = bp0[16 * kc + s2]; f[8 + s2] = bp1[16 * kc + s2];
         }
+      };
+      auto mm = [&](const float (&f)[12]) {
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], b0[s2], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s2], b1[s2], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[4 + s2], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], a1, 0, 0, 0);
+        }
+      };
+      ld(0, fa);
+      for (int kc = 0; kc < NPT; kc += 2) {
+        if (kc + 1 < NPT) ld(kc + 1, fb);
+        mm(fa);
+        if (kc + 1 < NPT) {
+          if (kc + 2 < NPT) ld(kc + 2, fa);
+          mm(fb);
         }
       }
 #pragma unroll
@@ -1048,7 +1103,9 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
     }
     if (tid < Cout) atomicAdd(&wsr[(long long)Cout * Cin + tid], sdb[tid]);
   }
+  CG_STAMP();
   __syncthreads();
+  CG_STAMP();
   {
     float* dxb = dx + (long long)b * Cin * TV + (long long)t0 * V;
     const int nvp = Pn / VWP;
@@ -1069,6 +1126,8 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
       }
     }
   }
+  CG_STAMP();
+  CG_STAMP_END();
 }
 
 // row stride of the x piece and of sdZ: == 4 (mod 8) floats, so that the 16 rows of a float4 fragment read (dW product) start in 16
@@ -1153,7 +1212,7 @@ int cg_domp_bwd_time_launch(const float* x, const float* adj, const float* W, co
   g.NTC = (T + g.TC - 1) / g.TC;
   const int last = T - (g.NTC - 1) * g.TC;
   g.VWP = ((g.TC * V) % 4 == 0 && (last * V) % 4 == 0 && g.TV % 4 == 0) ? 4 : ((g.TC * V) % 2 == 0 && (last * V) % 2 == 0 && g.TV % 2 == 0) ? 2 : 1;
-  if (g.TC * V > 64 * g.VWP) return CG_ESHAPE;                      // one vector per lane and plane row
+  if (g.TC * V > 64 * g.VWP || Cin + Cout > 16 * CG_DOMPT_NW) return CG_ESHAPE;      // one vector per lane and plane row, 16 plane rows per wave
   g.VWA = V % 4 == 0 ? 4 : V % 2 == 0 ? 2 : 1;
   g.XS = g.TC * V + ((2 - g.TC * V) & 3);                           // == 2 (mod 4): see JS
   if (g.XS < cg_domp_up(g.TC * V, 16)) g.XS += 4 * ((cg_domp_up(g.TC * V, 16) - g.XS + 3) / 4);   // tiles reach up to a multiple of 16 positions

@@ -180,7 +180,12 @@ int cg_seed_bump(unsigned long long* seed, void* stream);
  * (ystats, [Cout][2], zero on entry) feed the train-mode BatchNorm that follows (:235).
  * Backward: dx, dAdj, dW, db from dy.  dW/db partial sums go through `ws`, a caller-owned scratch of
  * cg_stgcn_domain_bwd_ws_floats(Cin, Cout) floats (zeroed here unless ws_prezeroed != 0; replicated accumulators
- * keep the fp32 atomics off a single address), and are folded into dW/db by a second tiny kernel. */
+ * keep the fp32 atomics off a single address), and are folded into dW/db by a second tiny kernel.
+ * Wide layers (16+ channels) at batch sizes that fill the chip run as plane kernels (csrc/stgcn_domain_planes.hip: the channel
+ * mix first, on whole plane rows; LDS transposes to the group-major order of the graph product); smaller launches use the tile
+ * kernels.  cg_stgcn_domain_planes_min_workgroups(n) moves that switch (n workgroups; returns the previous value, n < 0 only
+ * reads it): both generations compute the same function, tests pin either one. */
+long long cg_stgcn_domain_planes_min_workgroups(long long n);
 int cg_stgcn_domain_fwd(const float* x, const float* adj, const float* W, const float* bias, float* y, double* ystats,
                         int B, int Cin, int Cout, int T, int V, int domain, void* stream);
 long long cg_stgcn_domain_bwd_ws_floats(int Cin, int Cout);

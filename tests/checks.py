@@ -544,23 +544,36 @@ def check_stage_kernels(device):
     assert_close(pd.grad, pr.grad, "mpjpe grad", rel=1e-5, floor=float(pr.grad.abs().max()))
 
 
-def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22), (2, 64, 64, 10, 22), (2, 32, 10, 50, 25), (100, 3, 3, 45, 4), (128, 20, 24, 40, 6))):
+def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 3, 3, 22, 25), (2, 8, 10, 50, 22), (2, 64, 64, 10, 22), (2, 32, 10, 50, 25), (100, 3, 3, 45, 4), (128, 20, 24, 40, 6)),
+                       planes=False):
+    """planes=True pins the plane kernels (csrc/stgcn_domain_planes.hip) at any batch size; the default switch would send the
+    small test batches to the tile kernels."""
+    from cistgcn_amd import _lib
     g = _gen(7)
-    for (B, Cin, Cout, T, V) in shapes:
-        for domain in (0, 1):
-            x = _rand(g, B, Cin, T, V)
-            adj = _rand(g, B, V, T, T, scale=0.3) if domain == 0 else _rand(g, B, T, V, V, scale=0.3)
-            w, bias = _rand(g, Cout, Cin, scale=0.3), _rand(g, Cout)
-            spec = "bctv,bvtq->bcqv" if domain == 0 else "bctv,btvw->bctw"
-            what = "stgcn_domain B%d Cin%d Cout%d T%d V%d dom%d" % (B, Cin, Cout, T, V, domain)
-            _run(lambda x_, a_, w_, b_: ops.stgcn_domain(x_, a_, w_, b_, domain)[0],
-                 lambda x_, a_, w_, b_: torch.einsum("oc,bchw->bohw", w_, torch.einsum(spec, x_, a_)) + b_.view(1, -1, 1, 1),
-                 [x, adj, w, bias], device, rel=5e-5, what=what)
-            ops.begin_step(device)
-            y, st = ops.stgcn_domain(x.to(device), adj.to(device), w.to(device), bias.to(device), domain, want_stats=True)
-            yc = y.detach().cpu().double()
-            ref = torch.stack((yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3))), 1).reshape(-1)
-            assert_close(_chan_sums(st), ref, what + " channel sums", rel=1e-6)
+    prev = _lib.lib().cg_stgcn_domain_planes_min_workgroups(1 if planes else -1)
+    try:
+        for (B, Cin, Cout, T, V) in shapes:
+            for domain in (0, 1):
+                x = _rand(g, B, Cin, T, V)
+                adj = _rand(g, B, V, T, T, scale=0.3) if domain == 0 else _rand(g, B, T, V, V, scale=0.3)
+                w, bias = _rand(g, Cout, Cin, scale=0.3), _rand(g, Cout)
+                spec = "bctv,bvtq->bcqv" if domain == 0 else "bctv,btvw->bctw"
+                what = "stgcn_domain B%d Cin%d Cout%d T%d V%d dom%d%s" % (B, Cin, Cout, T, V, domain, " planes" if planes else "")
+                _run(lambda x_, a_, w_, b_: ops.stgcn_domain(x_, a_, w_, b_, domain)[0],
+                     lambda x_, a_, w_, b_: torch.einsum("oc,bchw->bohw", w_, torch.einsum(spec, x_, a_)) + b_.view(1, -1, 1, 1),
+                     [x, adj, w, bias], device, rel=5e-5, what=what)
+                ops.begin_step(device)
+                y, st = ops.stgcn_domain(x.to(device), adj.to(device), w.to(device), bias.to(device), domain, want_stats=True)
+                yc = y.detach().cpu().double()
+                ref = torch.stack((yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3))), 1).reshape(-1)
+                assert_close(_chan_sums(st), ref, what + " channel sums", rel=1e-6)
+    finally:
+        _lib.lib().cg_stgcn_domain_planes_min_workgroups(prev)
+
+
+# shapes that reach every instantiation of the plane kernels: (T, V) families 50x22 / 10x22 / 50x25 / 10x18, channel counts that
+# are not multiples of 16, a batch that does not fill the last group of 8 samples
+PLANE_SHAPES = ((2, 64, 64, 50, 22), (9, 64, 10, 50, 22), (2, 10, 64, 10, 22), (3, 32, 32, 50, 25), (2, 32, 16, 10, 18), (2, 16, 48, 10, 25))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -35,3 +35,9 @@ def test_operator(check):
 
 def test_stgcn_domain_small():
     checks.check_stgcn_domain("cpu", shapes=((3, 10, 8, 5, 7), (2, 3, 3, 6, 9), (2, 18, 16, 5, 7)))
+
+
+def test_stgcn_domain_planes():
+    """plane kernels of the fused ST-GCN stage (forward both domains, both backward kernels) on small instances of every
+    instantiated (T, V) family; the full PLANE_SHAPES list runs on the MI355X"""
+    checks.check_stgcn_domain("cpu", shapes=((2, 16, 16, 10, 22), (3, 16, 10, 50, 22), (2, 16, 16, 50, 25), (2, 32, 16, 10, 18)), planes=True)

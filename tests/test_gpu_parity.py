@@ -27,6 +27,13 @@ def test_operator(check):
     check("cuda")
 
 
+def test_stgcn_domain_plane_kernels():
+    """the plane generation of the fused ST-GCN stage pinned at test batch sizes (its default switch is 256 workgroups), on every
+    instantiated (T, V) family, against einsum on the CPU: forward, channel sums, dx, dAdj, dW, db"""
+    checks.check_stgcn_domain("cuda", shapes=checks.PLANE_SHAPES, planes=True)
+    checks.check_stgcn_domain("cuda", shapes=((300, 64, 64, 50, 22),))          # default switch, a full chip of workgroups
+
+
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_model_matches_reference_golden(name, mode):

@@ -19,14 +19,15 @@ _lib.LIB_PATH = OUT
 from cistgcn_amd import ops
 h = _lib.lib()
 B, ci, co, T, V = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "256,64,64,50,22").split(",")]
-x = torch.randn(B, ci, T, V, device="cuda"); adj = torch.randn(B, V, T, T, device="cuda") * 0.1
+dom = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+x = torch.randn(B, ci, T, V, device="cuda"); adj = torch.randn((B, V, T, T) if dom == 0 else (B, T, V, V), device="cuda") * 0.1
 w = torch.randn(co, ci, device="cuda") * 0.1; dy = torch.randn(B, co, T, V, device="cuda")
 dx, dadj, dw, db = torch.empty_like(x), torch.empty_like(adj), torch.empty_like(w), torch.empty(co, device="cuda")
 ws = torch.zeros(int(h.cg_stgcn_domain_bwd_ws_floats(ci, co)), device="cuda")
-nblk = 8 * ((B + 7) // 8) * 8
+nblk = 8 * ((B + 7) // 8) * 8 * 2
 buf = torch.zeros(nblk * 256, dtype=torch.int64, device="cuda")
 p = ops._ptr
-run = lambda: _lib.call("cg_stgcn_domain_bwd", p(x), p(adj), p(w), p(dy), p(dx), p(dadj), p(dw), p(db), p(ws), B, ci, co, T, V, 0, 0, ops._stream(x))
+run = lambda: _lib.call("cg_stgcn_domain_bwd", p(x), p(adj), p(w), p(dy), p(dx), p(dadj), p(dw), p(db), p(ws), B, ci, co, T, V, dom, 0, ops._stream(x))
 for _ in range(3): run()
 torch.cuda.synchronize()
 h.cg_domp_set_stamps.argtypes = [ctypes.c_void_p]
