@@ -37,7 +37,7 @@ WORKLOADS = {
     "cistgcn64_b256_t10_v22": (64, 256, 10, 22),
     "cistgcn32_b256_t10_v18": (32, 256, 10, 18),  # reference AMASS joints
 }
-HEADLINE, SECONDARY = "cistgcn64_b256_t50_v22", "cistgcn8_b16_t50_v22"
+HEADLINE, SECONDARY, AMASS25 = "cistgcn64_b256_t50_v22", "cistgcn8_b16_t50_v22", "cistgcn32_b256_t50_v25"
 MIXED_BATCHES = (64, 128, 256, 512)   # configs[4]: per-GPU batch of rank r = MIXED_BATCHES[r % 4]
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3    # same guide: fp32 vector = fp32-input MFMA peak
@@ -83,6 +83,32 @@ def model_bytes_per_sequence(C, T, V, To=25):
 # live per-entry-point timing: HIP events (on the stream the library launches on) around every C-ABI call of one
 # eager training step, with the ALGORITHMIC bytes of each call computed from its arguments
 # ---------------------------------------------------------------------------------------------------------------------
+# Kernel families: forward AND backward entry points of one stage form one family everywhere (round-2 review: a stage split in two
+# next to stages counted whole made "the dominant family" an artefact of the grouping).  Each family names the device kernels
+# rocprofv3 reports for it, so profiles/*kernel_stats.csv can be summed the same way.
+FAM_STGCN = "fused ST-GCN stage (cg_stgcn_domain_fwd/bwd)"
+FAM_TAIL = "DSTD_GC tail phases (cg_dstd_tail_fwd/bwd)"
+FAM_CONTRACT = "contraction (cg_contract_many)"
+FAM_ADJ = "Map2Adj tail phases (cg_map2adj_tail_fwd/bwd)"
+FAM_ROWS = "row kernels (cg_norm_act_fwd/bwd, cg_chan_stats)"
+FAM_PWM = "stacked tower maps (cg_pointwise_maps_fwd/bwd)"
+FAM_ROWSCONV = "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)"
+FAM_FPN = "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)"
+FAM_STATS = "block statistics (cg_dstd_stats_fwd/bwd)"
+FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as rocprofv3 --kernel-trace reports them
+    FAM_STGCN: ("cg_stgcn_", "cg_dom_fold"),
+    FAM_TAIL: ("cg_tail_",),
+    FAM_CONTRACT: ("cg_contract",),
+    FAM_ADJ: ("cg_adj_",),
+    FAM_ROWS: ("cg_norm_act_", "cg_chan_stats"),
+    FAM_PWM: ("cg_pwm_",),
+    FAM_ROWSCONV: ("cg_rows_",),
+    FAM_FPN: ("cg_fpn_",),
+    FAM_STATS: ("cg_dstd_stats",),
+}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")      # HBM bytes per family from rocprofv3 PMC passes (tools/collect_profiles_r03.py)
+
+
 def _numel(v):
     return int(v.n[0]) * int(v.n[1]) * int(v.n[2]) * int(v.n[3])
 
@@ -96,7 +122,7 @@ def _call_bytes(name, args):
         for i in range(n):
             d = arr[i]
             total += 4 * (d.G * d.M * d.K + d.G * d.K * d.N + d.G * d.M * d.N)
-        return "contraction (cg_contract_many: tiled / streaming / K-reduction kernels)", total
+        return FAM_CONTRACT, total
     if name in ("cg_norm_act_fwd_many", "cg_norm_act_bwd_many"):
         arr, n = args[0], args[-2] if name.endswith("bwd_many") else args[1]
         total = 0
@@ -107,16 +133,16 @@ def _call_bytes(name, args):
                 total += 4 * e * (2 + (1 if a.add else 0))                      # x (+ add) -> y
             else:
                 total += 4 * e * (2 + (1 if a.dx else 0) + (1 if (a.add and not a.add_post) else 0) + (1 if a.dadd else 0))
-        return ("row kernels fwd (cg_norm_act_fwd)" if name.endswith("fwd_many") else "row kernels bwd (cg_norm_act_bwd reduce + apply)"), total
+        return FAM_ROWS, total
     if name == "cg_chan_stats_many":
-        return "row kernels fwd (cg_norm_act_fwd)", sum(4 * _numel(args[0][i].xv) for i in range(args[1]))
+        return FAM_ROWS, sum(4 * _numel(args[0][i].xv) for i in range(args[1]))
     if name in ("cg_stgcn_domain_fwd", "cg_stgcn_domain_bwd"):
         B, ci, co, T, V, dom = args[-7:-1] if name.endswith("fwd") else args[-8:-2]
         ng, j = (V, T) if dom == 0 else (T, V)
         x, y, adj = B * ci * T * V, B * co * T * V, B * ng * j * j
         if name.endswith("fwd"):
-            return "fused ST-GCN stage fwd (cg_stgcn_domain_fwd)", 4 * (x + adj + y + co * ci + co)
-        return "fused ST-GCN stage bwd (cg_stgcn_domain_bwd)", 4 * (2 * x + 2 * adj + y + 2 * co * ci)
+            return FAM_STGCN, 4 * (x + adj + y + co * ci + co)
+        return FAM_STGCN, 4 * (2 * x + 2 * adj + y + 2 * co * ci)
     if name in ("cg_dstd_tail_fwd", "cg_dstd_tail_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.DstdTail)).contents
@@ -124,30 +150,30 @@ def _call_bytes(name, args):
         # tensor passes of each phase (section 4 of DESIGN.md): F1 y,r x2 | F2 y,r x2 -> h0 | F3 h0 | F4 h0,bres -> out;
         # K1 dout,h0 | K2 dout,h0 | K3 dout,h0,y,r x2 -> gp x2 | K4 y,r,gp x2 -> dr x2 | K5 y,dr x2 -> dy x2
         passes = {1: 4, 2: 5, 3: 1, 4: 3} if name.endswith("fwd") else {1: 2, 2: 2, 3: 8, 4: 8, 5: 6}
-        return "DSTD_GC tail phases (cg_dstd_tail_fwd/bwd)", n * passes.get(args[1], 0)
+        return FAM_TAIL, n * passes.get(args[1], 0)
     if name in ("cg_map2adj_tail_fwd", "cg_map2adj_tail_bwd"):
         items, n, phase = args[0], args[1], args[2]
         e = sum(4 * items[i].B * items[i].Kc * items[i].J * items[i].J for i in range(n))      # one (B,Kc,J,J) tensor per tower
         passes = {1: 1, 2: 2} if name.endswith("fwd") else {1: 3, 2: 2}
-        return "Map2Adj tail phases (cg_map2adj_tail_fwd/bwd)", e * passes.get(phase, 0)
+        return FAM_ADJ, e * passes.get(phase, 0)
     if name in ("cg_pointwise_maps_fwd", "cg_pointwise_maps_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.PwMaps)).contents
         x, ys = 4 * t.B * t.Cin * t.P, sum(4 * t.B * t.M[i] * t.P for i in range(t.n))
-        return "stacked tower maps (cg_pointwise_maps_fwd/bwd)", (x + ys) if name.endswith("fwd") else (2 * x + ys)
+        return FAM_PWM, (x + ys) if name.endswith("fwd") else (2 * x + ys)
     if name in ("cg_collapse_rows_fwd", "cg_collapse_rows_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.RowsConv)).contents
         x = 4 * t.B * t.C * t.T * t.V
-        return "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)", x if name.endswith("fwd") else 2 * x
+        return FAM_ROWSCONV, x if name.endswith("fwd") else 2 * x
     if name in ("cg_fpn_conv_fwd", "cg_fpn_conv_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.FpnConv)).contents
         x, y = 4 * t.B * t.C * t.H * t.W, 4 * t.B * t.O * t.H * t.W
-        return "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)", (x + t.n * y) if name.endswith("fwd") else (3 * x + 2 * t.n * y)
+        return FAM_FPN, (x + t.n * y) if name.endswith("fwd") else (3 * x + 2 * t.n * y)
     if name in ("cg_dstd_stats_fwd", "cg_dstd_stats_bwd"):
         B, C, T, V = args[-5:-1]
-        return "block statistics (cg_dstd_stats_fwd/bwd)", 4 * B * C * T * V * (1 if name.endswith("fwd") else 3)
+        return FAM_STATS, 4 * B * C * T * V * (1 if name.endswith("fwd") else 3)
     return "other (%s)" % name, 0
 
 
@@ -220,9 +246,23 @@ def family_rooflines(net, x, tgt, reps=3):
             continue
         f["GBps"] = f["algorithmic_bytes"] / max(f["us"], 1e-9) / 1e3
         f["frac"] = f["GBps"] / HBM_PEAK_GBS
+        f["kernels"] = [pre + "*" for pre in FAMILY_KERNELS.get(k, ())]
         out[k] = f
     out["other entry points (cat / sum / zero copies, SE gates, pooling, MPJPE, feature lift)"] = other
     return out
+
+
+def attach_traffic(fams, workload):
+    """HBM bytes per step of every family from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
+    very workload, corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE doubled for wide streaming reads); null when the
+    profile of this round has not been collected."""
+    rec = {}
+    if os.path.exists(TRAFFIC_FILE):
+        rec = json.load(open(TRAFFIC_FILE)).get(workload, {})
+    for k, f in fams.items():
+        t = rec.get(k)                       # bytes per training step, all launches of the family
+        f["traffic_per_step"] = t
+        f["traffic_over_algorithmic"] = (t / f["algorithmic_bytes"]) if (t and f.get("algorithmic_bytes")) else None
 
 
 def block_roofline(C, B, T, V, device, dropout, reps=5):
@@ -263,7 +303,7 @@ def block_roofline(C, B, T, V, device, dropout, reps=5):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = stock-PyTorch restatement pinned to the reference), child process with fixed thread count
 # ---------------------------------------------------------------------------------------------------------------------
-def cpu_baseline_worker(C, B, T, V, dropout, budget_s, max_steps):
+def cpu_baseline_worker(C, B, T, V, dropout, budget_s, max_steps, min_steps=3):
     from oracle import cistgcn_ref as O
     torch.manual_seed(0)
     net = O.CISTGCN(*make_cfg(C, T, V, dropout)).train()
@@ -280,7 +320,7 @@ def cpu_baseline_worker(C, B, T, V, dropout, budget_s, max_steps):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= max_steps:
+        if n >= min(min_steps, max_steps) and (el >= budget_s or n >= max_steps):      # at least three timed steps
             break
     print(json.dumps({"rate": B * n / el, "steps": n, "seconds": el, "threads": torch.get_num_threads()}))
 
@@ -312,6 +352,100 @@ def cpu_baseline(C, B, T, V, dropout, thread_counts, budget_s, max_steps=30):
     return {"value": best[0], "unit": "sequences/sec", "cores": best[1], "kind": "port",
             "sample": "fwd+bwd steps of the same workload (C=%d, B=%d, T=%d, V=%d) on the host (%d logical CPUs), torch %s CPU, "
                       "1 warm-up step, best of: %s" % (C, B, T, V, ncpu, torch.__version__, "; ".join(tried))}
+
+
+def headline_cpu_baseline(C, B, T, V, dropout):
+    """Large workloads: the thread count is chosen on a bounded sample (a quarter of the batch, >= 3 timed steps per count, 16 / 32 /
+    64 / 128 threads), then the FULL batch is timed with the best count for >= 3 steps; `value` is the full-batch rate.  Small
+    workloads: the whole sweep runs at full size."""
+    if B * C < 4096:
+        return cpu_baseline(C, B, T, V, dropout, (8, 16, 32), 12.0)
+    Bs = max(16, B // 4)
+    sweep = cpu_baseline(C, Bs, T, V, dropout, (16, 32, 64, 128), 48.0, max_steps=3)
+    nt = sweep["cores"] or 16
+    full = cpu_baseline(C, B, T, V, dropout, (nt,), 40.0, max_steps=3)
+    full["thread_sweep"] = {"batch": Bs, "best_threads": nt, "rates": sweep["sample"]}
+    return full
+
+
+def cpu_forward_worker(C, B, T, V, budget_s, max_steps):
+    """BASELINE configs[0]: eval-mode forward only (no_grad) of the CPU oracle."""
+    from oracle import cistgcn_ref as O
+    torch.manual_seed(0)
+    net = O.CISTGCN(*make_cfg(C, T, V, 0.0)).eval()
+    x, _ = synth(B, T, V, 0)
+    with torch.no_grad():
+        net(x)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            net(x)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or n >= max_steps:
+                break
+    print(json.dumps({"rate": B * n / el, "steps": n, "seconds": el, "threads": torch.get_num_threads()}))
+
+
+def cpu_forward_baseline(C, B, T, V, thread_counts=(8, 16, 32), budget_s=9.0):
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    tried, best = [], None
+    for nt in sorted({min(ncpu, c) for c in thread_counts}):
+        env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt), HIP_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-forward-worker", str(C), str(B), str(T), str(V), str(budget_s / 3), "200"]
+        try:
+            r = json.loads(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+        except Exception as e:
+            tried.append("%d thr: failed (%s)" % (nt, type(e).__name__))
+            continue
+        tried.append("%d thr: %.1f seq/s (%d forwards, %.1f s)" % (nt, r["rate"], r["steps"], r["seconds"]))
+        if best is None or r["rate"] > best[0]:
+            best = (r["rate"], nt)
+    return {"value": best[0] if best else None, "unit": "sequences/sec", "cores": best[1] if best else 0, "kind": "port",
+            "sample": "eval-mode forward of the same workload (C=%d, B=%d, T=%d, V=%d, no_grad) on the host (%d logical CPUs), 1 warm-up, "
+                      "best of: %s" % (C, B, T, V, ncpu, "; ".join(tried))}
+
+
+def dp_overhead(net, device, reps=20):
+    """What data parallelism adds to a step besides waiting for other ranks, timed on this one GPU: the weighted gather of all
+    gradients into the flat buffer, an RCCL all-reduce of that buffer in a ONE-rank communicator (launch + kernel cost, no wire)
+    and the 1/world scale.  HIP events on the launch stream."""
+    import torch.distributed as dist
+    from cistgcn_amd import ops, _lib
+    from cistgcn_amd.runtime import FlatGrads
+    own = False
+    try:
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            own = True
+        params = [p for p in net.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        flat = FlatGrads(params, device)
+        def once():
+            flat.gather(scale=1.0)
+            dist.all_reduce(flat.flat)
+            _lib.call("cg_scale", ops._ptr(flat.flat), flat.flat.numel(), 1.0, ops._stream(flat.flat))
+        for _ in range(3):
+            once()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        for p in params:
+            p.grad = None
+        return {"ms": ms, "bytes": 4 * flat.numel, "tensors": len(params), "what": "gather + one-rank RCCL all-reduce + scale of the flat gradient buffer"}
+    except Exception as e:           # a missing RCCL must not take the throughput line down
+        return {"ms": None, "error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        if own and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -360,7 +494,13 @@ def timed_training(workload, args, device, rank, world, steps, warmup, batch=Non
     res = {"workload": workload, "value": total_b * steps / el, "ms_per_step": el / steps * 1e3, "steps": steps, "seconds": el,
            "loss": loss, "capture_ms": getattr(step, "capture_ms", None), "global_batch": total_b, "per_gpu_batch": B,
            "shard_weight": getattr(step, "weight", None),
-           "buckets": len(step.flat.buckets) if world > 1 else None}
+           "buckets": len(step.flat.buckets) if world > 1 else None,
+           "bucket_bytes": [4 * int(step.flat.bucket_view(k).numel()) for k in range(len(step.flat.buckets))] if world > 1 else None,
+           "per_rank": None}
+    if world > 1:          # per-GPU batch and gradient weight of every rank (mixed batches: B_r * world / sum B)
+        per = [None] * world
+        dist.all_gather_object(per, {"rank": rank, "batch": B, "shard_weight": getattr(step, "weight", None)})
+        res["per_rank"] = per
     del step
     for p in net.parameters():
         p.grad = None
@@ -396,6 +536,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         C, B, T, V = [int(v) for v in sys.argv[2:6]]
         return cpu_baseline_worker(C, B, T, V, float(sys.argv[6]), float(sys.argv[7]), int(sys.argv[8]))
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-forward-worker":
+        C, B, T, V = [int(v) for v in sys.argv[2:6]]
+        return cpu_forward_worker(C, B, T, V, float(sys.argv[6]), int(sys.argv[7]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=80, help="timed steps of the headline workload (80 x ~30 ms > 2 s)")
@@ -407,7 +550,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval-mode forward-only timing")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (CISTGCN-8, B=16) line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (CISTGCN-8, B=16) and configs[4]-shape lines")
+    ap.add_argument("--no-dp-overhead", action="store_true", help="skip the one-GPU timing of gather + one-rank RCCL all-reduce + scale")
     ap.add_argument("--capture-tries", type=int, default=3,
                     help="graphs captured before the run; the MEDIAN one is kept (buffer placement moves the step by +-3 %%)")
     ap.add_argument("--data-seed", type=int, default=1234, help="base seed of the synthetic batch (rank is added)")
@@ -452,7 +596,8 @@ def main():
                    "graph_branches": bool(args.branches and not args.no_graph), "timed_seconds": res["seconds"],
                    "capture_probe_ms": res["capture_ms"], "capture_kept": "median" if res["capture_ms"] else None,
                    "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
-                   "gradient_buckets": res["buckets"], "mixed_batches": bool(batch), "loss": res["loss"]},
+                   "gradient_buckets": res["buckets"], "gradient_bucket_bytes": res["bucket_bytes"], "per_rank": res["per_rank"],
+                   "mixed_batches": bool(batch), "loss": res["loss"]},
     }
     if rank == 0 and world == 1:
         out["step_roofline"] = step_roofline(C, T, V, out["value"])
@@ -460,27 +605,29 @@ def main():
             out["eval_forward"] = eval_forward(net, x, args.steps, args.warmup)
         if not args.no_roofline:
             fams = family_rooflines(net, x, tgt)
+            attach_traffic(fams, args.workload)
             dom = max((k for k in fams if not k.startswith("other")), key=lambda k: fams[k]["us"])
-            traffic = None      # HBM bytes per launch from rocprofv3 PMC passes (tools/gpu_pmc.sh), recorded under profiles/
-            tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            if os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
             f = fams[dom]
-            out["roofline"] = {"bound": "hbm", "achieved": f["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f["frac"],
-                               "traffic": traffic, "kernel": dom, "launches_per_step": f["launches"],
-                               "avg_us": f["us"] / max(1, f["launches"]),
-                               "algorithmic_bytes_per_launch_avg": f["algorithmic_bytes"] / max(1, f["launches"]),
-                               "how": "dominant family by summed time of one eager step; HIP events around every C-ABI call on the "
-                                      "launch stream, algorithmic bytes = each operand/result of each call once",
-                               "per_family": fams}
             del net
             torch.cuda.synchronize()
-            out["block_roofline"] = block_roofline(C, B, T, V, device, args.dropout)
+            blk = block_roofline(C, B, T, V, device, args.dropout)
+            out["roofline"] = {"bound": "hbm", "achieved": f["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f["frac"],
+                               "traffic": (f["traffic_per_step"] / max(1, f["launches"])) if f["traffic_per_step"] else None, "family": dom, "kernel": ", ".join(f["kernels"]),
+                               "launches_per_step": f["launches"], "avg_us": f["us"] / max(1, f["launches"]), "us_per_step": f["us"],
+                               "algorithmic_bytes_per_launch_avg": f["algorithmic_bytes"] / max(1, f["launches"]),
+                               "how": "largest family by summed time of one eager step (forward + backward entry points of a stage "
+                                      "form ONE family, for every stage); HIP events around every C-ABI call on the launch stream; "
+                                      "algorithmic bytes = each operand / result of each call once",
+                               # SURVEY 8(d)'s unit: bytes of ONE DSTD_GC invocation (read x, write out, both adjacency maps, gates;
+                               # backward: x, dOut, maps, dx) over the time of ALL kernels of the block
+                               "vs_8d": {"block": blk["block"], "algorithmic_bytes": blk["algorithmic_bytes_fwd"] + blk["algorithmic_bytes_bwd"],
+                                         "us": blk["fwd_us"] + blk["bwd_us"], "achieved": blk["achieved"], "frac": blk["frac"]},
+                               "per_family": fams}
+            out["block_roofline"] = blk
         else:
             del net
         if not args.no_cpu_baseline:
-            big = B * C >= 4096
-            out["cpu_baseline"] = cpu_baseline(C, B, T, V, args.dropout, (16,) if big else (8, 16, 32), 1.0 if big else 12.0, 1 if big else 30)
+            out["cpu_baseline"] = headline_cpu_baseline(C, B, T, V, args.dropout)
         if not args.no_secondary and args.workload != SECONDARY:
             torch.cuda.empty_cache()
             C2, B2, T2, V2 = WORKLOADS[SECONDARY]
@@ -490,10 +637,25 @@ def main():
                    "step_roofline": step_roofline(C2, T2, V2, r2["value"])}
             if not args.no_eval:
                 sec["eval_forward"] = eval_forward(net2, x2, 400, 20)
+                if not args.no_cpu_baseline:       # BASELINE configs[0]: the same forward on the reference's CPU path
+                    sec["eval_forward"]["cpu_baseline"] = cpu_forward_baseline(C2, B2, T2, V2)
             del net2
             if not args.no_cpu_baseline:
                 sec["cpu_baseline"] = cpu_baseline(C2, B2, T2, V2, args.dropout, (8, 16, 32), 12.0)
             out["secondary"] = sec
+            # BASELINE configs[4]'s per-GPU workload (CISTGCN-32, 25 joints) at one of its batch sizes, on this one GPU
+            torch.cuda.empty_cache()
+            r3, net3, _, _ = timed_training(AMASS25, args, device, rank, world, 60, 10)
+            out["other_workloads"] = [{"config": "BASELINE configs[4] shape on one GPU: %s" % AMASS25, "value": r3["value"], "unit": "sequences/sec",
+                                       "ms_per_step": r3["ms_per_step"], "steps": 60, "timed_seconds": r3["seconds"], "loss": r3["loss"],
+                                       "step_roofline": step_roofline(*[WORKLOADS[AMASS25][i] for i in (0, 2, 3)], r3["value"])}]
+            del net3
+        if not args.no_dp_overhead:
+            torch.cuda.empty_cache()
+            from cistgcn_amd.models import CISTGCN_0
+            torch.manual_seed(0)
+            out["dp_overhead"] = dp_overhead(CISTGCN_0(*make_cfg(C, T, V, args.dropout)).to(device), device)
+            out["dp_overhead_ms"] = out["dp_overhead"].get("ms")
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

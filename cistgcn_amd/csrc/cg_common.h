@@ -90,6 +90,18 @@ __device__ __forceinline__ float cg_row16_sum(float v) {
   v += cg_dpp<0x128>(0.f, v); v += cg_dpp<0x124>(0.f, v); v += cg_dpp<0x122>(0.f, v); v += cg_dpp<0x121>(0.f, v);
   return v;
 }
+// the same in f64 (BatchNorm channel sums are kept in f64 end to end: the variance is formed as E[x^2] - E[x]^2): the two 32-bit
+// halves travel through the DPP rotation, the additions are f64
+template <int CTRL>
+__device__ __forceinline__ double cg_dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = cg_dpp<CTRL>(0, (int)(unsigned)(u & 0xFFFFFFFFull)), hi = cg_dpp<CTRL>(0, (int)(unsigned)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ double cg_row16_sum(double v) {
+  v += cg_dpp_f64<0x128>(v); v += cg_dpp_f64<0x124>(v); v += cg_dpp_f64<0x122>(v); v += cg_dpp_f64<0x121>(v);
+  return v;
+}
 
 // The gradient of a shared PReLU slope is a sum over the whole tensor.  One f64 word would take an atomic from every
 // workgroup: same-address atomics serialise at ~20 ns each on MI355X (measured, profiles/README.md), 4096 of them cost more than

@@ -688,8 +688,13 @@ static CgAdjGeom cg_adj_geometry(int B, int Kc, int J) {
   g.magicJ = cg_adj_magic(J); g.magicKc = cg_adj_magic(Kc); g.magicPad = cg_adj_magic(g.WS - Kc);
   return g;
 }
-// ablation mask of the backward kernels (tools/gpu_adj_ablate.sh): results are WRONG with it set, so it also needs CISTGCN_ABLATION=1
-static int cg_adj_dbg() { static const int v = (getenv("CG_ADJ_DBG") && getenv("CISTGCN_ABLATION")) ? atoi(getenv("CG_ADJ_DBG")) : 0; return v; }
+// ablation mask of the backward kernels (tools/gpu_adj_ablate.sh builds a private library with -DCG_ABLATION): results are WRONG
+// with it set; the shipped library is compiled without the flag and cannot skip a phase
+#ifdef CG_ABLATION
+static int cg_adj_dbg() { static const int v = getenv("CG_ADJ_DBG") ? atoi(getenv("CG_ADJ_DBG")) : 0; return v; }
+#else
+static int cg_adj_dbg() { return 0; }
+#endif
 static int cg_adj_tile(int Kc) { const int KcM = (Kc + 15) & ~15; return KcM > 32 ? 64 : KcM > 16 ? 128 : 256; }
 
 static int cg_adj_check(const CgAdjTail* it, int n) {

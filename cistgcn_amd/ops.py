@@ -182,8 +182,27 @@ def seed_state(device):
     return s
 
 
+# Dropout keep-masks are regenerated in backward from the device-resident seed word, so a backward pass must see the seed of
+# its own forward.  Every change of the word is counted per device; a forward with dropout records the count and its backward
+# raises if the seed has moved in between (two micro-batches before one backward, a retained graph, ...) instead of silently
+# applying different masks.  Under HIP-graph replay nothing of this runs: a captured step contains its own bump + fwd + bwd.
+_seed_epochs = {}
+
+
+def seed_epoch(device):
+    return _seed_epochs.get(_dev(device), 0)
+
+
+def _check_seed_epoch(ctx, device, what):
+    ep = getattr(ctx, "seed_epoch", None)
+    if ep is not None and ep != seed_epoch(device):
+        raise RuntimeError("%s: the dropout seed advanced between this forward and its backward (another training forward ran in "
+                           "between); run backward before the next forward or use drop_p = 0" % what)
+
+
 def manual_seed(seed, device):
     seed_state(device).fill_(int(seed))
+    _seed_epochs[_dev(device)] = seed_epoch(device) + 1
 
 
 def begin_step(device, bump_seed=False):
@@ -197,6 +216,7 @@ def begin_step(device, bump_seed=False):
     if bump_seed:
         s = seed_state(device)
         _lib.call("cg_seed_bump", _ptr(s), _stream(s))
+        _seed_epochs[device] = _seed_epochs.get(device, 0) + 1
 
 
 # ----------------------------------------------------------------------------------------------
@@ -677,6 +697,7 @@ class _NormActMany(torch.autograd.Function):
             m = min(_ROW_BATCH, n - c0)
             _lib.call("cg_norm_act_fwd_many", ctypes.cast(ctypes.byref(arr[c0]), ctypes.POINTER(NormAct)), m, stream)
         ctx.cfgs, ctx.ps, ctx.modes = cfgs, ps, [arr[i].bn_mode for i in range(n)]
+        ctx.seed_epoch = seed_epoch(six[0][0].device) if any(p > 0.0 for p in ps) else None
         flat = []
         for i in range(n):
             flat += list(six[i]) + [saves[i]]
@@ -690,6 +711,7 @@ class _NormActMany(torch.autograd.Function):
     def backward(ctx, *dys):
         n = len(ctx.cfgs)
         saved = ctx.saved_tensors
+        _check_seed_epoch(ctx, saved[0].device, "norm_act")
         arr = (NormAct * n)()
         flags = (ctypes.c_int * n)()
         grads = []
@@ -1482,6 +1504,7 @@ class _DstdTail(torch.autograd.Function):
         t.gate = gate.data_ptr()
         _lib.call("cg_dstd_tail_fwd", ctypes.byref(t), 4, stream)
         ctx.cfg, ctx.p = cfg, p
+        ctx.seed_epoch = seed_epoch(dev) if p > 0.0 else None
         ctx.save_for_backward(*ts, h0, pooled, gate, saves)
         if ostats is not None:
             ctx.mark_non_differentiable(ostats)
@@ -1493,6 +1516,7 @@ class _DstdTail(torch.autograd.Function):
         (y1, y2, r1, r2, w1, w2, gt1, bt1, ad1, gt2, bt2, ad2, gp1, bp1, ap1, gp2, bp2, ap2, wc, gc, bc, ac, sw1, sw2, bres) = sv[:25]
         h0, pooled, gate, saves = sv[25:]
         cfg = ctx.cfg
+        _check_seed_epoch(ctx, y1.device, "dstd_tail")
         B, C, T, V = y1.shape
         dev, train, f32 = y1.device, bool(cfg["train"]), torch.float32
         dout = dout if dout.is_contiguous() else _copy(dout)
@@ -1617,6 +1641,7 @@ class _Map2AdjTail(torch.autograd.Function):
         for phase in (1, 2):
             _lib.call("cg_map2adj_tail_fwd", items, n, phase, stream)
         ctx.cfg, ctx.p, ctx.n = cfg, p, n
+        ctx.seed_epoch = seed_epoch(dev) if p > 0.0 else None
         ctx.save_for_backward(*ts, *e, *saves)
         return tuple(adj)
 
@@ -1628,6 +1653,7 @@ class _Map2AdjTail(torch.autograd.Function):
         dev, train, f32 = ts[0].device, bool(cfg["train"]), torch.float32
         if any(d is None for d in dadj):
             raise RuntimeError("map2adj_tail: every adjacency needs a gradient")
+        _check_seed_epoch(ctx, dev, "map2adj_tail")
         dadj = [d if d.is_contiguous() else _copy(d) for d in dadj]
         items = _Map2AdjTail._items(cfg, ts, train, saves, None, e, dev, ctx.p)
         arena = _arena(dev)

@@ -40,11 +40,11 @@ class FlatGrads:
         dev = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(device)
         self._off = dev(self.offsets[:-1], np.int64)
         self._ct, self._cb, self._cl = dev(ct, np.int32), dev(cb, np.int32), dev(cl, np.int32)
-        self._ptr_host = torch.zeros(len(sizes), dtype=torch.int64)
-        if torch.device(device).type == "cuda":
-            self._ptr_host = self._ptr_host.pin_memory()
-        self._ptr_dev = torch.zeros(len(sizes), dtype=torch.int64, device=device)
-        self._last_ptrs = None
+        # one pointer table per bucket (key None = the whole buffer): buckets are gathered on different streams in the two-phase
+        # data-parallel step, and a shared table would be rewritten for one bucket while the gather kernel of another still
+        # reads it
+        self._tables = {}
+        self._device = device
         self.buckets = [(0, len(sizes))]          # tensor index ranges
 
     def set_buckets(self, tensor_cuts):
@@ -69,16 +69,22 @@ class FlatGrads:
             if not p.grad.is_contiguous():
                 raise RuntimeError("FlatGrads: non-contiguous gradient")
             ptrs.append(p.grad.data_ptr())
-        if ptrs != self._last_ptrs:
+        tab = self._tables.get(bucket)
+        if tab is None:
+            host = torch.zeros(len(self.params), dtype=torch.int64)
+            if torch.device(self._device).type == "cuda":
+                host = host.pin_memory()
+            tab = self._tables[bucket] = {"host": host, "dev": torch.zeros(len(self.params), dtype=torch.int64, device=self._device), "last": None}
+        if ptrs != tab["last"]:
             # the pointer table only changes when autograd hands out new gradient buffers; under HIP-graph replay
             # the buffers are static and this upload happens once
-            self._ptr_host.copy_(torch.tensor(ptrs, dtype=torch.int64))
-            self._ptr_dev.copy_(self._ptr_host)          # synchronous: the host staging buffer is reused
-            self._last_ptrs = ptrs
+            tab["host"].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            tab["dev"].copy_(tab["host"])                # synchronous: the host staging buffer is reused
+            tab["last"] = ptrs
         c0, c1 = self._first_chunk[a], self._first_chunk[b]
         if c1 <= c0:
             return
-        _lib.call("cg_multi_copy", ops._ptr(self._ptr_dev), ops._ptr(self._off), ops._ptr(self._ct[c0:]), ops._ptr(self._cb[c0:]),
+        _lib.call("cg_multi_copy", ops._ptr(tab["dev"]), ops._ptr(self._off), ops._ptr(self._ct[c0:]), ops._ptr(self._cb[c0:]),
                   ops._ptr(self._cl[c0:]), c1 - c0, ops._ptr(self.flat), direction, float(scale), ops._stream(self.flat))
 
     def gather(self, bucket=None, scale=1.0):

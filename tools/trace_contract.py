@@ -22,9 +22,9 @@ ops.manual_seed(1234, dev)
 x, tgt = [t.to(dev) for t in bench.synth(B, T, V, 0)]
 log = []
 orig = ops._contract_launch
-def timed(builders, device, groups=None):
+def timed(builders, device, groups=None, chains=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    probe = orig(builders, device, groups)
+    probe = orig(builders, device, groups, chains)
     arrs = [( _lib.ContractDesc * len(probe[c:c + 16]))(*[r.desc for r in probe[c:c + 16]]) for c in range(0, len(probe), 16)]
     st = ops._stream(probe[0].y)
     e0.record()
