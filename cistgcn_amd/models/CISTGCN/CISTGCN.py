@@ -542,6 +542,7 @@ class CISTGCN(nn.Module):
             if taps is not None:
                 for mod, tap in zip((doms[0].prelu, doms[1].prelu, m.prelu1[1], m.prelu2[1], c[2]), taps):
                     self.act_trace[mod] = (tap, None)
+            self._site += 4          # the row-kernel chain below numbers four more (dropout-free) sites: later blocks draw the same masks on either path
             return (out, ost) if tr else out
         x12 = self._na_many([dict(x=ys[i], bn=d.tcn[1], drop=True, add=res[i], prelu=d.prelu) for i, d in enumerate(doms)])
         ab = self._na_many([dict(x=x12[0], pre=m.w1, bn=m.prelu1[0], prelu=m.prelu1[1]),

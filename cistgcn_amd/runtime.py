@@ -438,6 +438,9 @@ class DataParallelStep(_StepBase):
         self._cut_in = self._cut_leaf = None
         self.graphs = None
         self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
+        self.force_collective = False     # run the all-reduce in a one-rank group too (overlap measurements on one GPU)
+        self.record_events = False        # replay() then leaves HIP events of both streams in self.events
+        self.events = None
         if graph:
             self._capture(warmup)
         self._freeze_param_pointers()
@@ -487,7 +490,7 @@ class DataParallelStep(_StepBase):
     def _reduce(self, bucket, async_op):
         import torch.distributed as dist
         buf = self.flat.gather(bucket, scale=self.weight)
-        if self.world > 1:
+        if self.world > 1 or (self.force_collective and dist.is_initialized()):
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         return None
 
@@ -500,19 +503,33 @@ class DataParallelStep(_StepBase):
             with ops.step_pool(self._pool):
                 self.loss = self._phase1()
         work = None
+        ev = None
+        if self.record_events and cuda:
+            ev = self.events = {k: torch.cuda.Event(enable_timing=True) for k in ("phase1_end", "reduce1_start", "reduce1_end", "phase2_start", "phase2_end")}
+            ev["phase1_end"].record()
         if self.two_phase:
             if cuda:                                   # early bucket: gather + all-reduce beside phase 2
                 self._side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._side):
+                    if ev:
+                        ev["reduce1_start"].record()
                     work = self._reduce(1, True)
+                    if ev:
+                        if work is not None:
+                            work.wait()                # stream-level wait: orders the end event behind the collective
+                        ev["reduce1_end"].record()
             else:
                 work = self._reduce(1, True)
+            if ev:
+                ev["phase2_start"].record()
             if self.graphs is not None:
                 self.graphs[1].replay()
             else:
                 with ops.step_pool(self._pool):
                     self._phase2()
                 self._cut_in = self._cut_leaf = None
+            if ev:
+                ev["phase2_end"].record()
             self._reduce(0, False)
             if work is not None:
                 work.wait()

@@ -712,7 +712,7 @@ def check_model_vs_oracle(device, C, T, V, B, mode, seed=0, scale=350.0, fused=T
 
 
 def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=350.0, grad_floor=1.0, max_flip_frac=2e-5,
-                              x=None, tgt=None, net=None, ora=None, **cfg_kw):
+                              x=None, tgt=None, net=None, ora=None, rel_bound=None, **cfg_kw):
     """Flip-aware parity of EVERY parameter gradient (north_star tolerance 1e-4): the HIP model runs first and records
     the branch each PReLU element took (`net.act_trace`); the oracle then differentiates the same piecewise-linear
     function (helpers.BranchReplay), so no kink allowance is needed: pred, loss, dL/dx and all parameter gradients are
@@ -760,13 +760,14 @@ def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=35
     assert_close(ld, lo, "loss")
     assert_close(xd.grad, xo.grad, "dL/dx", floor=1e-1)
     gd = dict(net.named_parameters())
+    rel_report = {}
     worst = assert_grads_strict({k: gd[k].grad for k, _ in ora.named_parameters()}, {k: p.grad for k, p in ora.named_parameters()},
-                                "branch replay", floor=grad_floor)
+                                "branch replay", floor=grad_floor, rel_bound=rel_bound, report=rel_report)
     sd, so = net.state_dict(), ora.state_dict()
     for k in so:
         if "running" in k or "num_batches" in k:
             assert_close(sd[k].float(), so[k].float(), k)
-    return {"flips": rep.flips, "elements": rep.elements, "worst_flip": rep.worst, "worst_grad": worst}
+    return {"flips": rep.flips, "elements": rep.elements, "worst_flip": rep.worst, "worst_grad": worst, "relative_error": rel_report}
 
 
 def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11))):

@@ -24,16 +24,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shards=SHARDS):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, shards)
     except BaseException as e:              # report instead of leaving the parent waiting on the queue
         import traceback
         q.put((rank, "error", traceback.format_exc()))
         raise
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, SHARDS):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -88,15 +88,18 @@ def _worker_body(rank, world, port, q):
 
 
 @pytest.mark.timeout(1500)
-def test_two_rank_model_step_matches_oracle_per_shard():
+@pytest.mark.parametrize("SHARDS", [SHARDS, (2, 5, 3, 4)], ids=["two ranks 3/4", "four ranks 2/5/3/4"])
+def test_model_step_matches_oracle_per_shard(SHARDS):
+    """two ranks, and four ranks with four different batch sizes (BASELINE configs[4]: the weight of a replica's gradient is
+    B_r * world / sum B, which only shows with more than two unequal shards that it is not B_r / B_other)"""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
     import build_emu
-    build_emu.build()          # compile the shim library ONCE here: the two workers would otherwise race to build it
-    world, port = 2, _free_port()
+    build_emu.build()          # compile the shim library ONCE here: the workers would otherwise race to build it
+    world, port = len(SHARDS), _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, SHARDS)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -111,7 +114,8 @@ def test_two_rank_model_step_matches_oracle_per_shard():
     for r in range(world):
         assert abs(res[r][3] - SHARDS[r] * world / tot) < 1e-6          # shard_weights
     offs = res[0][2]
-    assert np.array_equal(res[0][0], res[1][0])                        # both ranks hold the same reduced buffer
+    for r in range(1, world):
+        assert np.array_equal(res[0][0], res[r][0])                    # every rank holds the same reduced buffer
     # SURVEY 8e parity check: oracle per shard -> weighted mean -> compare with the all-reduced buffer
     n = len(res[0][1])
     for i in range(n):
@@ -120,4 +124,5 @@ def test_two_rank_model_step_matches_oracle_per_shard():
         err = float(np.abs(got - ref).max())
         bound = 1e-4 * max(0.1, float(np.abs(ref).max()))
         assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
-    assert np.array_equal(res[0][4], res[1][4]), "replicas diverged after the optimizer step"
+    for r in range(1, world):
+        assert np.array_equal(res[0][4], res[r][4]), "replicas diverged after the optimizer step"
