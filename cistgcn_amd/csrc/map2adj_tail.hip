@@ -688,7 +688,7 @@ static CgAdjGeom cg_adj_geometry(int B, int Kc, int J) {
   g.magicJ = cg_adj_magic(J); g.magicKc = cg_adj_magic(Kc); g.magicPad = cg_adj_magic(g.WS - Kc);
   return g;
 }
-// ablation mask of the backward kernels (tools/gpu_adj_ablate.sh builds a private library with -DCG_ABLATION): results are WRONG
+// ablation mask of the backward kernels (a private library built with -DCG_ABLATION; profiles/r02_ablations.txt): results are WRONG
 // with it set; the shipped library is compiled without the flag and cannot skip a phase
 #ifdef CG_ABLATION
 static int cg_adj_dbg() { static const int v = getenv("CG_ADJ_DBG") ? atoi(getenv("CG_ADJ_DBG")) : 0; return v; }

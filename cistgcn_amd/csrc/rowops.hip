@@ -718,7 +718,7 @@ extern "C" int cg_copy_many(const CgCopyItem* items, int n, void* stream_) {
 
 // Zero fill as a KERNEL, not hipMemsetAsync: inside a captured HIP graph the memset node was observed not to be ordered
 // reliably against the kernels around it once the process had allocated and freed other device memory between replays
-// (zero halos of the dilated convolutions read NaN left by unrelated tensors; tools/diag_replay_stability.py).
+// (zero halos of the dilated convolutions read NaN left by unrelated tensors; tools/diag_replay_stability.py, round 1).
 __global__ void cg_zero_kernel(uint4* __restrict__ p16, long long n16, unsigned char* __restrict__ tail, int ntail) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;

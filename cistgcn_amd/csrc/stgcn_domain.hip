@@ -22,7 +22,7 @@
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
-// Kernel-generation switches for A/B runs (tools/bench_domain*.py).  They are honoured only in a process started with
+// Kernel-generation switches for A/B runs (tools/bench_planes.py).  They are honoured only in a process started with
 // CISTGCN_ABLATION=1 (read once); a production process never calls getenv() per launch and a stray variable cannot change
 // which kernel runs.  INTEGRATION.md lists them.
 static const char* cg_dom_env(const char* name) {
@@ -567,7 +567,7 @@ static int cg_dom_geom(CgDomainGeom& g, int B, int Cin, int Cout, int T, int V, 
   // (fewer than 1024 single-group tiles) instead aim at one wave of ~256 workgroups: one round on the 256 CUs.
   const long long tiles1 = (long long)B * g.NG;
   const int want_wgs = tiles1 < 1024 ? 256 : 1024;
-  const char* env_gt = cg_dom_env("CG_DOM_GT");          // tuning aid (tools/bench_domain.py); unset in production
+  const char* env_gt = cg_dom_env("CG_DOM_GT");          // tuning aid (tools/bench_planes.py); unset in production
   int best = 0;
   for (int gt = 1; gt <= g.NG; ++gt) {
     g.GT = gt; g.PP = gt * g.Jp;

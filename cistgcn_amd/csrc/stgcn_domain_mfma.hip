@@ -3,7 +3,7 @@
 // stage runs on v_mfma_f32_16x16x4_f32 (exact f32 fma chains).  Persistent 256-thread workgroups, two per CU (LDS image
 // <= 80 KiB), each walking a contiguous range of tiles; the next tile's operands are fetched into registers while the
 // current tile's last phase runs, and the second workgroup of the CU computes while the first one waits for memory
-// (measured with the phases switched off, tools/ablate_domain.py: loads, compute and stores of a tile cost about the same,
+// (measured with the phases switched off, round-2 ablation builds, profiles/r02_ablations.txt: loads, compute and stores of a tile cost about the same,
 // serialised they were 3x the compute time).
 //
 // Backward, per tile = (sample b, GT groups; a group is one joint in the "space" domain, one frame in the "time" domain):

@@ -307,7 +307,7 @@ class GraphedStep(_StepBase):
     def __init__(self, model, x, target, warmup=3, flat=None, branches=False, tries=1):
         """tries > 1: capture that many graphs (each lands in different memory), time a few replays of each and keep the
         median one (the same step replays in 5.27 .. 5.46 ms depending on where the capture's buffers were placed, stable
-        for the life of a capture: tools/diag_bimodal.py); `capture_ms` lists all probes."""
+        for the life of a capture, profiles/README.md); `capture_ms` lists all probes."""
         self._init_common(model, x.clone(), target.clone(), flat)
         # Optional: the context branch on a forked stream (one fork / join per step, CISTGCN._parallel) -> a parallel graph
         # branch.  Captures and replays correctly on ROCm 7.2 but measured no faster (5.44 vs 5.43 ms at B=16), so it is off.

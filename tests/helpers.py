@@ -65,7 +65,7 @@ def assert_grads_close(named_got, named_ref, what=""):
     """Parameter-gradient comparison that tolerates PReLU-kink sign flips.
 
     A pre-activation within fp32 rounding of 0 may take the other PReLU branch in another fp32 implementation
-    (the reference's CPU path does it too against its own fp64 run: tools/diag_sites.py prints the flip counts).
+    (the reference's CPU path does it too against its own fp64 run: the branch-replay tests print the flip counts).
     One flipped element changes dy there by (1-alpha)*dy, i.e. a few percent of every weight-gradient entry of that
     output channel (sum of ~N random terms, one of them changed) and of scalar gradients such as a PReLU slope.
     So with the real slopes tensors are compared in relative L2 norm with a 5 % bound (plus a floor for
