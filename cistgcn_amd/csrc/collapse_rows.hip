@@ -27,7 +27,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
   const int b = blockIdx.x, K = g.K, V = t.V;
   float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][33] partial sums of the eight waves
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ROWS_FWD_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ROWS_FWD_THREADS / 64;
   for (int e = tid; e < 16 * g.OT * 33; e += CG_ROWS_FWD_THREADS) sY[e] = 0.f;
   __syncthreads();
   const float* xb = t.x + (long long)b * K * V;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
   float* sW = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][KB + 4]  W[o][k0 ..]
   float* sDY = sW + 16 * g.OT * (CG_ROWS_KB + 4);                 // [2][16 * OT][36]   dy of the current / next sample, v padded with zeros
   const int WS = CG_ROWS_KB + 4, DS = 36;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   for (int e = tid; e < 16 * g.OT * WS; e += CG_ROWS_BWD_THREADS) {
     const int o = e / WS, kk = e - o * WS;
     sW[e] = (o < O && kk < CG_ROWS_KB && k0 + kk < K) ? t.W[(long long)o * K + k0 + kk] : 0.f;

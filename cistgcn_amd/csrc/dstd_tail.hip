@@ -236,7 +236,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
   float* sW = sAct + C2M * CG_TAIL_PS;                            // [CM][WS]
   float* sK = sW + CM * WS;                                       // [2C][8]
   double* sStat = reinterpret_cast<double*>(sK + 8 * C2M);        // [CM][2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const int wg = blockIdx.x;
   if (wg * per >= total) return;
   for (int e = tid; e < C2M * CG_TAIL_PS + CM * WS; e += CG_TAIL_THREADS) sAct[e] = 0.f;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
   float* sK = sW + CM * WS;                                       // [2C][8]
   float* sKc = sK + 8 * C2M;                                      // [CM][8] compressor BatchNorm backward constants
   double* sRed = reinterpret_cast<double*>(sKc + 8 * CM);         // [C2M][2] sums of g_p, g_p * zhat ; then [2] d alpha_p
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_TAIL_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_TAIL_THREADS / 64;
   const int wg = blockIdx.x;
   if (wg * per >= total) return;
   for (int e = tid; e < C2M * CG_TAIL_PS3 + CM * CG_TAIL_PS3 + CM * WS; e += CG_TAIL_THREADS) sZ[e] = 0.f;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
 __global__ void cg_tail_k4_kernel(CgDstdTail t, int rb) {
   const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb, P = t.T * t.V;
   if (b0 >= t.B) return;
-  const int nb = min(rb, t.B - b0), lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int nb = min(rb, t.B - b0), lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const double cnt = (double)t.B * P;
   const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, 0.0, t.train, true, false);
   const CgAff ap = cg_tail_aff(t.bn_p[i], c, t.C, 0.0, t.train, true, false);

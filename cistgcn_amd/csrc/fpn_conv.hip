@@ -61,7 +61,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_fwd_kernel(CgFpnArgs a)
   float* sW = sX + t.C * g.IMG;                                   // [OM][KS]
   int* sTap = reinterpret_cast<int*>(sW + g.OM * g.KS);           // [KP] image offset of tap k
   int* sPos = sTap + g.KP;                                        // [PM] image offset of position p
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   cg_fpn_zero(sX, t.C * g.IMG);
   cg_fpn_zero(sW, g.OM * g.KS);
   __syncthreads();
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dx_kernel(CgFpnArgs a) 
   float* sW = sD + t.O * g.IMG;                                   // [CM][KS2]  Wt[c][(o,i,j)]
   int* sTap = reinterpret_cast<int*>(sW + g.CM * g.KS2);          // [KP2]
   int* sPos = sTap + g.KP2;                                       // [PM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_FPN_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_FPN_THREADS / 64;
   const int PT = g.PM / 16, CT = g.CM / 16;
   cg_f32x4 acc[CG_FPN_DXT];
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dw_kernel(CgFpnArgs a) 
   float* sD = sX + t.C * g.IMG;                                   // [OM][DS]  dy rows, positions padded with zeros
   int* sTap = reinterpret_cast<int*>(sD + g.OM * DS);             // [KP]
   int* sPos = sTap + g.KP;                                        // [PM]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_FPN_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_FPN_THREADS / 64;
   const int OT = g.OM / 16, KT = g.KP / 16;
   cg_f32x4 acc[CG_FPN_DWT];
 #pragma unroll

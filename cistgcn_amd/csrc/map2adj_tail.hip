@@ -103,7 +103,7 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
   float* sQ = sS + g.KcM * g.JS;
   float* sW = sQ + g.KcM * g.JS;
   double* sStat = reinterpret_cast<double*>(sW + g.KcM * g.WS + ((g.KcM * g.JS * 2 + g.KcM * g.WS) & 1));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   cg_adj_tables(t, g, b, sS, sQ);
   cg_adj_weight(t.W0, t, g, sW);
   for (int e = tid; e < 2 * g.KcM; e += CG_ADJ_THREADS) sStat[e] = 0.0;
@@ -245,7 +245,7 @@ __device__ __forceinline__ void cg_adj_m2_body(const CgAdjTail& t, const CgAdjGe
   float* sH = reinterpret_cast<float*>(cg_dyn_lds);              // [KcM][PS]
   float* sW = sH + g.KcM * g.PS;                             // [KcM][WS]
   float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   constexpr int N = VEC ? 4 : 1;
   const float* eb = t.e + (long long)b * t.Kc * g.Pn;
   float ebuf[16];
@@ -330,7 +330,7 @@ __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGe
   float* sW = sD + g.KcM * g.PS;                             // [KcM][WS] W4
   float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
   double* sRed = reinterpret_cast<double*>(sK + 8 * g.KcM);       // [KcM][2] + [1]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
   constexpr int N = VEC ? 4 : 1;
   const float* eb = t.e + (long long)b * t.Kc * g.Pn;
   const float* db = t.dadj + (long long)b * t.Kc * g.Pn;
@@ -498,7 +498,7 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
   float* sDO = sDE + g.KcM * g.PS;                           // [KcM][PS] do
   float* sW = sDO + g.KcM * g.PS;                            // [KcM][WS] W0
   float* sK = sW + g.KcM * g.WS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
   constexpr int N = VEC ? 4 : 1;
   const float* gsrc = t.g + (long long)b * t.Kc * g.Pn;
   const float* eb = t.e + (long long)b * t.Kc * g.Pn;

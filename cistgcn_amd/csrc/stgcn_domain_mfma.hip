@@ -166,7 +166,7 @@ __device__ __forceinline__ int cg_domm_wg(const CgDomM& g) {
 
 // P1 of both directions: G[ci][grp, o] = sum_j X[ci][grp, j] A[grp][j][o]  -> sBuf
 __device__ __forceinline__ void cg_domm_graph_product(const CgDomM& g, const float* sX, const float* sA, float* sBuf) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = CG_DOMM_THREADS / 64, l15 = lane & 15, slot = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = CG_DOMM_THREADS / 64, l15 = lane & 15, slot = lane >> 4;
   const int MTi = g.CiM / 16, NT = g.Jr / 16, NP = (NT + 1) / 2;
   for (int w = wave; w < g.GT * MTi * NP; w += nw) {
     const int r = (int)cg_fastdiv((unsigned)w, g.magicNP), np = w - r * NP;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CG_DOMM_THREADS, 2) void cg_stgcn_domain_bwd_mfma_k
   const int lds_floats = (2 * g.CiM + g.CoM) * g.RS + g.GT * g.Jr * g.Jsa + (g.w_global ? 0 : g.CoM * g.WS);
 
   const int tid = threadIdx.x, nt = CG_DOMM_THREADS;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, l15 = lane & 15, slot = lane >> 4;
   const int wg = cg_domm_wg(g);
   if (wg < 0) return;
 
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(CG_DOMM_THREADS, 2) void cg_stgcn_domain_fwd_mfma2_
   const int lds_floats = 2 * g.CiM * g.RS + g.GT * g.Jr * g.Jsa + g.CoM * g.WS + 4 * g.CoM;
 
   const int tid = threadIdx.x, nt = CG_DOMM_THREADS;
-  const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nt >> 6, l15 = lane & 15, slot = lane >> 4;
   const int wg = cg_domm_wg(g);
   if (wg < 0) return;
 

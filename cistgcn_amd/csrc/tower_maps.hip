@@ -64,7 +64,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
   float* sX = reinterpret_cast<float*>(cg_dyn_lds);              // [CinM][PS]
   float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
   double* sStat = reinterpret_cast<double*>(sW + g.MM * g.WS + ((g.CinM * g.PS + g.MM * g.WS) & 1));      // [MM][2]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
   float xbuf[16];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   float* sD = reinterpret_cast<float*>(cg_dyn_lds);              // [MM][PS]   dy of every map, stacked
   float* sX = sD + g.MM * g.PS;                                   // [CinM][PS]
   float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, slot = lane >> 4, nw = CG_PWM_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_PWM_THREADS / 64;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
   float xbuf[16], dbuf[16];
