@@ -119,16 +119,19 @@ __device__ __forceinline__ void cg_tail_keep4(const CgDstdTail& t, int i, unsign
 // GEMM phases call `load` for tile k+1 right before the matrix-core work of tile k, so the reads travel while the MFMAs run.
 template <int PT>
 __device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int p0, int np, float4 yq[PT / 8], float4 rq[PT / 8]) {
+  // quads q < PT / 16 belong to branch 0, the others to branch 1: the branch (and with it the base pointers) is uniform per
+  // quad slot, so the addresses are scalar base + 32-bit lane offset (C <= 64: C * PT / 4 work items per branch fit PT / 16 slots)
   const int C = t.C, P = t.T * t.V;
 #pragma unroll
   for (int q = 0; q < PT / 8; ++q) {
-    const int e = threadIdx.x + q * CG_TAIL_THREADS;
-    const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
+    const int i = q / (PT / 16), e = threadIdx.x + (q - i * (PT / 16)) * CG_TAIL_THREADS;
+    const int c = e / (PT / 4), pp = 4 * (e - c * (PT / 4));
     yq[q] = make_float4(0.f, 0.f, 0.f, 0.f); rq[q] = yq[q];
-    if (c2 < 2 * C && pp < np) {
-      const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
-      const long long off = ((long long)b * C + c) * P + p0 + pp;
-      yq[q] = *reinterpret_cast<const float4*>(t.y[i] + off); rq[q] = *reinterpret_cast<const float4*>(t.r[i] + off);
+    if (c < C && pp < np) {
+      const float* yb = t.y[i] + (long long)b * C * P + p0;
+      const float* rb = t.r[i] + (long long)b * C * P + p0;
+      const int off = c * P + pp;
+      yq[q] = *reinterpret_cast<const float4*>(yb + off); rq[q] = *reinterpret_cast<const float4*>(rb + off);
     }
   }
 }
@@ -140,12 +143,11 @@ __device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const fl
   const int C = t.C, P = t.T * t.V;
 #pragma unroll
   for (int q = 0; q < PT / 8; ++q) {
-    const int e = threadIdx.x + q * CG_TAIL_THREADS;
-    const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
-    if (c2 >= 2 * C) continue;
+    const int i = q / (PT / 16), e = threadIdx.x + (q - i * (PT / 16)) * CG_TAIL_THREADS;       // same slots as cg_tail_act_load
+    const int c = e / (PT / 4), pp = 4 * (e - c * (PT / 4)), c2 = i * C + c;
+    if (c >= C) continue;
     float val[4] = {0.f, 0.f, 0.f, 0.f};
     if (pp < np) {
-      const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
       const float4 k0 = *reinterpret_cast<const float4*>(sK + 8 * c2), k1 = *reinterpret_cast<const float4*>(sK + 8 * c2 + 4);
       const long long off = ((long long)b * C + c) * P + p0 + pp;
       const float yv[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w}, rv[4] = {rq[q].x, rq[q].y, rq[q].z, rq[q].w};
@@ -175,12 +177,15 @@ __device__ __forceinline__ void cg_tail_stage_act(const CgDstdTail& t, const flo
   constexpr int PS = PT + 4;
   const int C = t.C, P = t.T * t.V;
   if ((P & 3) == 0) {
-#pragma unroll 4
-    for (int e = threadIdx.x; e < 2 * C * (PT / 4); e += CG_TAIL_THREADS) {
-      const int c2 = e / (PT / 4), pp = 4 * (e - c2 * (PT / 4));
+    // branch by branch: the branch index (base pointers, gate row, slopes) is uniform, addresses are scalar base + 32-bit lane offset
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll 2
+    for (int e = threadIdx.x; e < C * (PT / 4); e += CG_TAIL_THREADS) {
+      const int c = e / (PT / 4), pp = 4 * (e - c * (PT / 4)), c2 = i * C + c;
       float val[4] = {0.f, 0.f, 0.f, 0.f};
       if (pp < np) {                                       // np % 4 == 0 here: a quad is inside the tile or outside
-        const int i = c2 >= C ? 1 : 0, c = c2 - i * C, p = p0 + pp;
+        const int p = p0 + pp;
         const float4 k0 = *reinterpret_cast<const float4*>(sK + 8 * c2), k1 = *reinterpret_cast<const float4*>(sK + 8 * c2 + 4);
         const long long off = ((long long)b * C + c) * P + p;
         const float4 y4 = *reinterpret_cast<const float4*>(t.y[i] + off), r4 = *reinterpret_cast<const float4*>(t.r[i] + off);

@@ -401,7 +401,9 @@ def test_two_ranks_on_one_gpu_match_oracle_per_shard():
     for i, _ in enumerate(res[0][2]):
         ref = sum(shards[r] / tot * res[r][2][i] for r in range(2))
         got = res[0][0][offs[i]:offs[i] + ref.size].reshape(ref.shape)
-        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(0.1, float(np.abs(ref).max()))
+        # floor 0.25 as in the strict single-GPU tests of this size class (train mode, batch statistics over 6 and 10 samples: the
+        # first tensor sat at 0.7 .. 1.04 of a 0.1 floor from run to run, fp32 atomics order)
+        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(0.25, float(np.abs(ref).max()))
         assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
 
 
