@@ -36,7 +36,7 @@ struct CgDomP {
   int NTC, TC;               // chunks of frames per sample, frames per chunk (<= 16)
   int CinR, XS;              // rows / row stride of the x piece sX[CinR][XS] (and of sdZ[16][XS])
   int GZ, GY, YS;            // sZ[V][16][16] group stride; sY[V][16][YS] group / row stride
-  int zfl, yfl, bwd_floats;  // floats of sZ, sY, the whole LDS image
+  int zfl, yfl, dzfl, bwd_floats;  // floats of sZ, sY, sdZ (= second dY image), the whole LDS image
   int VWP, VWY, VWA;         // floats per lane: x piece / dx rows, dY pieces, slab rows
 };
 int cg_domp_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V, int domain);

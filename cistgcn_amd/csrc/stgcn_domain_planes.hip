@@ -300,9 +300,9 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
                                                                   float* __restrict__ dx, float* __restrict__ dadj,
                                                                   float* __restrict__ ws, int replicas, CgDomP g) {
   float* sX = reinterpret_cast<float*>(cg_dyn_lds);       // [CinR][XS]
-  float* sdZ = sX + g.CinR * g.XS;                        // [16][XS]
-  float* sZ = sdZ + 16 * g.XS;                            // [V][GZ]   ([16 o][16 t] per joint)
-  float* sY = sZ + g.zfl;                                 // [V][GY]   ([16 o][YS q] per joint)
+  float* sdZ = sX + g.CinR * g.XS;                        // [16][XS]; the same memory is the SECOND dY image (odd pieces)
+  float* sZ = sdZ + g.dzfl;                               // [V][GZ]   ([16 o][16 t] per joint)
+  float* sY = sZ + g.zfl;                                 // [V][GY]   ([16 o][16 q] per joint, column-swizzled): even pieces
   float* sW = sY + g.yfl;                                 // [16][WS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform for the compiler: scalar address arithmetic
   const int l15_ = lane & 15, slot_ = lane >> 4;
@@ -337,16 +337,17 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
       }
     };
     x_load(4 * wave);
-    // zeroed once: the pad columns [Pn, XS) of sX and sdZ and the channel rows beyond Cin (operands of the dW product and of
-    // tiles that reach beyond the piece), sZ (frames beyond the chunk stay zero), sY (frames beyond T must stay finite)
+    // zeroed once: the pad columns [Pn, XS) of sX and its channel rows beyond Cin (operands of the dW product and of tiles that
+    // reach beyond the piece), sdZ, sZ (frames beyond the chunk stay zero), both dY images (frames beyond T must stay finite)
     {
-      const int padc = XS - Pn, nrow = g.CinR + 16;
+      const int padc = XS - Pn, nrow = g.CinR;
       for (int e = tid; e < nrow * padc; e += CG_DOMPB_THREADS) {
         const int r = e / padc, c = e - r * padc;
         sX[r * XS + Pn + c] = 0.f;
       }
       for (int e = tid; e < (g.CinR - Cin) * Pn; e += CG_DOMPB_THREADS) sX[(Cin + e / Pn) * XS + e % Pn] = 0.f;
-      for (int e = tid; e < g.zfl + g.yfl + 16 * WS + CG_DOMPB_NW * 256 + 64; e += CG_DOMPB_THREADS) sZ[e] = 0.f;
+      // sdZ / second dY image, sZ, sY, sW in one sweep (they are contiguous)
+      for (int e = tid; e < g.dzfl + g.zfl + g.yfl + 16 * WS; e += CG_DOMPB_THREADS) sdZ[e] = 0.f;
     }
     __syncthreads();
     CG_STAMP();                                       // 2: LDS zeroed
@@ -360,7 +361,10 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   // moves vector k of run o
   float pf[PF][VWY];
   const int po = tid >> 5, pk = tid & 31;
-  auto piece_load = [&](int oc, int qc) {
+  // pieces are numbered n = oc * NQC + qc; piece n lives in the dY image (n % NQC) & 1 (0: sY, 1: the sdZ memory)
+  const int NPIECES = g.NOC * NQC;
+  auto piece_load = [&](int n) {
+    const int oc = n / NQC, qc = n - oc * NQC;
     const int q0 = 16 * qc, runv = min(16, T - q0) * V / VWY, co = oc * 16 + po;
     const float* src = dy + ((long long)(b * Cout + oc * 16) * T + q0) * V;        // uniform
     const int voff = po * g.TV + pk * VWY;
@@ -384,16 +388,18 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
         pso[i][jj] = v * GY + po * 16 + ((q & 15) ^ sw);
       }
   }
-  auto piece_store = [&](int qc) {
-    const int runv = min(16, T - 16 * qc) * V / VWY;
+  auto piece_store = [&](int n) {
+    const int qc = n % NQC, runv = min(16, T - 16 * qc) * V / VWY;
+    float* img = (qc & 1) ? sdZ : sY;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       if (pk + 32 * i < runv) {
 #pragma unroll
-        for (int jj = 0; jj < VWY; ++jj) sY[pso[i][jj]] = pf[i][jj];
+        for (int jj = 0; jj < VWY; ++jj) img[pso[i][jj]] = pf[i][jj];
       }
     }
   };
+  int pfn = 0;                                          // piece held (loaded, not yet stored) by the pf registers; NPIECES: none
 
   cg_f32x4 dAacc[NJW][4];
 #pragma unroll
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   auto dw_flush = [&](int ocp) {
     if (wks == 0) {
       cg_f32x4 sum = dWhold;
-      for (int ks = 1; ks < nks; ++ks) sum += *reinterpret_cast<const cg_f32x4*>(sPart + ((wct + ks * MTc) * 64 + lane) * 4);
+      for (int ks = 1; ks < nks; ++ks) sum += *reinterpret_cast<const cg_f32x4*>(sPart + ((wct + (ks - 1) * MTc) * 64 + lane) * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = ocp * 16 + 4 * slot_ + r, c = 16 * wct + l15_;
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
   };
   float ar[NJW][4];
   rows_load(0, ar);
-  piece_load(0, 0);
+  piece_load(0);
   // weights of the next chunk of output channels travel in registers while the current chunk computes
   float wq[3];
   auto w_load = [&](int oc) {
@@ -463,7 +469,10 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
     for (int i = 0; i < 3; ++i)
       if (tid + i * CG_DOMPB_THREADS < 16 * WS) sW[tid + i * CG_DOMPB_THREADS] = wq[i];
     if (oc + 1 < g.NOC) w_load(oc + 1);
-    piece_store(0);
+    if (pfn == oc * NQC) {                             // the chunk's first piece is still in registers (first chunk; one piece per chunk; odd NQC)
+      piece_store(pfn);
+      if (++pfn < NPIECES) piece_load(pfn);
+    }
     cg_f32x4 dZacc[NJW];
 #pragma unroll
     for (int a = 0; a < NJW; ++a) dZacc[a] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -478,7 +487,8 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
     // into scratch; scratch reloads count in vmcnt and would make every phase wait for the global prefetches in flight)
     CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
     for (int pt = wave; pt < NPT; pt += 2 * CG_DOMPB_NW) {
-      const int pt1 = pt + CG_DOMPB_NW < NPT ? pt + CG_DOMPB_NW : pt;     // (recomputes the same tile when there is no partner)
+      const bool pair = pt + CG_DOMPB_NW < NPT;                           // the last tiles have no partner: one accumulator then
+      const int pt1 = pair ? pt + CG_DOMPB_NW : pt;
       cg_f32x4 acc0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
       const float* ap = sW + l15 * WS + slot;
       const float* bp0 = sX + slot * XS + 16 * pt + l15;
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[4 + s2], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], acc1, 0, 0, 0);
+          if (pair) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f[s2], f[8 + s2], acc1, 0, 0, 0);
         }
       };
       s2_ld(0, fa);
@@ -524,8 +534,17 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
 #pragma nounroll
     for (int qc = 0; qc < NQC; ++qc) {
       {
-        if (qc + 1 < NQC) piece_load(oc, qc + 1);
-        else if (oc + 1 < g.NOC) piece_load(oc + 1, 0);
+        // one barrier per piece: every wave is done with S4 of the previous piece, so the OTHER dY image is free, and the stores
+        // of the current piece (made during that S4) are visible.  The piece in the pf registers (requested a whole S4 ago) goes
+        // into the other image now - unless that is the image being read (first piece of the next chunk when NQC is odd or 1:
+        // it waits for the top of the next chunk) - and the one after it is requested.
+        if (qc > 0) __syncthreads();
+        const int n = oc * NQC + qc;
+        if (pfn == n + 1 && pfn < NPIECES && (((pfn % NQC) ^ qc) & 1)) {
+          piece_store(pfn);
+          if (++pfn < NPIECES) piece_load(pfn);
+        }
+        const float* sYc = (qc & 1) ? sdZ : sY;
         // S4
         const int q0 = 16 * qc;
         CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
@@ -539,7 +558,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
             for (int a = 0; a < NJW; ++a) {
               const int v = min(wave + CG_DOMPB_NW * a, V - 1);
               const float* zp = sZ + v * GZ + slot * 16 + l15;
-              const float* yp = sY + v * GY + slot * 16;
+              const float* yp = sYc + v * GY + slot * 16;
 #pragma unroll
               for (int st = 0; st < 4; ++st) {
                 za[a][st] = zp[4 * st * 16];
@@ -559,7 +578,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
 #pragma unroll
             for (int a = 0; a < NJW; ++a) {
               const int v = min(wave + CG_DOMPB_NW * a, V - 1);
-              const float* yq = sY + v * GY + l15 * 16;
+              const float* yq = sYc + v * GY + l15 * 16;
 #pragma unroll
               for (int st = 0; st < 4; ++st) yb[a][st] = yq[(4 * slot + st) ^ sw];
             }
@@ -580,17 +599,10 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
         // slab rows of the next piece: requested behind the dY piece (vmcnt retires in order: the piece is waited for first, by
         // piece_store, and these rows are not needed before the next S4 has done its dA products)
         rows_load(qc + 1 < NQC ? qc + 1 : 0, ar);
-        CG_STAMP();                                   // q+0: S4 done
-        if (qc + 1 < NQC) {
-          __syncthreads();
-          CG_STAMP();                                 // q+1
-          piece_store(qc + 1);
-          CG_STAMP();                                 // q+2: piece stored (includes the wait for its loads)
-          __syncthreads();
-          CG_STAMP();                                 // q+3
-        }
+        CG_STAMP();                                   // S4 of the piece done
       }
     }
+    __syncthreads();                                  // every S4 of the chunk is done: the sdZ memory may take dZ now
 
     // S5
     CG_OPAQUE_V(l15); CG_OPAQUE_V(slot);
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(CG_DOMPB_THREADS, 2) void cg_stgcn_planes_bwd_kerne
         for (int s2 = 0; s2 < 4; ++s2) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s2], b0[s2], c0, 0, 0, 0);
       }
       if (wks == 0) dWhold = c0;
-      else *reinterpret_cast<cg_f32x4*>(sPart + (wave * 64 + lane) * 4) = c0;
+      else *reinterpret_cast<cg_f32x4*>(sPart + ((wave - MTc) * 64 + lane) * 4) = c0;
     }
     {
       // dx: the channel tile of a wave is fixed (8 % MTc == 0), its weight fragments are read once per chunk
@@ -1152,14 +1164,16 @@ int cg_domp_bwd_geom(CgDomP& g, int B, int Cin, int Cout, int T, int V) {
       const int last = T - (ntc - 1) * tc;
       const int al = ((tc * V) % 4 == 0 && (last * V) % 4 == 0 && g.TV % 4 == 0) ? 4 : ((tc * V) % 2 == 0 && (last * V) % 2 == 0 && g.TV % 2 == 0) ? 2 : 1;
       const int xs = cg_domp_xs(tc * V);
-      const size_t bytes = ((size_t)(g.CinR + 16) * xs + g.zfl + g.yfl + 16 * (size_t)g.WS + CG_DOMPB_NW * 256 + 64) * sizeof(float);
+      const int dzfl = 16 * xs > g.yfl ? 16 * xs : g.yfl;          // sdZ [16][XS] / second dY image
+      const size_t bytes = ((size_t)g.CinR * xs + dzfl + g.zfl + g.yfl + 16 * (size_t)g.WS + CG_DOMPB_NW * 256 + 64) * sizeof(float);
       if (bytes > limit || (g.CinR / 16) * ((tc * V + 15) / 16) > CG_DOMPB_NDX * CG_DOMPB_NW || tc * V > 128 * al) continue;      // x piece: two vectors per lane and plane row
       if (al > best_al) { best = tc; best_al = al; }
     }
     if (best) {
       g.NTC = ntc; g.TC = best; g.VWP = best_al;
       g.XS = cg_domp_xs(best * V);
-      g.bwd_floats = (g.CinR + 16) * g.XS + g.zfl + g.yfl + 16 * g.WS + CG_DOMPB_NW * 256 + 64;
+      g.dzfl = 16 * g.XS > g.yfl ? 16 * g.XS : g.yfl;
+      g.bwd_floats = g.CinR * g.XS + g.dzfl + g.zfl + g.yfl + 16 * g.WS + CG_DOMPB_NW * 256 + 64;
       const int lastq = T - 16 * ((T + 15) / 16 - 1);
       g.VWY = (g.TV % 4 == 0 && (lastq * V) % 4 == 0) ? 4 : (g.TV % 2 == 0 && (lastq * V) % 2 == 0) ? 2 : 1;
       g.VWA = T % 4 == 0 ? 4 : T % 2 == 0 ? 2 : 1;
