@@ -179,7 +179,7 @@ _SIGNATURES = {
     "cg_map2adj_tail_ws_floats": [c_int],
     "cg_map2adj_tail_part_floats": [c_int, c_int, c_int],
     "cg_map2adj_tail_red_doubles": [c_int],
-    "cg_augment_sequences": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "cg_augment_sequences": [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "cg_adam_flat": [P, P, P, P, LL, c_float, c_float, c_float, c_float, c_float, c_float, c_float, LL, P],
 }
 EXPORTS = tuple(sorted(_SIGNATURES))

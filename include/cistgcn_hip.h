@@ -327,13 +327,17 @@ int cg_eval_scatter_mpjpe(const float* pred, const float* target, float* out, fl
 
 /* ---- on-device input pipeline -----------------------------------------------------------------
  * The training augmentations of environment/custom_transforms.py (RandomFlip :243-298, RandomRotation :10-84, RandomScale
- * :87-161, RandomTranslation :164-240; order of loaders/loader.py:42-130) and the per-item tensors of
- * loaders/h36m_motion_3d.py:94-108 for a whole batch in one launch.  raw (B,L,J,3); params (B,20) = per sequence
- * [flip x,y,z | rotate? | R 3x3 row-major (p' = (p-c) R + c) | scale x,y,z | translation rate x,y,z | pad], drawn on the host
- * in the reference's order; outputs sample (B,input_n,J,3), target (B,L-input_n,J,3), target_vel (same shape, cumulative
- * frame differences from frame input_n-1 on), target_gvel (B,L-input_n,J,1) cumulative speeds, processed (B,L,J,3) or NULL. */
+ * :87-161, RandomNoise :350-400, RandomTranslation :164-240, RandomPoseInvers :301-347; order of loaders/loader.py:42-130) and
+ * the per-item tensors of loaders/h36m_motion_3d.py:94-108 for a whole batch in one launch.  raw (B,L,J,3); params (B,24) = per
+ * sequence [flip x,y,z | rotate? | R 3x3 row-major (p' = (p-c) R + c) | scale x,y,z | translation rate x,y,z | noise amplitude
+ * (0: off) | invert? | pad], drawn on the host in the reference's order; noise_tab (B,J,3) the U(-1,1) draws of RandomNoise or
+ * NULL; perm (J) the joint permutation the pair swaps of RandomPoseInvers compose to, or NULL; outputs sample (B,input_n,J,3),
+ * target (B,L-input_n,J,3), target_vel (same shape, cumulative frame differences from frame input_n-1 on), target_gvel
+ * (B,L-input_n,J,1) cumulative speeds, processed (B,L,J,3) or NULL, sample_vel (B,input_n,J,3) = frame differences of the input
+ * frames or NULL (the same dictionary comes out of loaders/amass_motion_3d.py:76-91). */
 int cg_augment_sequences(const float* raw, const float* params, float* sample, float* target, float* target_vel,
-                         float* target_gvel, float* processed, int B, int L, int J, int input_n, void* stream);
+                         float* target_gvel, float* processed, float* sample_vel, const float* noise_tab, const int32_t* perm,
+                         int B, int L, int J, int input_n, void* stream);
 
 /* ---- optimizer on the flat parameter buffer -----------------------------------
  * torch.optim.Adam semantics (environment/utils.py:53-57): L2 weight decay added to the gradient,

@@ -502,6 +502,7 @@ def test_device_input_pipeline_matches_reference():
     import test_environment as te
     from cistgcn_amd.environment import DeviceAugmentation, DevicePrefetcher
     te.check_augmentation_golden("cuda")
+    te.check_augmentation_noise_inversion_golden("cuda")
     te.check_augmentation_vs_oracle("cuda", B=64, L=75, J=25, input_n=50)
     te.check_augmentation_vs_oracle("cuda", B=5, L=35, J=18, input_n=10, seed=12)
     aug = DeviceAugmentation(te._aug_cfg())

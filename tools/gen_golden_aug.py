@@ -53,21 +53,53 @@ orig_uniform = np.random.uniform
 
 def logged(*a, **k):
     v = orig_uniform(*a, **k)
-    draws.append(float(v))
+    if isinstance(v, np.ndarray):                 # RandomNoise draws a (joints, 3) array in one call
+        draws.extend(float(t) for t in v.reshape(-1))
+    else:
+        draws.append(float(v))
     return v
 
 
 np.random.seed(2024)
 np.random.uniform = logged
-out = {"sample": [], "target": [], "target_vel": [], "target_gvel": [], "processed": [], "ndraws": []}
+out = {"sample": [], "sample_vel": [], "target": [], "target_vel": [], "target_gvel": [], "processed": [], "ndraws": []}
 for i in range(B):
     n0 = len(draws)
     item = ds[i]
     out["ndraws"].append(len(draws) - n0)
-    for k in ("sample", "target", "target_vel", "target_gvel", "processed"):
+    for k in ("sample", "sample_vel", "target", "target_vel", "target_gvel", "processed"):
         out[k].append(np.asarray(item[k], dtype=np.float32))
 np.random.uniform = orig_uniform
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "aug_h36m.npz")
 np.savez_compressed(path, raw=ds.target, draws=np.array(draws, dtype=np.float64), ndraws=np.array(out["ndraws"]),
                     input_n=np.array(Tin), **{k: np.stack(v) for k, v in out.items() if k != "ndraws"})
 print("wrote", os.path.normpath(path), "draws per sample:", out["ndraws"], "shapes:", {k: np.stack(v).shape for k, v in out.items() if k != "ndraws"})
+
+# ---- second fixture: the same chain with RandomNoise (loader.py:62-64, a bare amplitude) and RandomPoseInvers (:121-125, always the
+# "h36m" mapping, whose pairs index the 32-joint skeleton) on 32-joint windows
+body_utils = importlib.import_module("human_motion_prediction.utils.body_utils")
+NOISE = 0.02
+chain[:] = [trs.ToTensor(), trs.RandomFlip(AUG.random_flip.x, AUG.random_flip.y, AUG.random_flip.z),
+            trs.RandomRotation(AUG.random_rotation.x, AUG.random_rotation.y, AUG.random_rotation.z),
+            trs.RandomScale(AUG.random_scale.x, AUG.random_scale.y, AUG.random_scale.z),
+            trs.RandomNoise(NOISE),
+            trs.RandomTranslation(AUG.random_translation.x, AUG.random_translation.y, AUG.random_translation.z),
+            trs.RandomPoseInvers("h36m", 0.5, [], True)]
+B, Tin, Tout, J = 10, 10, 25, 32
+g = np.random.RandomState(321)
+ds.target = (50 + 350 * g.randn(B, Tin + Tout, J, 3)).astype(np.float32)
+draws.clear()
+np.random.seed(777)
+np.random.uniform = logged
+out = {"sample": [], "sample_vel": [], "target": [], "target_vel": [], "target_gvel": [], "processed": [], "ndraws": []}
+for i in range(B):
+    n0 = len(draws)
+    item = ds[i]
+    out["ndraws"].append(len(draws) - n0)
+    for k in ("sample", "sample_vel", "target", "target_vel", "target_gvel", "processed"):
+        out[k].append(np.asarray(item[k], dtype=np.float32))
+np.random.uniform = orig_uniform
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "aug_h36m_noise_inv.npz")
+np.savez_compressed(path, raw=ds.target, draws=np.array(draws, dtype=np.float64), ndraws=np.array(out["ndraws"]), input_n=np.array(Tin),
+                    noise=np.array(NOISE), **{k: np.stack(v) for k, v in out.items() if k != "ndraws"})
+print("wrote", os.path.normpath(path), "draws per sample:", out["ndraws"])
