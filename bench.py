@@ -497,7 +497,7 @@ def timed_training(workload, args, device, rank, world, steps, warmup, batch=Non
            "shard_weight": getattr(step, "weight", None),
            "buckets": len(step.flat.buckets) if world > 1 else None,
            "bucket_bytes": [4 * int(step.flat.bucket_view(k).numel()) for k in range(len(step.flat.buckets))] if world > 1 else None,
-           "per_rank": None}
+           "per_rank": None, "overlap_probe": getattr(step, "overlap_probe", None) if world > 1 else None}
     if world > 1:          # per-GPU batch and gradient weight of every rank (mixed batches: B_r * world / sum B)
         per = [None] * world
         dist.all_gather_object(per, {"rank": rank, "batch": B, "shard_weight": getattr(step, "weight", None)})
@@ -604,6 +604,7 @@ def main():
                    "capture_probe_ms": res["capture_ms"], "capture_kept": "median" if res["capture_ms"] else None,
                    "collective": ("rccl" if args.backend == "nccl" else "gloo") if world > 1 else None,
                    "gradient_buckets": res["buckets"], "gradient_bucket_bytes": res["bucket_bytes"], "per_rank": res["per_rank"],
+                   "side_stream_probe": res["overlap_probe"],
                    "mixed_batches": bool(batch), "loss": res["loss"]},
     }
     if rank == 0 and world == 1:

@@ -397,6 +397,21 @@ __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
   }
 }
 
+// Diagnostic build only (tools/stamps_tail.py compiles a private copy of the library with -DCG_TAIL_STAMPS): thread 0 of every
+// workgroup stores the shader clock at the phase boundaries of K3; nothing depends on it, the shipped library has no stamp.
+#ifdef CG_TAIL_STAMPS
+__device__ unsigned long long* cg_tail_stamp_buf = nullptr;
+extern "C" int cg_tail_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(cg_tail_stamp_buf), &p, sizeof(p)); }
+#define CG_TSTAMP()                                                                                     \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && cg_tail_stamp_buf && nst < 255) cg_tail_stamp_buf[blockIdx.x * 256 + (++nst)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define CG_TSTAMP_END() do { if (threadIdx.x == 0 && cg_tail_stamp_buf) cg_tail_stamp_buf[blockIdx.x * 256] = nst; } while (0)
+#else
+#define CG_TSTAMP() do { } while (0)
+#define CG_TSTAMP_END() do { } while (0)
+#endif
+
 // K3: per tile: dh0 (BatchNorm backward of g_c), d a = Wc^T dh0, dWc += dh0 a^T, g_p = d a * PReLU_p' -> HBM + its sums
 __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTail t, int tiles_per_sample, int total, int per, int replicas) {
   const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
@@ -410,6 +425,8 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_TAIL_THREADS / 64;
   const int wg = blockIdx.x;
   if (wg * per >= total) return;
+  int nst = 0; (void)nst;
+  CG_TSTAMP();
   for (int e = tid; e < C2M * CG_TAIL_PS3 + CM * CG_TAIL_PS3 + CM * WS; e += CG_TAIL_THREADS) sZ[e] = 0.f;
   for (int e = tid; e < 2 * C2M + 2; e += CG_TAIL_THREADS) sRed[e] = 0.0;
   __syncthreads();
@@ -430,31 +447,54 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
 #pragma unroll
   for (int u = 0; u < CG_TAIL_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float alpha_c = t.alpha_c[0];
+  const float alpha_p0 = t.alpha_p[0][0], alpha_p1 = t.alpha_p[1][0];      // once: a global load inside the matrix phases stalls every task
   float racc[CG_TAIL_K3_TASKS][4][3];              // per lane: sums of g_p, g_p * zhat and the d alpha_p terms of the wave's d a tasks
 #pragma unroll
   for (int i = 0; i < CG_TAIL_K3_TASKS * 12; ++i) (&racc[0][0][0])[i] = 0.f;
+  CG_TSTAMP();
+  // Loads of a tile travel while something else runs: y / r of tile k+1 are issued in front of the matrix phases of tile k
+  // (registers yq / rq), h0 / dout / gate / dpooled of tile k in front of the VALU work that builds the zhat image
+  const bool vec = (P & 3) == 0;
+  constexpr int DQ = CG_TAIL_PT3 / 16;               // quads of the dh0 image per thread (C <= 64)
+  float4 yq[CG_TAIL_PT3 / 8], rq[CG_TAIL_PT3 / 8];
+  if (vec) {
+    const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT3;
+    cg_tail_act_load<CG_TAIL_PT3>(t, b, p0, min(CG_TAIL_PT3, P - p0), yq, rq);
+  }
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
     if (lid >= total) break;
     const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT3, np = min(CG_TAIL_PT3, P - p0);
     __syncthreads();
-    cg_tail_stage_act<CG_TAIL_PT3>(t, sK, seed, b, p0, np, sZ, 1);
-    // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
-    if ((P & 3) == 0) {
-#pragma unroll 2
-      for (int e = tid; e < C * (CG_TAIL_PT3 / 4); e += CG_TAIL_THREADS) {
-        const int c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
+    CG_TSTAMP();
+    if (vec) {
+      float4 h4[DQ], d4[DQ];
+      float gt[DQ], dp[DQ];
+#pragma unroll
+      for (int q = 0; q < DQ; ++q) {
+        const int e = tid + q * CG_TAIL_THREADS, c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
+        h4[q] = make_float4(0.f, 0.f, 0.f, 0.f); d4[q] = h4[q]; gt[q] = 0.f; dp[q] = 0.f;
+        if (c < C && pp < np) {
+          const long long off = ((long long)b * C + c) * P + p0 + pp;
+          h4[q] = *reinterpret_cast<const float4*>(t.h0 + off); d4[q] = *reinterpret_cast<const float4*>(t.dout + off);
+          gt[q] = t.gate[(long long)b * C + c]; dp[q] = t.dpooled[(long long)b * C + c] * invP;
+        }
+      }
+      cg_tail_act_finish<CG_TAIL_PT3>(t, sK, seed, b, p0, np, yq, rq, sZ, 1);
+      CG_TSTAMP();
+      // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
+#pragma unroll
+      for (int q = 0; q < DQ; ++q) {
+        const int e = tid + q * CG_TAIL_THREADS, c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
+        if (c >= C) continue;
         float val[4] = {0.f, 0.f, 0.f, 0.f};
         if (pp < np) {
           const float* kc = sKc + 8 * c;                  // mean, rstd, scale = gamma * rstd, beta, m1, m2
-          const long long off = ((long long)b * C + c) * P + p0 + pp;
-          const float4 h4 = *reinterpret_cast<const float4*>(t.h0 + off), d4 = *reinterpret_cast<const float4*>(t.dout + off);
-          const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-          const float gt = t.gate[(long long)b * C + c], dp = t.dpooled[(long long)b * C + c] * invP;
+          const float hv[4] = {h4[q].x, h4[q].y, h4[q].z, h4[q].w}, dv[4] = {d4[q].x, d4[q].y, d4[q].z, d4[q].w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float u = (hv[j] - kc[0]) * kc[2] + kc[3];
-            const float dh = dv[j] * gt + dp;
+            const float dh = dv[j] * gt[q] + dp[q];
             const float g = u > 0.f ? dh : alpha_c * dh;
             val[j] = t.train ? kc[2] * (g - kc[4] - (hv[j] - kc[0]) * kc[1] * kc[5]) : g * kc[2];
           }
@@ -462,6 +502,8 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         *reinterpret_cast<float4*>(sDH + c * CG_TAIL_PS3 + pp) = make_float4(val[0], val[1], val[2], val[3]);
       }
     } else {
+      cg_tail_stage_act<CG_TAIL_PT3>(t, sK, seed, b, p0, np, sZ, 1);
+      CG_TSTAMP();
       for (int e = tid; e < C * CG_TAIL_PT3; e += CG_TAIL_THREADS) {
         const int c = e / CG_TAIL_PT3, pp = e - c * CG_TAIL_PT3;
         float val = 0.f;
@@ -478,6 +520,11 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       }
     }
     __syncthreads();
+    if (vec && it + 1 < per && lid + 1 < total) {
+      const int b2 = (lid + 1) / tiles_per_sample, q0 = (lid + 1 - b2 * tiles_per_sample) * CG_TAIL_PT3;
+      cg_tail_act_load<CG_TAIL_PT3>(t, b2, q0, min(CG_TAIL_PT3, P - q0), yq, rq);
+    }
+    CG_TSTAMP();
     // dWc[co][c2] += sum_p dh0[co][p] a[c2][p],  a = PReLU_p(gamma zhat + beta) rebuilt from zhat in the B fragments
 #pragma unroll
     for (int u = 0; u < CG_TAIL_MAXW; ++u) {
@@ -486,7 +533,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         const int mt = id / NT2, n2 = id - mt * NT2, c2 = 16 * n2 + l15;
         const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
         const bool cok = c2 < C2;
-        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (i ? alpha_p1 : alpha_p0) : 0.f;
         (void)c;
         const float* ap = cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
         const float* bp = cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot);
@@ -502,6 +549,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         }
       }
     }
+    CG_TSTAMP();
     // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat
     // (per lane in registers over all tiles of the workgroup: a wave owns the same (at most CG_TAIL_K3_TASKS) c2 tiles in every tile)
 #pragma unroll
@@ -527,7 +575,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         const int c2 = 16 * mt + 4 * slot + q;
         const bool cok = c2 < C2;
         const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
-        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? t.alpha_p[i][0] : 0.f;
+        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (i ? alpha_p1 : alpha_p0) : 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pp = (h ? n1 : n0) + l15;
@@ -543,6 +591,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       }
     }
   }
+  CG_TSTAMP();
   // one cross-lane reduction for all tiles (a row of 16 lanes holds the positions of a channel)
 #pragma unroll
   for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
@@ -576,6 +625,8 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       }
     }
   }
+  CG_TSTAMP();
+  CG_TSTAMP_END();
 }
 
 // K4: dz = BN_p'(g_p); dw = sum dz * x; g_d = w * dz * PReLU_d'(u) -> dr (HBM); sums of g_t = g_d * keep for the tcn BatchNorm.

@@ -437,13 +437,77 @@ class DataParallelStep(_StepBase):
             flat.set_buckets([k])                # bucket 0 = blocks [0, cut] (gradients land last), bucket 1 = the rest
         self._cut_in = self._cut_leaf = None
         self.graphs = None
-        self._side = torch.cuda.Stream(device=x.device) if x.is_cuda else None
+        self._side, self.overlap_probe = None, None
         self.force_collective = False     # run the all-reduce in a one-rank group too (overlap measurements on one GPU)
+        if x.is_cuda:
+            self.pick_side_stream(collective=self.world > 1)
         self.record_events = False        # replay() then leaves HIP events of both streams in self.events
         self.events = None
         if graph:
             self._capture(warmup)
         self._freeze_param_pointers()
+
+    def pick_side_stream(self, collective=False, tries=8, new_groups=3):
+        """HIP maps its streams onto a few hardware queues, and two streams on the same queue run one after the other whatever
+        the program says (measured on the MI355X box: about one pool stream in eight delays the default stream,
+        tools/diag_stream_overlap.py; the stream the nccl backend launches its collectives on can be such a stream, and then
+        every all-reduce - behind whatever it waits for - sits in front of the main stream's next kernel).  The side stream of
+        the early bucket is therefore CHOSEN: a ~0.3 ms spin kernel goes on a candidate (with `collective`, followed by a
+        one-element all-reduce of the group, whose own stream then waits behind the spin), an event on the main stream says
+        whether the main stream ran beside it.  When no candidate passes with the collective in the chain, the group itself is
+        replaced (`dist.new_group` over the same ranks gets another stream for its collectives; all ranks decide together) up
+        to `new_groups` times.  `overlap_probe` keeps the evidence: {"independent", "collective", "main_ms", "side_ms",
+        "tried", "groups"}."""
+        import torch.distributed as dist
+        dev = self.x.device
+        main = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(200000)
+        e0.record(); torch.cuda._sleep(200000); e1.record(); torch.cuda.synchronize()
+        spin = int(200000 * 0.3 / max(e0.elapsed_time(e1), 1e-3))
+        collective = bool(collective and dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl")
+        tiny = torch.zeros(1, device=dev) if collective else None
+        kept, last = [], None
+
+        def probe(group):
+            nonlocal last
+            if collective:
+                dist.all_reduce(tiny, group=group)              # communicator and its stream exist before the probe
+            for n in range(1, tries + 1):
+                cand = torch.cuda.Stream(device=dev)
+                kept.append(cand)                               # rejected candidates stay alive: the next one is another stream
+                torch.cuda.synchronize()
+                a, b, c = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                a.record()
+                cand.wait_stream(main)
+                with torch.cuda.stream(cand):
+                    torch.cuda._sleep(spin)
+                    if collective:
+                        dist.all_reduce(tiny, group=group, async_op=True).wait()
+                    c.record()
+                b.record()
+                torch.cuda.synchronize()
+                last = {"independent": a.elapsed_time(b) < 0.5 * a.elapsed_time(c), "collective": collective,
+                        "main_ms": round(a.elapsed_time(b), 4), "side_ms": round(a.elapsed_time(c), 4), "tried": n}
+                if last["independent"]:
+                    return True
+            return False
+
+        groups = 0
+        while True:
+            ok = probe(self.group)
+            if not collective:
+                break
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)        # every rank has to have found one
+            if float(flag.item()) > 0.0 or groups >= new_groups:
+                break
+            ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+            self.group = dist.new_group(ranks=ranks, backend="nccl")
+            groups += 1
+        last["groups"] = groups
+        self._side, self.overlap_probe = kept[-1], last
+        return last
 
     # ---- the two phases ---------------------------------------------------------------------------------------
     def _cut(self, h):

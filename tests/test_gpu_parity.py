@@ -1,11 +1,14 @@
 """Parity tests proper: the HIP path (through the C ABI of libcistgcn_hip.so) on a real MI355X
 against (a) stock-PyTorch CPU references per operator, (b) the golden vectors generated from the
 real reference, (c) the CPU oracle on fresh seeded inputs.  Run with `-m gpu`."""
+import os
+
 import pytest
 import torch
 
 import checks
 from helpers import CASES
+from oracle import cistgcn_ref as O
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +23,7 @@ def _real_library():
     yield
 
 
-# Relative bound on every gradient tensor with max|ref| >= 1e-4, next to the north_star rule 1e-4 * max(floor, max|ref|) (which is
+# Relative bound (max|a-b| <= REL_BOUND * max|ref| + 3e-7, helpers.assert_grads_strict) on every gradient tensor with max|ref| >= 1e-4, next to the north_star rule 1e-4 * max(floor, max|ref|) (which is
 # an absolute bound for most of the 698 tensors: their max|g| is far below the floor).  The distribution is printed by each test.
 REL_BOUND = 2e-3
 
@@ -294,6 +297,64 @@ def test_training_steps_with_graph_and_flat_adam():
     assert all(bool(torch.isfinite(p).all()) for p in net.parameters())
 
 
+def test_stock_adam_checkpoint_resumes_into_flat_adam_under_a_captured_step(tmp_path):
+    """The reference's resume path (environment/model_loader.py:7-35, train.py:186-191) across implementations: three steps
+    of stock `torch.optim.Adam` on the oracle model (CPU), the checkpoint written with the reference's keys, loaded into
+    a product model whose step was ALREADY captured in a HIP graph with `FlatAdam` (the load must copy into the captured
+    addresses), then three more steps on each side.  Parameters and losses have to track each other."""
+    from cistgcn_amd.environment import load_params_from_model_path, make_checkpoint, save_ckpt
+    from cistgcn_amd.runtime import FlatAdam, GraphedStep
+    lr, steps = 1e-3, 3
+    net, ora = checks.build_pair(8, 10, 22, "cuda", seed=3)
+    other, _ = checks.build_pair(8, 10, 22, "cuda", seed=77)        # what the product model holds before the resume
+    net.load_state_dict(other.state_dict())
+    net.train(); ora.train()
+    g = torch.Generator().manual_seed(21)
+    x = 50 + 350 * torch.randn(16, 10, 22, 3, generator=g)
+    tgt = x[:, -1:] + 20 * torch.randn(16, 25, 22, 3, generator=g)
+    opt_ref = torch.optim.Adam(ora.parameters(), lr=lr, weight_decay=1e-4)
+
+    def ref_step():
+        opt_ref.zero_grad()
+        loss = O.mpjpe(ora(x)[0], tgt)
+        loss.backward()
+        opt_ref.step()
+        return loss.item()
+
+    before = [ref_step() for _ in range(steps)]
+    path = save_ckpt(make_checkpoint(4, ora, opt_ref, {"mpjpe": before[-1]}), is_best=False,
+                     file_name=os.path.join(tmp_path, "CISTGCN_0-resume.pth.tar"))[0]
+    opt = FlatAdam(net, lr=1.0)
+    step = GraphedStep(net, x.cuda(), tgt.cuda(), warmup=2, flat=opt.grads)
+    upd = load_params_from_model_path(path, net, opt)
+    assert upd["epoch"] == 4 and opt.step_count == steps and abs(opt.lr - lr) < 1e-15
+    for (k, p), q in zip(ora.named_parameters(), net.parameters()):
+        assert torch.equal(p.detach(), q.detach().cpu()), k
+    for i in range(steps):
+        l_ref = ref_step()
+        l_dev = step.replay().item()
+        opt.step(gathered=True)
+        assert abs(l_dev - l_ref) <= 2e-4 * abs(l_ref), (i, l_dev, l_ref)
+    # Adam normalises each gradient entry by its own running magnitude, so entries whose gradient is at rounding level move by
+    # +-lr per step on BOTH sides in directions set by rounding (convolution biases in front of a train-mode BatchNorm have an
+    # analytically zero gradient and no effect on the output): every entry stays within half the distance travelled (<= lr per
+    # step), the typical tensor agrees far better than that, and what the parameters compute - the eval-mode prediction with
+    # the running statistics both sides accumulated - is the same
+    worst, typical = 0.0, []
+    for (k, p), q in zip(ora.named_parameters(), net.parameters()):
+        d = (p.detach() - q.detach().cpu()).abs()
+        worst = max(worst, d.max().item())
+        typical.append(d.mean().item())
+    typical.sort()
+    print("resume: max |dp| %.3e, per-tensor mean |dp| median %.3e max %.3e (lr * steps = %.1e)" % (worst, typical[len(typical) // 2], typical[-1], lr * steps))
+    assert worst <= 0.5 * lr * steps, worst
+    assert typical[len(typical) // 2] <= 0.02 * lr * steps, typical[len(typical) // 2]
+    net.eval(); ora.eval()
+    with torch.no_grad():
+        p_dev, p_ref = net(x.cuda())[0].cpu(), ora(x)[0]
+    assert float((p_dev - p_ref).abs().max()) <= 1e-3 * float(p_ref.abs().max()), float((p_dev - p_ref).abs().max())
+
+
 def test_two_phase_graph_step_matches_one_graph():
     """runtime.DataParallelStep on one rank: the backward pass cut behind input block 1 and captured as two HIP graphs
     (bucketed gradient gather between them) fills the flat buffer with the same gradients as the single-graph step."""
@@ -401,9 +462,9 @@ def test_two_ranks_on_one_gpu_match_oracle_per_shard():
     for i, _ in enumerate(res[0][2]):
         ref = sum(shards[r] / tot * res[r][2][i] for r in range(2))
         got = res[0][0][offs[i]:offs[i] + ref.size].reshape(ref.shape)
-        # floor 0.25 as in the strict single-GPU tests of this size class (train mode, batch statistics over 6 and 10 samples: the
-        # first tensor sat at 0.7 .. 1.04 of a 0.1 floor from run to run, fp32 atomics order)
-        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(0.25, float(np.abs(ref).max()))
+        # floor 1 (the north_star form, as in the train-mode single-GPU tests): batch statistics over 6 and 10 samples amplify the
+        # fp32 atomics order - the worst tensor sat at 0.7 .. 1.04 of a 0.1 floor and at 0.8 .. 1.03 of a 0.25 floor from run to run
+        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(1.0, float(np.abs(ref).max()))
         assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
 
 
@@ -429,23 +490,44 @@ def test_first_bucket_allreduce_overlaps_second_phase():
         step = DataParallelStep(net, x, tgt, graph=True)
         assert step.two_phase and len(step.flat.buckets) == 2
         step.force_collective = True
+        probe = step.pick_side_stream(collective=True)      # the side stream is chosen by measurement (hardware queues are shared)
+        print("side stream probe: %s" % probe)
+        assert probe["independent"], "no stream found that runs beside the main stream: %s" % probe
         for _ in range(3):
             step.replay()
-        step.record_events = True
-        step.replay()
-        torch.cuda.synchronize()
-        ev = step.events
-        t = {k: ev["phase1_end"].elapsed_time(e) for k, e in ev.items()}      # ms since the end of phase 1
-        print("two-phase step, ms after the end of phase 1: %s" % {k: round(v, 4) for k, v in t.items()})
-        # With ONE rank the gather + all-reduce of the first bucket takes ~40 us and is over before the second graph has even
-        # started executing (a graph launch costs about as much), so "overlap" shows as: issued on the side stream right behind
-        # phase 1, finished long before phase 2 ends - phase 2 (milliseconds) never waits for it, and only the LAST bucket's
-        # all-reduce stays exposed behind phase 2.  On N > 1 GPUs the same schedule hides a collective up to the length of phase 2.
-        p2 = t["phase2_end"] - t["phase2_start"]
-        assert t["reduce1_end"] > t["reduce1_start"] and p2 > 0
-        assert t["reduce1_start"] < t["phase2_start"] + 0.25 * p2, "the first bucket was not issued beside phase 2: %s" % t
-        assert t["reduce1_end"] < t["phase2_end"] - 0.5 * p2, "the first bucket's all-reduce finished behind phase 2: %s" % t
-        assert t["phase2_start"] < t["reduce1_end"], "phase 2 waited for the first bucket's all-reduce: %s" % t
+        # With ONE rank the gather + all-reduce of the first bucket takes ~40 us - over before the second graph has started
+        # executing - so the collective is made as long as a collective over xGMI would be: a spin kernel of ~2 ms goes in front of
+        # it on the side stream.  If phase 2 ran behind the first bucket's all-reduce, it would start ~2 ms late; if it runs
+        # beside it, phase 2 starts right away, takes as long as without the delay, and the collective ends in the middle of it.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(1000000); e1.record(); torch.cuda.synchronize()
+        spin = int(1000000 * 2.0 / max(e0.elapsed_time(e1), 1e-3))          # spin count of ~2 ms on this clock
+
+        def timed(delay):
+            reduce = step._reduce
+
+            def delayed(bucket, *a, **k):
+                if delay and bucket == 1:
+                    torch.cuda._sleep(spin)
+                return reduce(bucket, *a, **k)
+
+            step._reduce = delayed
+            try:
+                step.record_events = True
+                step.replay()
+                torch.cuda.synchronize()
+            finally:
+                step._reduce = reduce
+            return {k: step.events["phase1_end"].elapsed_time(e) for k, e in step.events.items()}       # ms since the end of phase 1
+
+        base, t = timed(False), timed(True)
+        print("two-phase step, ms after the end of phase 1: plain %s, first bucket delayed by ~2 ms %s" % (
+            {k: round(v, 4) for k, v in base.items()}, {k: round(v, 4) for k, v in t.items()}))
+        p2_base, p2 = base["phase2_end"] - base["phase2_start"], t["phase2_end"] - t["phase2_start"]
+        assert t["reduce1_end"] - t["reduce1_start"] > 1.5, "the delay did not take: %s" % t
+        assert t["phase2_start"] < 0.5, "phase 2 waited for the first bucket's all-reduce: %s" % t
+        assert t["phase2_start"] < t["reduce1_end"] < t["phase2_end"], "the collective did not run beside phase 2: %s" % t
+        assert p2 < 1.15 * p2_base + 0.1, "phase 2 slowed down beside the collective: %.3f vs %.3f ms" % (p2, p2_base)
     finally:
         if own:
             dist.destroy_process_group()
