@@ -43,6 +43,18 @@ static int cg_rows_per_block(const CgView4& v) {
 }
 
 #define CG_ROW_MAX_BATCH 6     // problems per launch of the row kernels (kernel-argument budget)
+// Vector width of the contiguous-row paths: 4 (rows 16-byte aligned, P % 4 == 0) or 2 (rows 8-byte aligned, P % 2 == 0: the
+// (T,V) planes of the 25-joint skeletons, P = 1250, and the (25, 66) planes of the output block).  The width is uniform per
+// problem; lanes j >= vw of a group are never used.
+__device__ __forceinline__ void cg_ldv(const float* p, int vw, float out[4]) {
+  if (vw == 4) { const float4 v = *reinterpret_cast<const float4*>(p); out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w; }
+  else { const float2 v = *reinterpret_cast<const float2*>(p); out[0] = v.x; out[1] = v.y; out[2] = 0.f; out[3] = 0.f; }
+}
+__device__ __forceinline__ void cg_stv(float* p, int vw, const float v[4]) {
+  if (vw == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+}
+
 struct CgStatsItem { const float* x; CgView4 xv; const float* pre; double* stats; int rb; int pad; };
 struct CgStatsBatch { int n; int pad; CgStatsItem it[CG_ROW_MAX_BATCH]; };
 
@@ -57,13 +69,15 @@ __global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
   const int P = (int)(xv.n[2] * xv.n[3]);
   const int nb = min(rb, (int)xv.n[0] - b0);
   double s = 0.0, q = 0.0;
-  if (it.pad) {                                   // pad = 1: contiguous 16-byte aligned rows (float4 path)
-    const int P4 = P >> 2;
-    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
-      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+  if (it.pad) {                                   // pad = 4 / 2: contiguous rows, 16- / 8-byte aligned (vector path)
+    const int vw = it.pad, PV = P / vw;
+    for (int e = threadIdx.x; e < nb * PV; e += blockDim.x) {
+      const int br = e / PV, p = vw * (e - br * PV), b = b0 + br;
       const float w = pre ? pre[(long long)b * xv.n[1] + c] : 1.f;
-      const float4 v4 = *reinterpret_cast<const float4*>(x + cg_row_base(xv, b, c) + p);
-      const float v[4] = {v4.x * w, v4.y * w, v4.z * w, v4.w * w};
+      float v[4];
+      cg_ldv(x + cg_row_base(xv, b, c) + p, vw, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= w;
       s += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
       q += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
     }
@@ -87,7 +101,7 @@ __global__ void cg_chan_stats_kernel(CgStatsBatch batch) {
 }
 
 struct CgStatsArgs { const float* x; CgView4 xv; const float* pre; double* stats; };
-static bool cg_view_vec(const void* ptr, const CgView4& v);      // contiguous 16-byte aligned rows (defined with the row kernels below)
+static int cg_view_vec(const void* ptr, const CgView4& v);       // vector width of contiguous aligned rows: 4, 2 or 0 (defined with the row kernels below)
 
 // include/cistgcn_hip.h : cg_chan_stats_many (up to CG_ROW_MAX_BATCH tensors per launch)
 extern "C" int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream_) {
@@ -102,7 +116,7 @@ extern "C" int cg_chan_stats_many(const CgStatsArgs* items, int n, void* stream_
     if (a.xv.n[0] <= 0 || a.xv.n[1] <= 0 || P <= 0) return CG_ESHAPE;
     const int rb = cg_rows_per_block(a.xv);
     batch.it[i].x = a.x; batch.it[i].xv = a.xv; batch.it[i].pre = a.pre; batch.it[i].stats = a.stats; batch.it[i].rb = rb;
-    batch.it[i].pad = cg_view_vec(a.x, a.xv) ? 1 : 0;          // float4 path flag
+    batch.it[i].pad = cg_view_vec(a.x, a.xv);                  // vector width of the contiguous-row path (0: none)
     gx = gx > a.xv.n[1] ? gx : a.xv.n[1];
     const long long chunks = (a.xv.n[0] + rb - 1) / rb;
     gy = gy > chunks ? gy : chunks;
@@ -177,23 +191,28 @@ struct CgNormAct {
 // nn.BatchNorm does); the folded form v*scale + (beta - mean*scale) cancels catastrophically when
 // |mean| >> std.
 struct CgChanAffine { float scale, shift, mean, rstd; };
-// vec[i] != 0: every view the kernel touches is a contiguous-row NCHW view (s[3] = 1, s[2] = n[3]) with P % 4 == 0 and
-// 16-byte aligned rows -> float4 path, no per-element index arithmetic
+// vec[i] = 4 / 2: every view the kernel touches is a contiguous-row NCHW view (s[3] = 1, s[2] = n[3]) with P % vec == 0 and
+// rows aligned to 4 * vec bytes -> vector path (float4 / float2), no per-element index arithmetic
 struct CgNormActBatch { int n; int rb[CG_ROW_MAX_BATCH]; int vec[CG_ROW_MAX_BATCH]; int pad; CgNormAct a[CG_ROW_MAX_BATCH]; };
 
-static bool cg_view_vec(const void* ptr, const CgView4& v) {
-  if (!ptr) return true;
+static int cg_view_vec(const void* ptr, const CgView4& v) {
+  if (!ptr) return 4;
   const long long P = v.n[2] * v.n[3];
   const bool rows = v.s[3] == 1 && (v.s[2] == v.n[3] || v.n[2] == 1);
-  return rows && (P & 3) == 0 && (v.s[0] & 3) == 0 && (v.s[1] & 3) == 0 && ((uintptr_t)ptr & 15) == 0;
+  if (!rows) return 0;
+  if ((P & 3) == 0 && (v.s[0] & 3) == 0 && (v.s[1] & 3) == 0 && ((uintptr_t)ptr & 15) == 0) return 4;
+  if ((P & 1) == 0 && (v.s[0] & 1) == 0 && (v.s[1] & 1) == 0 && ((uintptr_t)ptr & 7) == 0) return 2;
+  return 0;
 }
-// kind: 0 forward, 1 backward reduce, 2 backward apply
+// kind: 0 forward, 1 backward reduce, 2 backward apply; returns the common vector width of every view the kernel touches
 static int cg_norm_act_vec(const CgNormAct& a, int kind) {
-  bool ok = cg_view_vec(a.x, a.xv) && cg_view_vec(a.add, a.av);
-  if (kind == 0) ok = ok && cg_view_vec(a.y, a.yv);
-  else ok = ok && cg_view_vec(a.dy, a.dyv);
-  if (kind == 2) ok = ok && cg_view_vec(a.dx, a.dxv) && cg_view_vec(a.dadd, a.dav);
-  return ok ? 1 : 0;
+  int vw = cg_view_vec(a.x, a.xv);
+  auto also = [&](const void* p, const CgView4& v) { const int w = cg_view_vec(p, v); vw = w < vw ? w : vw; };
+  also(a.add, a.av);
+  if (kind == 0) also(a.y, a.yv);
+  else also(a.dy, a.dyv);
+  if (kind == 2) { also(a.dx, a.dxv); also(a.dadd, a.dav); }
+  return vw;
 }
 
 __device__ __forceinline__ CgChanAffine cg_chan_affine(const CgNormAct& a, int c, bool backward) {
@@ -257,23 +276,22 @@ __global__ void cg_norm_act_fwd_kernel(CgNormActBatch batch) {
   __shared__ double red[32];
   double ys = 0.0, yq = 0.0;
   if (batch.vec[blockIdx.z]) {
-    const int P4 = P >> 2;
-    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
-      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
+    const int vw = batch.vec[blockIdx.z], PV = P / vw;
+    for (int e = threadIdx.x; e < nb * PV; e += blockDim.x) {
+      const int br = e / PV, p = vw * (e - br * PV), b = b0 + br;
       const float w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
-      const float4 xv4 = *reinterpret_cast<const float4*>(a.x + cg_row_base(a.xv, b, c) + p);
-      float4 ad4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.add) ad4 = *reinterpret_cast<const float4*>(a.add + cg_row_base(a.av, b, c) + p);
-      const unsigned long long bits = drop ? cg_drop_bits(seed, a.salt, (((unsigned long long)b * C + c) * P + p) >> 2) : 0ull;
-      float4 y4;
-      y4.x = cg_norm_act_y(a, af, alpha, xv4.x, w, drop ? cg_drop_pick(bits, 0, a.drop_p) : 1.f, ad4.x);
-      y4.y = cg_norm_act_y(a, af, alpha, xv4.y, w, drop ? cg_drop_pick(bits, 1, a.drop_p) : 1.f, ad4.y);
-      y4.z = cg_norm_act_y(a, af, alpha, xv4.z, w, drop ? cg_drop_pick(bits, 2, a.drop_p) : 1.f, ad4.z);
-      y4.w = cg_norm_act_y(a, af, alpha, xv4.w, w, drop ? cg_drop_pick(bits, 3, a.drop_p) : 1.f, ad4.w);
-      *reinterpret_cast<float4*>(a.y + cg_row_base(a.yv, b, c) + p) = y4;
+      float xq[4], aq[4] = {0.f, 0.f, 0.f, 0.f}, yv[4];
+      cg_ldv(a.x + cg_row_base(a.xv, b, c) + p, vw, xq);
+      if (a.add) cg_ldv(a.add + cg_row_base(a.av, b, c) + p, vw, aq);
+      const unsigned long long idx = ((unsigned long long)b * C + c) * P + p;      // element index: its group of four shares 64 random bits
+      const unsigned long long bits = drop ? cg_drop_bits(seed, a.salt, idx >> 2) : 0ull;
+      const int j0 = (int)(idx & 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv[j] = j < vw ? cg_norm_act_y(a, af, alpha, xq[j], w, drop ? cg_drop_pick(bits, j0 + j, a.drop_p) : 1.f, aq[j]) : 0.f;
+      cg_stv(a.y + cg_row_base(a.yv, b, c) + p, vw, yv);
       if (a.ystats) {
-        ys += ((double)y4.x + (double)y4.y) + ((double)y4.z + (double)y4.w);
-        yq += ((double)y4.x * (double)y4.x + (double)y4.y * (double)y4.y) + ((double)y4.z * (double)y4.z + (double)y4.w * (double)y4.w);
+        ys += ((double)yv[0] + (double)yv[1]) + ((double)yv[2] + (double)yv[3]);
+        yq += ((double)yv[0] * (double)yv[0] + (double)yv[1] * (double)yv[1]) + ((double)yv[2] * (double)yv[2] + (double)yv[3] * (double)yv[3]);
       }
     }
   } else {
@@ -319,22 +337,22 @@ __device__ __forceinline__ float cg_norm_act_gh(const CgNormAct& a, const CgChan
   return cg_norm_act_gh_val(a, af, alpha, a.x[cg_row_base(a.xv, b, c) + CG_OFF(a.xv)], w, keep, ad, g, v, u, gu);
 }
 
-// the four lanes of a float4: loads for the vector path of both backward passes
+// a group of vw (4 or 2) consecutive elements: loads for the vector path of both backward passes
 struct CgNaQuad { float x[4], ad[4], g[4], keep[4]; float w; };
-__device__ __forceinline__ CgNaQuad cg_norm_act_quad(const CgNormAct& a, unsigned long long seed, int b, int c, long long C, int P, int p) {
+__device__ __forceinline__ CgNaQuad cg_norm_act_quad(const CgNormAct& a, unsigned long long seed, int b, int c, long long C, int P, int p, int vw) {
   CgNaQuad q;
   q.w = a.pre ? a.pre[(long long)b * C + c] : 1.f;
-  const float4 x4 = *reinterpret_cast<const float4*>(a.x + cg_row_base(a.xv, b, c) + p);
-  const float4 g4 = *reinterpret_cast<const float4*>(a.dy + cg_row_base(a.dyv, b, c) + p);
-  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.add && !a.add_post) a4 = *reinterpret_cast<const float4*>(a.add + cg_row_base(a.av, b, c) + p);
-  q.x[0] = x4.x; q.x[1] = x4.y; q.x[2] = x4.z; q.x[3] = x4.w;
-  q.g[0] = g4.x; q.g[1] = g4.y; q.g[2] = g4.z; q.g[3] = g4.w;
-  q.ad[0] = a4.x; q.ad[1] = a4.y; q.ad[2] = a4.z; q.ad[3] = a4.w;
-  if (a.drop_p > 0.f) {
-    const unsigned long long bits = cg_drop_bits(seed, a.salt, (((unsigned long long)b * C + c) * P + p) >> 2);
+  cg_ldv(a.x + cg_row_base(a.xv, b, c) + p, vw, q.x);
+  cg_ldv(a.dy + cg_row_base(a.dyv, b, c) + p, vw, q.g);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) q.keep[j] = cg_drop_pick(bits, j, a.drop_p);
+  for (int j = 0; j < 4; ++j) q.ad[j] = 0.f;
+  if (a.add && !a.add_post) cg_ldv(a.add + cg_row_base(a.av, b, c) + p, vw, q.ad);
+  if (a.drop_p > 0.f) {
+    const unsigned long long idx = ((unsigned long long)b * C + c) * P + p;
+    const unsigned long long bits = cg_drop_bits(seed, a.salt, idx >> 2);
+    const int j0 = (int)(idx & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q.keep[j] = j < vw ? cg_drop_pick(bits, j0 + j, a.drop_p) : 0.f;
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) q.keep[j] = 1.f;
@@ -357,12 +375,13 @@ __global__ void cg_norm_act_bwd_reduce_kernel(CgNormActBatch batch) {
   const unsigned long long seed = (a.drop_p > 0.f) ? *a.seed : 0ull;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
   if (batch.vec[blockIdx.z]) {
-    const int P4 = P >> 2;
-    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
-      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
-      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p);
+    const int vw = batch.vec[blockIdx.z], PV = P / vw;
+    for (int e = threadIdx.x; e < nb * PV; e += blockDim.x) {
+      const int br = e / PV, p = vw * (e - br * PV), b = b0 + br;
+      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p, vw);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (j >= vw) break;
         float v, u, gu;
         const float gh = cg_norm_act_gh_val(a, af, alpha, q.x[j], q.w, q.keep[j], q.ad[j], q.g[j], v, u, gu);
         s1 += (double)gh;
@@ -412,13 +431,14 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormActBatch batch) {
   }
   double sp = 0.0;
   if (batch.vec[blockIdx.z]) {
-    const int P4 = P >> 2;
-    for (int e = threadIdx.x; e < nb * P4; e += blockDim.x) {
-      const int br = e / P4, p = 4 * (e - br * P4), b = b0 + br;
-      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p);
-      float dxq[4], daq[4];
+    const int vw = batch.vec[blockIdx.z], PV = P / vw;
+    for (int e = threadIdx.x; e < nb * PV; e += blockDim.x) {
+      const int br = e / PV, p = vw * (e - br * PV), b = b0 + br;
+      const CgNaQuad q = cg_norm_act_quad(a, seed, b, c, C, P, p, vw);
+      float dxq[4] = {0.f, 0.f, 0.f, 0.f}, daq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (j >= vw) break;
         float v, u, gu;
         const float gh = cg_norm_act_gh_val(a, af, alpha, q.x[j], q.w, q.keep[j], q.ad[j], q.g[j], v, u, gu);
         float gv;
@@ -427,8 +447,8 @@ __global__ void cg_norm_act_bwd_apply_kernel(CgNormActBatch batch) {
         dxq[j] = gv * q.w; daq[j] = gu;
         if (a.dpre) sp += (double)gv * (double)q.x[j];
       }
-      if (a.dx) *reinterpret_cast<float4*>(a.dx + cg_row_base(a.dxv, b, c) + p) = make_float4(dxq[0], dxq[1], dxq[2], dxq[3]);
-      if (a.dadd) *reinterpret_cast<float4*>(a.dadd + cg_row_base(a.dav, b, c) + p) = make_float4(daq[0], daq[1], daq[2], daq[3]);
+      if (a.dx) cg_stv(a.dx + cg_row_base(a.dxv, b, c) + p, vw, dxq);
+      if (a.dadd) cg_stv(a.dadd + cg_row_base(a.dav, b, c) + p, vw, daq);
     }
   } else {
     CG_CHUNK_LOOP(nb, P, e) {
@@ -638,15 +658,17 @@ struct CgSumArgs { float* y; CgView4 yv; int n; int vec; const float* a[CG_SUM_M
 __global__ void cg_sum_many_kernel(CgSumArgs s) {
   const int c = blockIdx.x, b = blockIdx.y;
   const int P = (int)(s.yv.n[2] * s.yv.n[3]);
-  if (s.vec) {                                   // contiguous 16-byte aligned rows everywhere
+  if (s.vec) {                                   // contiguous rows everywhere, aligned to 4 * vec bytes (vec = 4 or 2)
+    const int vw = s.vec;
     float* yr = s.y + cg_row_base(s.yv, b, c);
-    for (int p = 4 * threadIdx.x; p < P; p += 4 * blockDim.x) {
-      float4 v = *reinterpret_cast<const float4*>(s.a[0] + cg_row_base(s.av[0], b, c) + p);
+    for (int p = vw * threadIdx.x; p < P; p += vw * blockDim.x) {
+      float v[4], w[4];
+      cg_ldv(s.a[0] + cg_row_base(s.av[0], b, c) + p, vw, v);
       for (int i = 1; i < s.n; ++i) {
-        const float4 w = *reinterpret_cast<const float4*>(s.a[i] + cg_row_base(s.av[i], b, c) + p);
-        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        cg_ldv(s.a[i] + cg_row_base(s.av[i], b, c) + p, vw, w);
+        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
       }
-      *reinterpret_cast<float4*>(yr + p) = v;
+      cg_stv(yr + p, vw, v);
     }
     return;
   }
@@ -665,7 +687,7 @@ extern "C" int cg_sum_many(float* y, const CgView4* yv, const CgSumItem* items, 
   if (yv->n[0] <= 0 || yv->n[0] > 65535 || yv->n[1] <= 0 || yv->n[2] * yv->n[3] <= 0) return CG_ESHAPE;
   CgSumArgs s;
   s.y = y; s.yv = *yv; s.n = n;
-  bool vec = cg_view_vec(y, *yv);
+  int vec = cg_view_vec(y, *yv);
   for (int i = 0; i < CG_SUM_MAX; ++i) {
     s.a[i] = i < n ? items[i].a : nullptr;
     s.av[i] = i < n ? items[i].av : *yv;
@@ -673,10 +695,10 @@ extern "C" int cg_sum_many(float* y, const CgView4* yv, const CgSumItem* items, 
       if (!items[i].a) return CG_EARG;
       for (int k = 0; k < 4; ++k)
         if (items[i].av.n[k] != yv->n[k]) return CG_ESHAPE;
-      vec = vec && cg_view_vec(items[i].a, items[i].av);
+      { const int w = cg_view_vec(items[i].a, items[i].av); vec = w < vec ? w : vec; }
     }
   }
-  s.vec = vec ? 1 : 0;
+  s.vec = vec;
   dim3 grid((unsigned)yv->n[1], (unsigned)yv->n[0]);
   hipLaunchKernelGGL(cg_sum_many_kernel, grid, cg_row_block(*yv), 0, (hipStream_t)stream_, s);
   return cg_launch_status();

@@ -180,6 +180,7 @@ def _check_norm_act_shape(device, quick, T, V, trains=(True, False)):
 def check_norm_act(device, quick=False):
     _check_norm_act_shape(device, quick, 5, 7)      # odd rows: strided scalar path
     _check_norm_act_shape(device, True, 4, 6, trains=(True,) if quick else (True, False))   # rows of 24 contiguous floats: float4 path
+    _check_norm_act_shape(device, True, 5, 6, trains=(True,) if quick else (True, False))   # rows of 30 floats, 8-byte aligned: float2 path
     # a larger float4 case (several rows per workgroup, addend before the PReLU, per-channel slopes)
     gb = _gen(21)
     bn_ref, pr_ref = nn.BatchNorm2d(3), nn.PReLU(3)
@@ -307,6 +308,13 @@ def check_dropout(device):
     yo = ops.norm_act(xo, train=True, drop_p=p, salt=9)
     yo.backward(torch.ones_like(yo))
     assert torch.equal(xo.grad.cpu(), yo.detach().cpu())
+    # rows of 30 floats (8-byte aligned): the float2 path draws the mask of the strided scalar path, forward and backward
+    x2 = torch.ones(3, 4, 5, 6, device=device, requires_grad=True)
+    y6 = ops.norm_act(x2, train=True, drop_p=p, salt=11)
+    y6.backward(torch.ones_like(y6))
+    assert torch.equal(x2.grad.cpu(), y6.detach().cpu())
+    y7 = ops.norm_act(torch.ones(3, 5, 6, 4, device=device).permute(0, 3, 1, 2), train=True, drop_p=p, salt=11)
+    assert torch.equal(y7.cpu(), y6.detach().cpu())
 
 
 def check_reduce_and_gate(device):

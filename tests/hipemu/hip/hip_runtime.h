@@ -29,6 +29,7 @@ extern dim3 blockIdx, blockDim, gridDim;
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }      // only ever applied to wave-uniform values
 struct float2 { float x, y; } __attribute__((aligned(8)));
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 #define __global__
 #define __device__
 #define __host__
