@@ -107,7 +107,8 @@ class AdjTail(ctypes.Structure):
 class PwMaps(ctypes.Structure):
     _fields_ = [("B", c_int), ("Cin", c_int), ("P", c_int), ("n", c_int), ("x", c_void_p),
                 ("W", c_void_p * 4), ("M", c_int * 4), ("y", c_void_p * 4), ("stats", c_void_p * 4),
-                ("dy", c_void_p * 4), ("dx", c_void_p), ("dW", c_void_p * 4), ("dW_ws", c_void_p)]
+                ("dy", c_void_p * 4), ("dx", c_void_p), ("dW", c_void_p * 4), ("dW_ws", c_void_p),
+                ("bias", c_void_p * 4), ("db", c_void_p * 4)]
 
 
 class FpnConv(ctypes.Structure):

@@ -18,4 +18,6 @@ struct CgPwMaps {
   float* dx;                        // (B, Cin, P): sum over the maps of W_i^T dy_i
   float* dW[CG_PWM_MAXN];           // (M_i, Cin)
   float* dW_ws;                     // cg_pointwise_maps_ws_floats(Cin) zeroed floats (replicated accumulators)
+  const float* bias[CG_PWM_MAXN];   // optional (M_i): y_i += bias_i (the residual convolutions, CISTGCN.py:246-254, :357-365)
+  float* db[CG_PWM_MAXN];           // backward, optional (M_i): sum over (b, p) of dy_i
 };

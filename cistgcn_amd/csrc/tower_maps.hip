@@ -64,6 +64,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
   float* sX = reinterpret_cast<float*>(cg_dyn_lds);              // [CinM][PS]
   float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
   double* sStat = reinterpret_cast<double*>(sW + g.MM * g.WS + ((g.CinM * g.PS + g.MM * g.WS) & 1));      // [MM][2]
+  float* sBias = reinterpret_cast<float*>(sStat + 2 * g.MM);                                                // [MM]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
@@ -78,6 +79,10 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
   for (int e = tid; e < g.CinM * g.PS; e += CG_PWM_THREADS) sX[e] = 0.f;
   const bool stats = t.stats[0] != nullptr;
   if (stats) for (int e = tid; e < 2 * g.MM; e += CG_PWM_THREADS) sStat[e] = 0.0;
+  for (int r = tid; r < g.MM; r += CG_PWM_THREADS) {
+    const int tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
+    sBias[r] = (m < t.M[i] && t.bias[i]) ? t.bias[i][m] : 0.f;
+  }
   for (int lid = lid0; lid < lid1; ++lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
     __syncthreads();
@@ -102,10 +107,12 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
       const int i = g.tile_map[nt], m = g.tile_row0[nt] + l15;
       if (m < t.M[i]) {
         float s1 = 0.f, s2 = 0.f;
+        const float bv = sBias[16 * nt + l15];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pq = (h ? n1 : n0) + 4 * slot;
-          const cg_f32x4 c = h ? c1 : c0;
+          cg_f32x4 c = h ? c1 : c0;
+          c[0] += bv; c[1] += bv; c[2] += bv; c[3] += bv;
           if (pq < np) {
             *reinterpret_cast<float4*>(t.y[i] + ((long long)b * t.M[i] + m) * t.P + p0 + pq) = make_float4(c[0], c[1], c[2], c[3]);
             s1 += (c[0] + c[1]) + (c[2] + c[3]); s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
@@ -151,9 +158,11 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   fetch(lid0);
   cg_pwm_weights(a, sW);
   for (int e = tid; e < (g.MM + g.CinM) * g.PS; e += CG_PWM_THREADS) sD[e] = 0.f;
-  cg_f32x4 wacc[CG_PWM_MAXW];
+  cg_f32x4 wacc[CG_PWM_MAXW], bacc[CG_PWM_MAXW];      // bacc: row sums of dy (bias gradient) on the tiles of the first channel column
 #pragma unroll
-  for (int u = 0; u < CG_PWM_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < CG_PWM_MAXW; ++u) { wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; bacc[u] = wacc[u]; }
+  bool want_db = false;
+  for (int i = 0; i < t.n; ++i) want_db = want_db || t.db[i] != nullptr;
   for (int lid = lid0; lid < lid1; ++lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
     __syncthreads();
@@ -173,6 +182,8 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
         const float* ap1 = cg_tfrag_ptr<0>(sD + 16 * mt1 * g.PS, g.PS, l15, slot);
         const float* bp1 = cg_tfrag_ptr<0>(sX + 16 * ct1 * g.PS, g.PS, l15, slot);
         cg_f32x4 w0 = wacc[u], w1 = wacc[u + 1];
+        const bool db0 = want_db && ct0 == 0, db1 = want_db && two && ct1 == 0;      // wave-uniform
+        cg_f32x4 s0 = bacc[u], s1 = bacc[u + 1];
 #pragma unroll 2
         for (int k0 = 0; k0 < g.PT; k0 += 16) {
           float a0[4], b0[4], a1[4], b1[4];
@@ -182,9 +193,17 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
             w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], w0, 0, 0, 0);
             w1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], b1[s], w1, 0, 0, 0);
           }
+          if (db0) {                                     // dy . 1: every column of the tile = the row sums
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], 1.f, s0, 0, 0, 0);
+          }
+          if (db1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], 1.f, s1, 0, 0, 0);
+          }
         }
-        wacc[u] = w0;
-        if (two) wacc[u + 1] = w1;
+        wacc[u] = w0; bacc[u] = s0;
+        if (two) { wacc[u + 1] = w1; bacc[u + 1] = s1; }
       }
     }
     // dx[p][c] = sum_m dy[m][p] W[m][c]
@@ -225,6 +244,11 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
         const int r = 16 * mt + 4 * slot + q, c = 16 * ct + l15;
         if (c < t.Cin) atomicAdd(&ws[r * t.Cin + c], wacc[u][q]);
       }
+      if (want_db && ct == 0 && l15 == 0) {
+        float* wsb = t.dW_ws + (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * t.Cin + (long long)(blockIdx.x % CG_PWM_REPLICAS) * CG_PWM_MAXROWS;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomicAdd(&wsb[16 * mt + 4 * slot + q], bacc[u][q]);
+      }
     }
   }
 }
@@ -238,6 +262,14 @@ __global__ void cg_pwm_fold_kernel(CgPwArgs a) {
     float s = 0.f;
     for (int r = 0; r < CG_PWM_REPLICAS; ++r) s += t.dW_ws[((long long)r * CG_PWM_MAXROWS + g.row_base[i] + m) * t.Cin + c];
     t.dW[i][e] = s;
+  }
+  if (t.db[i]) {
+    const float* wsb = t.dW_ws + (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * t.Cin;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < t.M[i]; m += gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int r = 0; r < CG_PWM_REPLICAS; ++r) s += wsb[(long long)r * CG_PWM_MAXROWS + g.row_base[i] + m];
+      t.db[i][m] = s;
+    }
   }
 }
 
@@ -258,8 +290,8 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   for (int i = t->n; i < CG_PWM_MAXN; ++i) g->row_base[i] = 0;
   g->CinM = (t->Cin + 15) & ~15; g->MM = rows; g->WS = g->CinM + 4; g->NT = rows / 16; g->CT = g->CinM / 16;
   const int big = bwd ? (g->MM > g->CinM ? g->MM : g->CinM) : g->CinM;
-  int pt = 16 * CG_PWM_THREADS / big;
-  pt = pt > 256 ? 256 : pt;
+  int pt = 256;                                   // largest power of two with big * pt <= 16 * threads (the staging registers), at most 256:
+  while (big * pt > 16 * CG_PWM_THREADS) pt >>= 1; // a 48-row stack (three 10-channel maps, or 40 input channels) gets 128, not 170
   g->PT = pt; g->PS = pt + 4;
   g->lgq = 0;
   while ((4 << g->lgq) < pt) ++g->lgq;
@@ -270,7 +302,7 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   return CG_OK;
 }
 
-extern "C" long long cg_pointwise_maps_ws_floats(int Cin) { return (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * Cin; }
+extern "C" long long cg_pointwise_maps_ws_floats(int Cin) { return (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * (Cin + 1); }      // + the bias-gradient rows
 
 // include/cistgcn_hip.h : cg_pointwise_maps_fwd / cg_pointwise_maps_bwd
 extern "C" int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream_) {
@@ -282,7 +314,7 @@ extern "C" int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream_) {
     if (!t->y[i]) return CG_EARG;
     if ((t->stats[i] != nullptr) != (t->stats[0] != nullptr)) return CG_EARG;
   }
-  const size_t lds = ((size_t)a.g.CinM * a.g.PS + (size_t)a.g.MM * a.g.WS + 2 + (size_t)4 * a.g.MM) * sizeof(float);
+  const size_t lds = ((size_t)a.g.CinM * a.g.PS + (size_t)a.g.MM * a.g.WS + 2 + (size_t)5 * a.g.MM) * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)cg_pwm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int nwg = (a.g.total + a.g.per - 1) / a.g.per;

@@ -379,6 +379,22 @@ class CISTGCN(nn.Module):
                     self.act_trace[kw["prelu"]] = (y.detach(), add.detach() if add is not None else None)
         return ys
 
+    @staticmethod
+    def _map_groups(x, ws):
+        """index groups of the 1x1 maps `ws` of x that `ops.pointwise_maps` takes in one launch each (at most four maps and 128
+        stacked rows, every map rounded up to 16 rows); None when one of them does not fit the kernel at all"""
+        groups, rows = [], 0
+        for i, w in enumerate(ws):
+            if not ops.pointwise_maps_ok(x, [w]):
+                return None
+            r = (w.shape[0] + 15) // 16 * 16
+            if not groups or rows + r > 128 or len(groups[-1]) == 4:
+                groups.append([])
+                rows = 0
+            groups[-1].append(i)
+            rows += r
+        return groups
+
     def _block_staged(self, m, x):
         """DSTD_GC.forward (CISTGCN.py:373-390) with the gate paths (:378-384), the four Map2Adj towers (:183-189) and
         the two domain layers (:259-269) advanced in lock-step: every stage is one contraction launch or one row-kernel
@@ -404,7 +420,13 @@ class CISTGCN(nn.Module):
         cs, ct = m.conv_s[0], m.conv_t[0]
         gates = big and self.fused_maps and cs.weight.shape == ct.weight.shape and cs.bias is None and ct.bias is None
         rows_gate = gates and 2 * cs.out_channels <= 64 and ops.collapse_rows_ok(xn0, cs.weight.view(cs.out_channels, cs.in_channels, -1))
-        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (0 if has_res else 2) + (0 if has_bres else 1)))
+        # the residual maps of a block that changes its width (1x1 convolutions WITH bias, CISTGCN.py:246-254 / :357-365) read the block
+        # input in one pass per group as well (a group: up to 128 stacked output rows)
+        res_convs = ([d.residual[0] for d in doms] if has_res else []) + ([m.residual[0]] if has_bres else [])
+        res_w = [c.weight.view(c.out_channels, c.in_channels) for c in res_convs]
+        res_groups = self._map_groups(xn0, res_w) if (big and self.fused_maps and res_convs) else None
+        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (len(res_groups) if res_groups else 0)
+                             + (0 if has_res else 2) + (0 if has_bres else 1)))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
         k = 4
         x_maps = x_gates = None
@@ -412,6 +434,9 @@ class CISTGCN(nn.Module):
             x_maps, k = xa[4], 5
         if rows_gate:
             x_gates, k = xa[k], k + 1
+        x_resmaps = []
+        if res_groups:
+            x_resmaps, k = xa[k:k + len(res_groups)], k + len(res_groups)
         x_res = xa[k:k + 2] if not has_res else None
         x_bres = xa[-1] if not has_bres else None
         stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
@@ -432,16 +457,20 @@ class CISTGCN(nn.Module):
         if not stacked:
             for a in maps:
                 items += [_pw_item(xn, a.time_compress[0], tr), _pw_item(xn, a.joint_compress[0], tr)]
-        if has_res:
-            items += [_pw_item(xn, d.residual[0], tr) for d in doms]
-        if has_bres:
-            items.append(_pw_item(xn, m.residual[0], tr))
+        if res_groups is None:
+            items += [_pw_item(xn, c, tr) for c in res_convs]
         o = _run_items(items) if items else []
         if gates:
             yg = gate_rows if gate_rows is not None else o.pop(0)[0]
             o = [(g.unsqueeze(2), None) for g in ops.split_channels(yg, (O, O))] + o
         if stacked:
             o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
+        if res_groups:
+            ro = [None] * len(res_convs)
+            for xg, grp in zip(x_resmaps, res_groups):
+                for i, y in zip(grp, ops.pointwise_maps(xg, [res_w[i] for i in grp], tr, biases=[res_convs[i].bias for i in grp])):
+                    ro[i] = y
+            o = o + ro
         gs, gt, tc = o[0], o[1], o[2:6]
         # 2. their BatchNorm / PReLU tails
         calls = [dict(x=gs, bn=m.conv_s[1], drop=True, prelu=m.conv_s[3]), dict(x=gt, bn=m.conv_t[1], drop=True, prelu=m.conv_t[3])]

@@ -1704,33 +1704,37 @@ def pointwise_maps_ok(x, weights):
 
 
 class _PointwiseMaps(torch.autograd.Function):
-    """y_i = W_i x for up to four 1x1 convolutions of one input, CISTGCN.py:138-163 / :183-186 (see csrc/tower_maps.hip).
-    Tensor inputs: x W_1 .. W_n; outputs y_1 .. y_n, then their f64 channel sums (or None)."""
+    """y_i = W_i x (+ bias_i) for up to four 1x1 convolutions of one input, CISTGCN.py:138-163 / :183-186 and the residual maps
+    :246-254 / :357-365 (see csrc/tower_maps.hip).  Tensor inputs: x, W_1 .. W_n, bias_1 .. bias_n (None where a map has none);
+    outputs y_1 .. y_n, then their f64 channel sums (or None)."""
 
     @staticmethod
-    def _block(x, ws):
+    def _block(x, ws, bs):
         B, C, H, W = x.shape
         t = _lib.PwMaps()
         t.B, t.Cin, t.P, t.n = B, C, H * W, len(ws)
         t.x = x.data_ptr()
         for i, w in enumerate(ws):
             t.W[i], t.M[i] = w.data_ptr(), w.shape[0]
+            t.bias[i] = _ptr(bs[i])
         return t
 
     @staticmethod
-    def forward(ctx, want_stats, x, *ws):
+    def forward(ctx, want_stats, n, x, *wb):
         ctx.set_materialize_grads(False)
         _chk(x)
         B, C, H, W = x.shape
         dev, f32 = x.device, torch.float32
-        ws = [w if w.is_contiguous() else _copy(w) for w in ws]
-        t = _PointwiseMaps._block(x, ws)
+        ws = [w if w.is_contiguous() else _copy(w) for w in wb[:n]]
+        bs = [None if b is None else (b if b.is_contiguous() else _copy(b)) for b in wb[n:]]
+        t = _PointwiseMaps._block(x, ws, bs)
         ys = [torch.empty(B, w.shape[0], H, W, dtype=f32, device=dev) for w in ws]
         stats = [_arena(dev).take(2 * w.shape[0] * _lib.STAT_REPLICAS) for w in ws] if want_stats else [None] * len(ws)
         for i in range(len(ws)):
             t.y[i], t.stats[i] = ys[i].data_ptr(), _ptr(stats[i])
         _lib.call("cg_pointwise_maps_fwd", ctypes.byref(t), _stream(x))
         ctx.save_for_backward(x, *ws)
+        ctx.has_bias = [b is not None for b in bs]
         if want_stats:
             ctx.mark_non_differentiable(*stats)
         return tuple(ys) + tuple(stats)
@@ -1744,23 +1748,26 @@ class _PointwiseMaps(torch.autograd.Function):
             raise RuntimeError("pointwise_maps: every map needs a gradient")
         dys = [d if d.is_contiguous() else _copy(d) for d in dys]
         dev, f32 = x.device, torch.float32
-        t = _PointwiseMaps._block(x, ws)
+        t = _PointwiseMaps._block(x, ws, [None] * n)
         dx = torch.empty_like(x)
         dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], dtype=f32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
         zb, _ = _zeros(int(_lib.lib().cg_pointwise_maps_ws_floats(x.shape[1])), dev)
         for i in range(n):
-            t.dy[i], t.dW[i] = dys[i].data_ptr(), dws[i].data_ptr()
+            t.dy[i], t.dW[i], t.db[i] = dys[i].data_ptr(), dws[i].data_ptr(), _ptr(dbs[i])
         t.dx, t.dW_ws = dx.data_ptr(), zb.data_ptr()
         _lib.call("cg_pointwise_maps_bwd", ctypes.byref(t), _stream(x))
         del dys
-        return (None, dx if ctx.needs_input_grad[1] else None) + tuple(dw if ctx.needs_input_grad[2 + i] else None for i, dw in enumerate(dws))
+        return (None, None, dx if ctx.needs_input_grad[2] else None) + tuple(dw if ctx.needs_input_grad[3 + i] else None for i, dw in enumerate(dws)) \
+            + tuple(db if (db is not None and ctx.needs_input_grad[3 + n + i]) else None for i, db in enumerate(dbs))
 
 
-def pointwise_maps(x, weights, want_stats=False):
-    """[(y_i, channel sums or None)] of the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W): one read of x forward, one read of x and
-    of every gradient backward.  Shapes outside `pointwise_maps_ok` are the caller's business."""
-    out = _PointwiseMaps.apply(bool(want_stats), x, *weights)
+def pointwise_maps(x, weights, want_stats=False, biases=None):
+    """[(y_i, channel sums or None)] of the 1x1 maps `weights` (each (M_i, C), optional `biases` (M_i) or None) of x (B,C,H,W): one read
+    of x forward, one read of x and of every gradient backward.  Shapes outside `pointwise_maps_ok` are the caller's business."""
     n = len(weights)
+    biases = [None] * n if biases is None else list(biases)
+    out = _PointwiseMaps.apply(bool(want_stats), n, x, *weights, *biases)
     return [(out[i], out[n + i] if want_stats else None) for i in range(n)]
 
 

@@ -286,6 +286,8 @@ typedef struct CgPwMaps {
   float* dx;                                             /* (B, Cin, P) */
   float* dW[CG_PWM_MAXN];
   float* dW_ws;                                          /* cg_pointwise_maps_ws_floats(Cin) zeroed floats */
+  const float* bias[CG_PWM_MAXN];                        /* optional (M_i): y_i = W_i x + bias_i (nn.Conv2d(..., 1) with bias: the residual maps) */
+  float* db[CG_PWM_MAXN];                                /* backward, optional (M_i): bias gradient, sum of dy_i over batch and positions */
 } CgPwMaps;
 int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream);
 int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream);

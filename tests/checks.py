@@ -898,32 +898,37 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6))):
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
-def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6))):
+def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6),
+                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6))):
     """ops.pointwise_maps (csrc/tower_maps.hip) against one generic contraction per map: outputs, f64 channel sums, the summed
-    input gradient, every weight gradient.  shapes: (B, Cin, (M_i), T, V)."""
+    input gradient, every weight gradient; every other shape with biases on all maps but the last (the residual maps of a block,
+    nn.Conv2d(cin, cout, 1) with its default bias) and their gradients.  shapes: (B, Cin, (M_i), T, V)."""
     g = _gen(53)
-    for (B, C, Ms, T, V) in shapes:
+    for n_shape, (B, C, Ms, T, V) in enumerate(shapes):
         x0 = _rand(g, B, C, T, V)
         w0 = [0.3 * _rand(g, M, C) for M in Ms]
+        b0 = [(_rand(g, M) if (n_shape % 2 == 1 and (k + 1 < len(Ms) or len(Ms) == 1)) else None) for k, M in enumerate(Ms)]
         gy = [_rand(g, B, M, T, V).to(device) for M in Ms]
         res = []
         for fused in (True, False):
             x = _leaf(x0, device)
             ws = [_leaf(w, device) for w in w0]
+            bs = [None if b is None else _leaf(b, device) for b in b0]
             ops.begin_step(device)
             if fused:
                 assert ops.pointwise_maps_ok(x, ws)
-                outs = ops.pointwise_maps(x, ws, want_stats=True)
+                outs = ops.pointwise_maps(x, ws, want_stats=True, biases=bs)
             else:
-                outs = [ops.contract_stats("oc,bchw->bohw", w, x) for w in ws]
+                outs = [ops.contract_stats("oc,bchw->bohw", w, x, b, "o" if b is not None else None) for w, b in zip(ws, bs)]
             ys = [o[0] for o in outs]
             sums = [_chan_sums(o[1]) for o in outs]
             torch.autograd.backward(ys, gy)
-            res.append(([y.detach() for y in ys], sums, [x.grad] + [w.grad for w in ws]))
-        what = "pointwise_maps B%d C%d M%s T%d V%d" % (B, C, Ms, T, V)
+            res.append(([y.detach() for y in ys], sums, [x.grad] + [w.grad for w in ws] + [b.grad for b in bs if b is not None]))
+        what = "pointwise_maps B%d C%d M%s T%d V%d%s" % (B, C, Ms, T, V, " +bias" if any(b is not None for b in b0) else "")
         for k in range(len(Ms)):
             assert_close(res[0][0][k], res[1][0][k], "%s y[%d]" % (what, k), rel=2e-5)
             assert_close(res[0][1][k], res[1][1][k], "%s sums[%d]" % (what, k), rel=1e-5)
+        assert len(res[0][2]) == len(res[1][2])
         for k, (a, b) in enumerate(zip(res[0][2], res[1][2])):
             assert_close(a, b, "%s grad[%d]" % (what, k), rel=5e-5, floor=max(1e-3, float(b.abs().max())))
 
