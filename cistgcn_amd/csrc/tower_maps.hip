@@ -19,7 +19,7 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
 struct CgPwGeom {
   int CinM, MM, WS, NT, CT;            // padded input channels, stacked rows, weight row stride, 16-row tiles of the stack / of Cin
-  int PT, PS, lgq;                     // tile width, LDS row stride, log2(PT / 4)
+  int PT, PS, lgq, vw;                 // tile width, LDS row stride, log2(PT / 4), vector width of the global rows (4, or 2 when P % 4 == 2)
   int tps, total, per;                 // tiles per sample, tiles, tiles per workgroup
   int tile_map[CG_PWM_MAXROWS / 16], tile_row0[CG_PWM_MAXROWS / 16], row_base[CG_PWM_MAXN];
 };
@@ -44,9 +44,23 @@ __device__ __forceinline__ void cg_pwm_fetch(const CgPwGeom& g, int np, float bu
     const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
     const float* p = pp < np ? src(row) : nullptr;         // nullptr: row outside the tensor
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p != nullptr) v = *reinterpret_cast<const float4*>(p + pp);
+    if (p != nullptr) {
+      if (g.vw == 4) v = *reinterpret_cast<const float4*>(p + pp);
+      else {                                               // rows aligned to 8 bytes (P % 4 == 2): pairs; the last quad of a row may be half
+        const float2 lo = *reinterpret_cast<const float2*>(p + pp);
+        v.x = lo.x; v.y = lo.y;
+        if (pp + 2 < np) { const float2 hi = *reinterpret_cast<const float2*>(p + pp + 2); v.z = hi.x; v.w = hi.y; }
+      }
+    }
     buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
   }
+}
+// four consecutive result positions pq .. pq + 3 (pq % 4 == 0) of a row with np valid positions
+__device__ __forceinline__ void cg_pwm_store_quad(const CgPwGeom& g, float* row, int pq, int np, const cg_f32x4& c) {
+  if (pq >= np) return;
+  if (g.vw == 4) { *reinterpret_cast<float4*>(row + pq) = make_float4(c[0], c[1], c[2], c[3]); return; }
+  *reinterpret_cast<float2*>(row + pq) = make_float2(c[0], c[1]);
+  if (pq + 2 < np) *reinterpret_cast<float2*>(row + pq + 2) = make_float2(c[2], c[3]);
 }
 __device__ __forceinline__ void cg_pwm_commit(const CgPwGeom& g, int rows, const float buf[16], float* img) {
 #pragma unroll
@@ -114,7 +128,8 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
           cg_f32x4 c = h ? c1 : c0;
           c[0] += bv; c[1] += bv; c[2] += bv; c[3] += bv;
           if (pq < np) {
-            *reinterpret_cast<float4*>(t.y[i] + ((long long)b * t.M[i] + m) * t.P + p0 + pq) = make_float4(c[0], c[1], c[2], c[3]);
+            cg_pwm_store_quad(g, t.y[i] + ((long long)b * t.M[i] + m) * t.P + p0, pq, np, c);
+            if (pq + 2 >= np) { c[2] = 0.f; c[3] = 0.f; }        // half quad at the end of a row (P % 4 == 2)
             s1 += (c[0] + c[1]) + (c[2] + c[3]); s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
           }
         }
@@ -228,7 +243,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
         for (int h = 0; h < 2; ++h) {
           const int pq = (h ? n1 : n0) + 4 * slot;
           const cg_f32x4 cc = h ? c1 : c0;
-          if (pq < np) *reinterpret_cast<float4*>(t.dx + ((long long)b * t.Cin + c) * t.P + p0 + pq) = make_float4(cc[0], cc[1], cc[2], cc[3]);
+          cg_pwm_store_quad(g, t.dx + ((long long)b * t.Cin + c) * t.P + p0, pq, np, cc);
         }
       }
     }
@@ -276,7 +291,8 @@ __global__ void cg_pwm_fold_kernel(CgPwArgs a) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   if (!t || t->n <= 0 || t->n > CG_PWM_MAXN) return CG_EARG;
-  if (t->B <= 0 || t->Cin <= 0 || t->Cin > 64 || t->P <= 0 || (t->P & 3)) return CG_ESHAPE;
+  if (t->B <= 0 || t->Cin <= 0 || t->Cin > 64 || t->P <= 0 || (t->P & 1)) return CG_ESHAPE;
+  g->vw = (t->P & 3) == 0 ? 4 : 2;
   if (!t->x) return CG_EARG;
   int rows = 0, tile = 0;
   for (int i = 0; i < t->n; ++i) {

@@ -596,7 +596,14 @@ class CISTGCN(nn.Module):
         x = x7.view(B, 1, To, V * 3)
         c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
         tr = self.training
-        o = _run_items([_pw_item(x, c1[0], tr), _rows_item(x, c2[0], tr), _pw_item(x, c3[0], tr)])
+        w13 = [c[0].weight.view(c[0].out_channels, c[0].in_channels) for c in (c1, c3)]
+        if self.fused_maps and B * To * V * 3 * sum(w.shape[0] for w in w13) >= self.stack_min_elements and ops.pointwise_maps_ok(x, w13):
+            # the two 1 -> hidden_dim maps read the sequence once and write their (B, hidden_dim, To, 3V) results from one kernel
+            xa, xb = ops.fanout(x, 2)
+            y13 = ops.pointwise_maps(xa, w13, tr, biases=[c1[0].bias, c3[0].bias])
+            o = [y13[0], _run_items([_rows_item(xb, c2[0], tr)])[0], y13[1]]
+        else:
+            o = _run_items([_pw_item(x, c1[0], tr), _rows_item(x, c2[0], tr), _pw_item(x, c3[0], tr)])
         r = self._na_many([dict(x=o[i], bn=c[1], prelu=c[2]) for i, c in enumerate((c1, c2, c3))])
         y1, y2, ym = ops.max_bc(r[0]), ops.max_bc(r[1]), ops.mean_bc(r[2])
         o = _run_items([_lin_item(y, h[0], False) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))])

@@ -1700,7 +1700,7 @@ def pointwise_maps_ok(x, weights):
         return False
     B, C, H, W = x.shape
     rows = sum((w.shape[0] + 15) // 16 * 16 for w in weights)
-    return C <= 64 and (H * W) % 4 == 0 and rows <= 128 and all(w.shape[0] <= 64 for w in weights)
+    return C <= 64 and (H * W) % 2 == 0 and rows <= 128 and all(w.shape[0] <= 64 for w in weights)
 
 
 class _PointwiseMaps(torch.autograd.Function):

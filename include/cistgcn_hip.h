@@ -273,7 +273,7 @@ long long cg_fpn_conv_ws_floats(int B, int C, int O, int n);
 /* ---- stacked pointwise maps of one input: the first convolutions of the Map2Adj towers of a block, CISTGCN.py:138-163 applied
  * to the normalised block input by :183-186 (up to four 1x1 convolutions of the same (B,C,T,V) tensor).  Forward: every y_i =
  * W_i x from one read of x, with the f64 channel sums of y_i (train-mode BatchNorm behind it).  Backward: dx = sum_i W_i^T dy_i and
- * every dW_i = dy_i x^T from one read of x and of each dy_i.  x (B,Cin,P) contiguous, P = T*V with P % 4 == 0, Cin <= 64,
+ * every dW_i = dy_i x^T from one read of x and of each dy_i.  x (B,Cin,P) contiguous, P = T*V with P % 2 == 0 (rows of 16- or 8-byte alignment), Cin <= 64,
  * M_i <= 64, sum of ceil16(M_i) <= 128; other shapes: CG_ESHAPE (the caller uses cg_contract_many). */
 #define CG_PWM_MAXN 4
 typedef struct CgPwMaps {

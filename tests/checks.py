@@ -899,7 +899,7 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6))):
 
 
 def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6),
-                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6))):
+                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6), (2, 1, (64, 64), 25, 66), (3, 32, (16, 16, 16, 16), 5, 10))):      # the last two: P % 4 == 2
     """ops.pointwise_maps (csrc/tower_maps.hip) against one generic contraction per map: outputs, f64 channel sums, the summed
     input gradient, every weight gradient; every other shape with biases on all maps but the last (the residual maps of a block,
     nn.Conv2d(cin, cout, 1) with its default bias) and their gradients.  shapes: (B, Cin, (M_i), T, V)."""
