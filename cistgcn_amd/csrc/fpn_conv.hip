@@ -12,6 +12,15 @@
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
+// four consecutive positions p .. p + 3 (p % 4 == 0) of a row of P floats: one float4 when the rows are 16-byte aligned (P % 4 == 0),
+// float2 pairs when P % 4 == 2 (25-joint skeletons: 10 x 25 planes; the last quad of a row is then half)
+__device__ __forceinline__ void cg_fpn_store_quad(float* row, int p, int P, float a, float b, float c, float d) {
+  if (p >= P) return;
+  if ((P & 3) == 0) { *reinterpret_cast<float4*>(row + p) = make_float4(a, b, c, d); return; }
+  *reinterpret_cast<float2*>(row + p) = make_float2(a, b);
+  if (p + 2 < P) *reinterpret_cast<float2*>(row + p + 2) = make_float2(c, d);
+}
+
 #define CG_FPN_THREADS 512
 #define CG_FPN_PAD 3
 
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_fwd_kernel(CgFpnArgs a)
         if (h == 1 && pt1 == pt0) break;
         const int p = 16 * (h ? pt1 : pt0) + 4 * slot;
         const cg_f32x4 c = h ? c1 : c0;
-        if (p < g.P) *reinterpret_cast<float4*>(yb + (long long)o * g.P + p) = make_float4(c[0] + bias, c[1] + bias, c[2] + bias, c[3] + bias);
+        cg_fpn_store_quad(yb + (long long)o * g.P, p, g.P, c[0] + bias, c[1] + bias, c[2] + bias, c[3] + bias);
       }
     }
   }
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dx_kernel(CgFpnArgs a) 
     const int id = u * nw + wave;
     if (id < PT * CT) {
       const int pt = id / CT, ct = id - pt * CT, c = 16 * ct + l15, p = 16 * pt + 4 * slot;
-      if (c < t.C && p < g.P) *reinterpret_cast<float4*>(dxb + (long long)c * g.P + p) = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+      if (c < t.C) cg_fpn_store_quad(dxb + (long long)c * g.P, p, g.P, acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
     }
   }
 }
@@ -208,10 +217,18 @@ __global__ __launch_bounds__(CG_FPN_THREADS) void cg_fpn_dw_kernel(CgFpnArgs a) 
     __syncthreads();
     cg_fpn_fill(t.x + (long long)b * t.xs[0], t.xs[1], t.xs[2], t.C, t.H, t.W, g, sX);
     const float* dyb = t.dy[di] + (long long)b * t.O * g.P;
+    if ((g.P & 3) == 0) {
 #pragma unroll 4
-    for (int e = tid; e < t.O * (g.P / 4); e += CG_FPN_THREADS) {
-      const int o = e / (g.P / 4), p = 4 * (e - o * (g.P / 4));
-      *reinterpret_cast<float4*>(sD + o * DS + p) = *reinterpret_cast<const float4*>(dyb + (long long)o * g.P + p);
+      for (int e = tid; e < t.O * (g.P / 4); e += CG_FPN_THREADS) {
+        const int o = e / (g.P / 4), p = 4 * (e - o * (g.P / 4));
+        *reinterpret_cast<float4*>(sD + o * DS + p) = *reinterpret_cast<const float4*>(dyb + (long long)o * g.P + p);
+      }
+    } else {                                                        // rows of 8-byte alignment: pairs
+#pragma unroll 4
+      for (int e = tid; e < t.O * (g.P / 2); e += CG_FPN_THREADS) {
+        const int o = e / (g.P / 2), p = 2 * (e - o * (g.P / 2));
+        *reinterpret_cast<float2*>(sD + o * DS + p) = *reinterpret_cast<const float2*>(dyb + (long long)o * g.P + p);
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -301,7 +318,7 @@ static int cg_fpn_geometry(const CgFpnConv* t, CgFpnGeom* g) {
   for (int i = 0; i < t->n; ++i) if (t->dil[i] < 1 || t->dil[i] > CG_FPN_PAD) return CG_ESHAPE;
   g->HP = t->H + 2 * CG_FPN_PAD; g->WP = t->W + 2 * CG_FPN_PAD; g->IMG = g->HP * g->WP;
   g->P = t->H * t->W; g->PM = (g->P + 15) & ~15;
-  if ((g->P & 3) || g->PM > 256) return CG_ESHAPE;
+  if ((g->P & 1) || g->PM > 256) return CG_ESHAPE;
   g->K = t->C * 9; g->KP = (g->K + 15) & ~15; g->KS = g->KP + 4;
   g->K2 = t->O * 9; g->KP2 = (g->K2 + 15) & ~15; g->KS2 = g->KP2 + 4;
   g->OM = (t->O + 15) & ~15; g->CM = (t->C + 15) & ~15;

@@ -470,8 +470,9 @@ def check_copies(device):
     _run(lambda t: sum(ops.fanout(t, 2)), lambda t: 2.0 * t, [_rand(g, 3, 6)], device, what="fanout 2-D")
 
 
-def check_dilated_convs(device, shapes=((2, 5, 4, 10, 7), (3, 6, 5, 4, 6), (2, 25, 25, 10, 22), (2, 50, 25, 10, 22))):
-    """(B, Cin, Cout, H, W): H * W % 4 != 0 takes the generic contraction, the others the whole-sample kernels (csrc/fpn_conv.hip)"""
+def check_dilated_convs(device, shapes=((2, 5, 4, 10, 7), (3, 6, 5, 4, 6), (2, 25, 25, 10, 22), (2, 50, 25, 10, 22), (2, 25, 25, 10, 25), (2, 3, 4, 5, 5))):
+    """(B, Cin, Cout, H, W): odd H * W takes the generic contraction, the others the whole-sample kernels (csrc/fpn_conv.hip; float2 rows when
+    H * W % 4 == 2: 10 x 7, 10 x 25)"""
     floor, ops._FPN_MIN_BATCH = ops._FPN_MIN_BATCH, 1          # the whole-sample kernels are switched on by batch size in production
     try:
         for shape in shapes:
