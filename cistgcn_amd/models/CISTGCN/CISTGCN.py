@@ -226,6 +226,7 @@ class CISTGCN(nn.Module):
         self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
         self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
+        self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
         self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
@@ -424,7 +425,7 @@ class CISTGCN(nn.Module):
         # input in one pass per group as well (a group: up to 128 stacked output rows)
         res_convs = ([d.residual[0] for d in doms] if has_res else []) + ([m.residual[0]] if has_bres else [])
         res_w = [c.weight.view(c.out_channels, c.in_channels) for c in res_convs]
-        res_groups = self._map_groups(xn0, res_w) if (big and self.fused_maps and res_convs) else None
+        res_groups = self._map_groups(xn0, res_w) if (big and self.fused_maps and self.fused_res_maps and res_convs) else None
         xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (len(res_groups) if res_groups else 0)
                              + (0 if has_res else 2) + (0 if has_bres else 1)))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]

@@ -152,12 +152,21 @@ def assert_grads_strict(named_got, named_ref, what="", rel=1e-4, floor=1.0, rel_
     relative errors."""
     worst = (0.0, None)
     rels = []
+    ranked = []
     for k, ref in named_ref.items():
         got = named_got[k]
         got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
         ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else ref
         ok, err, bound = tol_ok(got, ref, rel, floor)
-        assert ok, "%s grad %s: max err %.3e > bound %.3e" % (what, k, err, bound)
+        ranked.append((err / bound, k, err, float(np.abs(ref).max()) if ref.size else 0.0))
+    ranked.sort(reverse=True)
+    listing = "; ".join("%s %.2f of the bound (err %.2e, max|ref| %.2e)" % (k, r, e, m) for r, k, e, m in ranked[:6])
+    for k, ref in named_ref.items():
+        got = named_got[k]
+        got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+        ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else ref
+        ok, err, bound = tol_ok(got, ref, rel, floor)
+        assert ok, "%s grad %s: max err %.3e > bound %.3e; the six tensors closest to the bound: %s" % (what, k, err, bound, listing)
         if err / bound > worst[0]:
             worst = (err / bound, k)
         mx = float(np.abs(ref).max()) if ref.size else 0.0
