@@ -26,17 +26,23 @@ struct CgPwGeom {
 struct CgPwArgs { CgPwMaps t; CgPwGeom g; };
 
 // stacked weights -> sW [MM][WS]; rows beyond a map's M_i and columns beyond Cin are zero
+// stacked weights [MM][WS] into LDS, zero in the padding.  Map by map (the map index is a scalar): looking the map of a stacked row up
+// per element - kernel-argument tables indexed by a lane value, three dependent loads - made this prologue 30 k cycles
 __device__ __forceinline__ void cg_pwm_weights(const CgPwArgs& a, float* sW) {
   const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
-  const int n = g.MM * g.WS;
+  for (int e = threadIdx.x; e < g.MM * g.WS; e += CG_PWM_THREADS) sW[e] = 0.f;
+  __syncthreads();
+  for (int i = 0; i < t.n; ++i) {
+    const float* __restrict__ W = t.W[i];
+    const int n = t.M[i] * t.Cin, r0 = g.row_base[i];
 #pragma unroll 4
-  for (int e = threadIdx.x; e < n; e += CG_PWM_THREADS) {
-    const int r = e / g.WS, c = e - r * g.WS, tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
-    sW[e] = (m < t.M[i] && c < t.Cin) ? t.W[i][m * t.Cin + c] : 0.f;
+    for (int e = threadIdx.x; e < n; e += CG_PWM_THREADS) {
+      const int m = e / t.Cin, c = e - m * t.Cin;
+      sW[(r0 + m) * g.WS + c] = W[e];
+    }
   }
 }
 
-// a thread's share of a [rows][PT] tile: float4 number r is element 4 * (tid + 512 r) of the tile image
 template <typename SRC>
 __device__ __forceinline__ void cg_pwm_fetch(const CgPwGeom& g, int np, float buf[16], SRC src) {
 #pragma unroll
@@ -61,6 +67,25 @@ __device__ __forceinline__ void cg_pwm_store_quad(const CgPwGeom& g, float* row,
   if (g.vw == 4) { *reinterpret_cast<float4*>(row + pq) = make_float4(c[0], c[1], c[2], c[3]); return; }
   *reinterpret_cast<float2*>(row + pq) = make_float2(c[0], c[1]);
   if (pq + 2 < np) *reinterpret_cast<float2*>(row + pq + 2) = make_float2(c[2], c[3]);
+}
+// the same fetch from row pointers resolved ONCE per kernel (slot r of a thread is the same tile row in every tile): base[r] is the row
+// at sample 0 / position 0 or nullptr, off[r] the element offset of this tile's sample and first position
+__device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, int np, float buf[16], const float* const base[4], const long long off[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << g.lgq) - 1));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (base[r] != nullptr && pp < np) {
+      const float* p = base[r] + off[r] + pp;
+      if (g.vw == 4) v = *reinterpret_cast<const float4*>(p);
+      else {
+        const float2 lo = *reinterpret_cast<const float2*>(p);
+        v.x = lo.x; v.y = lo.y;
+        if (pp + 2 < np) { const float2 hi = *reinterpret_cast<const float2*>(p + 2); v.z = hi.x; v.w = hi.y; }
+      }
+    }
+    buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
+  }
 }
 __device__ __forceinline__ void cg_pwm_commit(const CgPwGeom& g, int rows, const float buf[16], float* img) {
 #pragma unroll
@@ -149,6 +174,21 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
 // ======================================================================================================================
 // backward
 // ======================================================================================================================
+// Diagnostic build only (-DCG_TAIL_STAMPS, tools/stamps_planes.py --build): shader-clock stamps of thread 0 at the phase boundaries of
+// the backward kernel, read by tools/stamps_pwm.py; the shipped library has no stamp.
+#ifdef CG_TAIL_STAMPS
+__device__ unsigned long long* cg_pwm_stamp_buf = nullptr;
+extern "C" int cg_pwm_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(cg_pwm_stamp_buf), &p, sizeof(p)); }
+#define CG_PSTAMP()                                                                                     \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && cg_pwm_stamp_buf && nst < 255) cg_pwm_stamp_buf[blockIdx.x * 256 + (++nst)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define CG_PSTAMP_END() do { if (threadIdx.x == 0 && cg_pwm_stamp_buf) cg_pwm_stamp_buf[blockIdx.x * 256] = nst; } while (0)
+#else
+#define CG_PSTAMP() do { } while (0)
+#define CG_PSTAMP_END() do { } while (0)
+#endif
+
 #define CG_PWM_MAXW 4        // weight-gradient register tiles per wave: (128 / 16) * (64 / 16) / 8 waves
 
 __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) {
@@ -159,16 +199,30 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_PWM_THREADS / 64;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
+  int nst = 0; (void)nst;
+  CG_PSTAMP();
   float xbuf[16], dbuf[16];
+  // Row pointers of the four staging slots, resolved once: looking the map of a stacked row up in the kernel arguments (three
+  // dependent loads indexed by a lane value) per tile kept the prefetch ISSUE at 9 k cycles of a 24 k-cycle tile (tools/stamps_pwm.py)
+  const float* xrow[4]; const float* drow[4];
+  long long dstr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ((int)threadIdx.x + CG_PWM_THREADS * r) >> g.lgq;
+    xrow[r] = row < t.Cin ? t.x + (long long)row * t.P : nullptr;
+    drow[r] = nullptr; dstr[r] = 0;
+    if (row < g.MM) {
+      const int tile = row >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (row & 15);
+      if (m < t.M[i]) { drow[r] = t.dy[i] + (long long)m * t.P; dstr[r] = (long long)t.M[i] * t.P; }
+    }
+  }
   auto fetch = [&](int lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
-    const float* xb = t.x + (long long)b * t.Cin * t.P + p0;
-    cg_pwm_fetch(g, np, xbuf, [&](int row) { return row < t.Cin ? xb + (long long)row * t.P : nullptr; });
-    cg_pwm_fetch(g, np, dbuf, [&](int row) -> const float* {
-      if (row >= g.MM) return nullptr;
-      const int tile = row >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (row & 15);
-      return m < t.M[i] ? t.dy[i] + ((long long)b * t.M[i] + m) * t.P + p0 : nullptr;
-    });
+    long long xo[4], doff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { xo[r] = (long long)b * t.Cin * t.P + p0; doff[r] = (long long)b * dstr[r] + p0; }
+    cg_pwm_fetch_rows(g, np, xbuf, xrow, xo);
+    cg_pwm_fetch_rows(g, np, dbuf, drow, doff);
   };
   fetch(lid0);
   cg_pwm_weights(a, sW);
@@ -178,13 +232,17 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   for (int u = 0; u < CG_PWM_MAXW; ++u) { wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; bacc[u] = wacc[u]; }
   bool want_db = false;
   for (int i = 0; i < t.n; ++i) want_db = want_db || t.db[i] != nullptr;
+  CG_PSTAMP();
   for (int lid = lid0; lid < lid1; ++lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
     __syncthreads();
+    CG_PSTAMP();
     cg_pwm_commit(g, g.MM, dbuf, sD);                              // rows of the padding and positions beyond the tensor arrive as zeros
     cg_pwm_commit(g, t.Cin, xbuf, sX);
     __syncthreads();
+    CG_PSTAMP();
     if (lid + 1 < lid1) fetch(lid + 1);
+    CG_PSTAMP();
     // dW[m][c] += sum_p dy[m][p] x[c][p]: two register tiles at a time (independent MFMA chains)
 #pragma unroll
     for (int u = 0; u < CG_PWM_MAXW; u += 2) {
@@ -221,6 +279,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
         if (two) { wacc[u + 1] = w1; bacc[u + 1] = s1; }
       }
     }
+    CG_PSTAMP();
     // dx[p][c] = sum_m dy[m][p] W[m][c]
     for (int w = wave; w < (g.PT / 32) * g.CT; w += nw) {
       const int pg = w / g.CT, ct = w - pg * g.CT, n0 = 32 * pg, n1 = n0 + 16;
@@ -248,6 +307,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
       }
     }
   }
+  CG_PSTAMP();
   float* ws = t.dW_ws + (long long)(blockIdx.x % CG_PWM_REPLICAS) * CG_PWM_MAXROWS * t.Cin;
 #pragma unroll
   for (int u = 0; u < CG_PWM_MAXW; ++u) {
@@ -266,6 +326,8 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
       }
     }
   }
+  CG_PSTAMP();
+  CG_PSTAMP_END();
 }
 
 __global__ void cg_pwm_fold_kernel(CgPwArgs a) {
