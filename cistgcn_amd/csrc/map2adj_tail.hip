@@ -528,33 +528,50 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
         v[j] = !ok ? 0.f : t.train ? k[2] * (gbuf[off + j] - k[4] - (ebuf[off + j] - k[0]) * k[1] * k[5]) : gbuf[off + j] * k[2];
       cg_adj_put<VEC>(g, sDE, c, pp, v);
     });
+    // The seed tile o[k][p] = S[k][a] Q[k][b'] of this tile, ONCE, into the image that `do` takes later (it is free until then):
+    // KcM * PT = 4096 = 16 consecutive positions of one slab per thread, (a, b') advanced by steps instead of one division and two
+    // table reads per element and per tile of output rows (the B fragments used to regenerate it MT times)
+    {
+      const int per_row = g.PT >> 4, k = tid / per_row, pp0 = 16 * (tid - k * per_row), p = p0 + pp0;
+      const bool kok = k < t.Kc;
+      int a = (int)cg_adj_div((unsigned)p, g.magicJ), bp = p - a * t.J;
+      float sv = (kok && a < t.J) ? sS[k * g.JS + a] : 0.f;
+      float* dst = sDO + k * g.PS + pp0;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = (kok && p + 4 * j4 + j < g.Pn) ? sv * sQ[k * g.JS + bp] : 0.f;
+          if (++bp == t.J) { bp = 0; ++a; sv = (kok && a < t.J) ? sS[k * g.JS + a] : 0.f; }
+        }
+        *reinterpret_cast<float4*>(dst + 4 * j4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
     __syncthreads();
     if (tile + 1 < tile1 && !(dbg & 8)) {
       const int q0 = p0 + g.PT, nq = min(g.PT, g.Pn - q0);
       cg_adj_fetch<VEC>(g, gsrc, t.Kc, g.Pn, q0, nq, gbuf);
       if (t.train) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, q0, nq, ebuf);
     }
-    // dW0[u][k] += sum_p de[u][p] o[k][p]: the seed generated along p in the B fragments (lane = slab k)
+    // dW0[u][k] += sum_p de[u][p] o[k][p]
 #pragma unroll
     for (int u = 0; u < CG_ADJ_MAXW; ++u) {
       const int id = u * nw + wave;
       if (id < MT * MT && !(dbg & 1)) {
-        const int mt = id / MT, n2 = id - mt * MT, kk = 16 * n2 + l15;
+        const int mt = id / MT, n2 = id - mt * MT;
         const float* ap = cg_tfrag_ptr<0>(sDE + 16 * mt * g.PS, g.PS, l15, slot);
+        const float* op = cg_tfrag_ptr<0>(sDO + 16 * n2 * g.PS, g.PS, l15, slot);
 #pragma unroll 4
         for (int k0 = 0; k0 < g.PT; k0 += 16) {
-          float av[4];
-          cg_tfrag<0>(ap, g.PS, k0, av);
+          float av[4], ov[4];
+          cg_tfrag<0>(ap, g.PS, k0, av); cg_tfrag<0>(op, g.PS, k0, ov);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int p = p0 + k0 + 4 * slot + s;
-            float o = 0.f;
-            if (p < g.Pn) { const int a = (int)cg_adj_div((unsigned)p, g.magicJ); o = sS[kk * g.JS + a] * sQ[kk * g.JS + p - a * t.J]; }
-            wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], o, wacc[u], 0, 0, 0);
-          }
+          for (int s = 0; s < 4; ++s) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ov[s], wacc[u], 0, 0, 0);
         }
       }
     }
+    __syncthreads();                                    // the seed image has been read: `do` overwrites it
     // do[k][p] = sum_u W0[u][k] de[u][p]  ->  dS (runs of equal a inside the 16 lanes of a column group), image for dQ
     for (int w = wave; w < MT * g.NP && !(dbg & 2); w += nw) {
       const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
