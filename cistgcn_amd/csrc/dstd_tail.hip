@@ -448,9 +448,9 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
   for (int u = 0; u < CG_TAIL_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
   const float alpha_c = t.alpha_c[0];
   const float alpha_p0 = t.alpha_p[0][0], alpha_p1 = t.alpha_p[1][0];      // once: a global load inside the matrix phases stalls every task
-  float racc[CG_TAIL_K3_TASKS][4][3];              // per lane: sums of g_p, g_p * zhat and the d alpha_p terms of the wave's d a tasks
+  float racc[CG_TAIL_K3_TASKS][3];                 // per lane: sums of g_p, g_p * zhat and the d alpha_p terms of its channel in the wave's d a tasks
 #pragma unroll
-  for (int i = 0; i < CG_TAIL_K3_TASKS * 12; ++i) (&racc[0][0][0])[i] = 0.f;
+  for (int i = 0; i < CG_TAIL_K3_TASKS * 3; ++i) (&racc[0][0])[i] = 0.f;
   CG_TSTAMP();
   // Loads of a tile travel while something else runs: y / r of tile k+1 are issued in front of the matrix phases of tile k
   // (registers yq / rq), h0 / dout / gate / dpooled of tile k in front of the VALU work that builds the zhat image
@@ -550,8 +550,10 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       }
     }
     CG_TSTAMP();
-    // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat
-    // (per lane in registers over all tiles of the workgroup: a wave owns the same (at most CG_TAIL_K3_TASKS) c2 tiles in every tile)
+    // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat.
+    // Result tiles are position-major (dh0 fragments as the A operand): a lane holds four consecutive positions of ONE channel -
+    // zhat comes as one 16-byte LDS read, g_p leaves as one 16-byte store, the channel constants are per lane, and the sums of a
+    // channel are three registers per task over all tiles of the workgroup (a wave owns the same c2 tiles in every tile)
 #pragma unroll
     for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
       const int w = wave + nw * ti;
@@ -565,45 +567,55 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         float av[4], b0v[4], b1v[4];
         cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS3, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS3, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {                       // C[position 4 * slot + q][channel l15]
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
         }
       }
+      const int c2 = 16 * mt + l15;
+      const bool cok = c2 < C2;
+      const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
+      const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (i ? alpha_p1 : alpha_p0) : 0.f;
+      float* gpr = t.gp[i] + ((long long)b * C + c) * P + p0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c2 = 16 * mt + 4 * slot + q;
-        const bool cok = c2 < C2;
-        const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
-        const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (i ? alpha_p1 : alpha_p0) : 0.f;
+      for (int h = 0; h < 2; ++h) {
+        const int pq = (h ? n1 : n0) + 4 * slot;
+        const cg_f32x4 cc = h ? c1 : c0;
+        if (cok && pq < np) {
+          const float4 z4 = *reinterpret_cast<const float4*>(sZ + c2 * CG_TAIL_PS3 + pq);
+          const float zh[4] = {z4.x, z4.y, z4.z, z4.w};
+          float gq[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int pp = (h ? n1 : n0) + l15;
-          const float da = h ? c1[q] : c0[q];
-          if (cok && pp < np) {
-            const float zh = sZ[c2 * CG_TAIL_PS3 + pp], v = gam * zh + bet;
-            const float g = v > 0.f ? da : alp * da;
-            t.gp[i][((long long)b * C + c) * P + p0 + pp] = g;
-            racc[ti][q][0] += g; racc[ti][q][1] += g * zh;
-            if (!(v > 0.f)) racc[ti][q][2] += da * v;
+          for (int q = 0; q < 4; ++q) {
+            const float v = gam * zh[q] + bet, da = cc[q];
+            const bool in = pq + q < np;
+            gq[q] = v > 0.f ? da : alp * da;
+            if (in) {
+              racc[ti][0] += gq[q]; racc[ti][1] += gq[q] * zh[q];
+              if (!(v > 0.f)) racc[ti][2] += da * v;
+            }
+          }
+          if (vec) *reinterpret_cast<float4*>(gpr + pq) = make_float4(gq[0], gq[1], gq[2], gq[3]);      // np % 4 == 0: the quad is inside the row
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (pq + q < np) gpr[pq + q] = gq[q];
           }
         }
       }
     }
   }
   CG_TSTAMP();
-  // one cross-lane reduction for all tiles (a row of 16 lanes holds the positions of a channel)
+  // the four lanes l15 + 16 * slot hold the partial sums of one channel: two exchanges, then one LDS atomic per channel and task
 #pragma unroll
   for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
     const int w = wave + nw * ti;
     if (w >= NT2 * (CG_TAIL_PT3 / 32)) break;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c2 = 16 * (w / (CG_TAIL_PT3 / 32)) + 4 * slot + q;
-      const float s1 = cg_row16_sum(racc[ti][q][0]), s2 = cg_row16_sum(racc[ti][q][1]), sa = cg_row16_sum(racc[ti][q][2]);
-      if (l15 == 0 && c2 < C2) {
-        atomicAdd(&sRed[2 * c2], (double)s1); atomicAdd(&sRed[2 * c2 + 1], (double)s2); atomicAdd(&sRed[2 * C2M + (c2 >= C ? 1 : 0)], (double)sa);
-      }
+    const int c2 = 16 * (w / (CG_TAIL_PT3 / 32)) + l15;
+    float s1 = racc[ti][0], s2 = racc[ti][1], sa = racc[ti][2];
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64); sa += __shfl_xor(sa, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64); sa += __shfl_xor(sa, 32, 64);
+    if (slot == 0 && c2 < C2) {
+      atomicAdd(&sRed[2 * c2], (double)s1); atomicAdd(&sRed[2 * c2 + 1], (double)s2); atomicAdd(&sRed[2 * C2M + (c2 >= C ? 1 : 0)], (double)sa);
     }
   }
   __syncthreads();
