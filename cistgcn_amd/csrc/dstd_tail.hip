@@ -452,14 +452,29 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
 #pragma unroll
   for (int i = 0; i < CG_TAIL_K3_TASKS * 3; ++i) (&racc[0][0])[i] = 0.f;
   CG_TSTAMP();
-  // Loads of a tile travel while something else runs: y / r of tile k+1 are issued in front of the matrix phases of tile k
-  // (registers yq / rq), h0 / dout / gate / dpooled of tile k in front of the VALU work that builds the zhat image
+  // Loads of a tile travel while something else runs: y / r / h0 / dout / gate / dpooled of tile k+1 are issued in front of the
+  // matrix phases of tile k (registers yq / rq / h4 / d4 / gt / dp)
   const bool vec = (P & 3) == 0;
   constexpr int DQ = CG_TAIL_PT3 / 16;               // quads of the dh0 image per thread (C <= 64)
   float4 yq[CG_TAIL_PT3 / 8], rq[CG_TAIL_PT3 / 8];
+  float4 h4[DQ], d4[DQ];
+  float gt[DQ], dp[DQ];
+  auto dh_load = [&](int b, int p0, int np) {            // h0 / dout quads and the per-row gate terms of a tile's dh0 image
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+      const int e = tid + q * CG_TAIL_THREADS, c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
+      h4[q] = make_float4(0.f, 0.f, 0.f, 0.f); d4[q] = h4[q]; gt[q] = 0.f; dp[q] = 0.f;
+      if (c < C && pp < np) {
+        const long long off = ((long long)b * C + c) * P + p0 + pp;
+        h4[q] = *reinterpret_cast<const float4*>(t.h0 + off); d4[q] = *reinterpret_cast<const float4*>(t.dout + off);
+        gt[q] = t.gate[(long long)b * C + c]; dp[q] = t.dpooled[(long long)b * C + c] * invP;
+      }
+    }
+  };
   if (vec) {
     const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT3;
     cg_tail_act_load<CG_TAIL_PT3>(t, b, p0, min(CG_TAIL_PT3, P - p0), yq, rq);
+    dh_load(b, p0, min(CG_TAIL_PT3, P - p0));
   }
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
@@ -468,18 +483,6 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     __syncthreads();
     CG_TSTAMP();
     if (vec) {
-      float4 h4[DQ], d4[DQ];
-      float gt[DQ], dp[DQ];
-#pragma unroll
-      for (int q = 0; q < DQ; ++q) {
-        const int e = tid + q * CG_TAIL_THREADS, c = e / (CG_TAIL_PT3 / 4), pp = 4 * (e - c * (CG_TAIL_PT3 / 4));
-        h4[q] = make_float4(0.f, 0.f, 0.f, 0.f); d4[q] = h4[q]; gt[q] = 0.f; dp[q] = 0.f;
-        if (c < C && pp < np) {
-          const long long off = ((long long)b * C + c) * P + p0 + pp;
-          h4[q] = *reinterpret_cast<const float4*>(t.h0 + off); d4[q] = *reinterpret_cast<const float4*>(t.dout + off);
-          gt[q] = t.gate[(long long)b * C + c]; dp[q] = t.dpooled[(long long)b * C + c] * invP;
-        }
-      }
       cg_tail_act_finish<CG_TAIL_PT3>(t, sK, seed, b, p0, np, yq, rq, sZ, 1);
       CG_TSTAMP();
       // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
@@ -523,6 +526,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     if (vec && it + 1 < per && lid + 1 < total) {
       const int b2 = (lid + 1) / tiles_per_sample, q0 = (lid + 1 - b2 * tiles_per_sample) * CG_TAIL_PT3;
       cg_tail_act_load<CG_TAIL_PT3>(t, b2, q0, min(CG_TAIL_PT3, P - q0), yq, rq);
+      dh_load(b2, q0, min(CG_TAIL_PT3, P - q0));
     }
     CG_TSTAMP();
     // dWc[co][c2] += sum_p dh0[co][p] a[c2][p],  a = PReLU_p(gamma zhat + beta) rebuilt from zhat in the B fragments
