@@ -118,7 +118,7 @@ __device__ __forceinline__ void cg_tail_keep4(const CgDstdTail& t, int i, unsign
 // tile (PT / 8 quads of y and of r per thread at C <= 64) before anything waits, `finish` turns them into the LDS image.  The
 // GEMM phases call `load` for tile k+1 right before the matrix-core work of tile k, so the reads travel while the MFMAs run.
 template <int PT>
-__device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int p0, int np, float4 yq[PT / 8], float4 rq[PT / 8]) {
+__device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int p0, int np, float4 yq[PT / 8], float4 rq[PT / 8], float wq[PT / 8]) {
   // quads q < PT / 16 belong to branch 0, the others to branch 1: the branch (and with it the base pointers) is uniform per
   // quad slot, so the addresses are scalar base + 32-bit lane offset (C <= 64: C * PT / 4 work items per branch fit PT / 16 slots)
   const int C = t.C, P = t.T * t.V;
@@ -126,19 +126,20 @@ __device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int
   for (int q = 0; q < PT / 8; ++q) {
     const int i = q / (PT / 16), e = threadIdx.x + (q - i * (PT / 16)) * CG_TAIL_THREADS;
     const int c = e / (PT / 4), pp = 4 * (e - c * (PT / 4));
-    yq[q] = make_float4(0.f, 0.f, 0.f, 0.f); rq[q] = yq[q];
+    yq[q] = make_float4(0.f, 0.f, 0.f, 0.f); rq[q] = yq[q]; wq[q] = 0.f;
     if (c < C && pp < np) {
       const float* yb = t.y[i] + (long long)b * C * P + p0;
       const float* rb = t.r[i] + (long long)b * C * P + p0;
       const int off = c * P + pp;
       yq[q] = *reinterpret_cast<const float4*>(yb + off); rq[q] = *reinterpret_cast<const float4*>(rb + off);
+      wq[q] = t.w[i][(long long)b * C + c];               // the row's gate travels with the row (a load inside `finish` is a round trip in front of its arithmetic)
     }
   }
 }
 
 template <int PT>
 __device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const float* sK, unsigned long long seed, int b, int p0, int np,
-                                                   const float4 yq[PT / 8], const float4 rq[PT / 8], float* img, int what) {
+                                                   const float4 yq[PT / 8], const float4 rq[PT / 8], const float wq[PT / 8], float* img, int what) {
   constexpr int PS = PT + 4;
   const int C = t.C, P = t.T * t.V;
 #pragma unroll
@@ -153,7 +154,7 @@ __device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const fl
       const float yv[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w}, rv[4] = {rq[q].x, rq[q].y, rq[q].z, rq[q].w};
       float keep[4];
       cg_tail_keep4(t, i, seed, (unsigned long long)off, keep);
-      const float wv = t.w[i][(long long)b * C + c], ap = t.alpha_p[i][0], scale_p = k1.z * k1.y;
+      const float wv = wq[q], ap = t.alpha_p[i][0], scale_p = k1.z * k1.y;
       float xv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -253,21 +254,22 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
   const int MT = CM / 16;
   const bool vec = (P & 3) == 0;
   float4 yq[CG_TAIL_PT / 8], rq[CG_TAIL_PT / 8];
+  float wq[CG_TAIL_PT / 8];
   if (vec) {
     const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT;
-    cg_tail_act_load<CG_TAIL_PT>(t, b, p0, min(CG_TAIL_PT, P - p0), yq, rq);
+    cg_tail_act_load<CG_TAIL_PT>(t, b, p0, min(CG_TAIL_PT, P - p0), yq, rq, wq);
   }
   for (int it = 0; it < per; ++it) {
     const int lid = wg * per + it;
     if (lid >= total) break;
     const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
     __syncthreads();
-    if (vec) cg_tail_act_finish<CG_TAIL_PT>(t, sK, seed, b, p0, np, yq, rq, sAct, 0);
+    if (vec) cg_tail_act_finish<CG_TAIL_PT>(t, sK, seed, b, p0, np, yq, rq, wq, sAct, 0);
     else cg_tail_stage_act<CG_TAIL_PT>(t, sK, seed, b, p0, np, sAct, 0);
     __syncthreads();
     if (vec && it + 1 < per && lid + 1 < total) {          // the next tile's reads travel while the matrix cores work
       const int l2 = lid + 1, b2 = l2 / tiles_per_sample, q0 = (l2 - b2 * tiles_per_sample) * CG_TAIL_PT;
-      cg_tail_act_load<CG_TAIL_PT>(t, b2, q0, min(CG_TAIL_PT, P - q0), yq, rq);
+      cg_tail_act_load<CG_TAIL_PT>(t, b2, q0, min(CG_TAIL_PT, P - q0), yq, rq, wq);
     }
     float* hb = t.h0 + (long long)b * C * P + p0;
     for (int w = wave; w < MT * 2; w += CG_TAIL_THREADS / 64) {          // (co tile, pair of position tiles)
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
   const bool vec = (P & 3) == 0;
   constexpr int DQ = CG_TAIL_PT3 / 16;               // quads of the dh0 image per thread (C <= 64)
   float4 yq[CG_TAIL_PT3 / 8], rq[CG_TAIL_PT3 / 8];
+  float wq[CG_TAIL_PT3 / 8];
   float4 h4[DQ], d4[DQ];
   float gt[DQ], dp[DQ];
   auto dh_load = [&](int b, int p0, int np) {            // h0 / dout quads and the per-row gate terms of a tile's dh0 image
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
   };
   if (vec) {
     const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT3;
-    cg_tail_act_load<CG_TAIL_PT3>(t, b, p0, min(CG_TAIL_PT3, P - p0), yq, rq);
+    cg_tail_act_load<CG_TAIL_PT3>(t, b, p0, min(CG_TAIL_PT3, P - p0), yq, rq, wq);
     dh_load(b, p0, min(CG_TAIL_PT3, P - p0));
   }
   for (int it = 0; it < per; ++it) {
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     __syncthreads();
     CG_TSTAMP();
     if (vec) {
-      cg_tail_act_finish<CG_TAIL_PT3>(t, sK, seed, b, p0, np, yq, rq, sZ, 1);
+      cg_tail_act_finish<CG_TAIL_PT3>(t, sK, seed, b, p0, np, yq, rq, wq, sZ, 1);
       CG_TSTAMP();
       // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
 #pragma unroll
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     __syncthreads();
     if (vec && it + 1 < per && lid + 1 < total) {
       const int b2 = (lid + 1) / tiles_per_sample, q0 = (lid + 1 - b2 * tiles_per_sample) * CG_TAIL_PT3;
-      cg_tail_act_load<CG_TAIL_PT3>(t, b2, q0, min(CG_TAIL_PT3, P - q0), yq, rq);
+      cg_tail_act_load<CG_TAIL_PT3>(t, b2, q0, min(CG_TAIL_PT3, P - q0), yq, rq, wq);
       dh_load(b2, q0, min(CG_TAIL_PT3, P - q0));
     }
     CG_TSTAMP();
