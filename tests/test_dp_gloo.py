@@ -88,7 +88,9 @@ def _worker_body(rank, world, port, q, SHARDS):
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("SHARDS", [SHARDS, (2, 5, 3, 4)], ids=["two ranks 3/4", "four ranks 2/5/3/4"])
+@pytest.mark.parametrize("SHARDS", [
+    pytest.param(SHARDS, id="two ranks 3/4", marks=pytest.mark.skipif(os.environ.get("CISTGCN_EMU_FULL", "0") != "1", reason="three more minutes of emulation; the four-rank case covers it (CISTGCN_EMU_FULL=1 runs both)")),
+    pytest.param((2, 5, 3, 4), id="four ranks 2/5/3/4")])
 def test_model_step_matches_oracle_per_shard(SHARDS):
     """two ranks, and four ranks with four different batch sizes (BASELINE configs[4]: the weight of a replica's gradient is
     B_r * world / sum B, which only shows with more than two unequal shards that it is not B_r / B_other)"""
