@@ -282,23 +282,36 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
         float av[4], b0v[4], b1v[4];
         cg_tfrag<0>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b0v[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], b1v[s], c1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {                                     // C[position 4 * slot + q][output channel l15]
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
         }
       }
+      // position-major tiles: a lane holds four consecutive positions of ONE output channel -> 16-byte stores of h0, channel sums
+      // per lane, combined over the four lanes l15 + 16 * slot of a channel by two exchanges
+      const int co = 16 * mt + l15;
+      const bool cok = co < C;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = 16 * mt + 4 * slot + q;
-        const bool cok = co < C, ok0 = cok && n0 + l15 < np, ok1 = cok && n1 + l15 < np;
-        const float v0 = ok0 ? c0[q] : 0.f, v1 = ok1 ? c1[q] : 0.f;
-        if (ok0) hb[(long long)co * P + n0 + l15] = v0;
-        if (ok1) hb[(long long)co * P + n1 + l15] = v1;
-        if (t.train) {
-          float s1 = v0 + v1, s2 = v0 * v0 + v1 * v1;
-          s1 = cg_row16_sum(s1); s2 = cg_row16_sum(s2);
-          if (l15 == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
+      for (int h = 0; h < 2; ++h) {
+        const int pq = (h ? n1 : n0) + 4 * slot;
+        const cg_f32x4 cc = h ? c1 : c0;
+        if (cok && pq < np) {
+          float* dst = hb + (long long)co * P + pq;
+          if (vec) *reinterpret_cast<float4*>(dst) = make_float4(cc[0], cc[1], cc[2], cc[3]);      // np % 4 == 0: the quad is inside the row
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (pq + q < np) {
+              if (!vec) dst[q] = cc[q];
+              s1 += cc[q]; s2 += cc[q] * cc[q];
+            }
+          }
         }
+      }
+      if (t.train) {
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (slot == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
       }
     }
   }
