@@ -126,8 +126,9 @@ def test_full_size_train_matches_oracle():
     ops._plans.clear()
     # floor 1 (the north_star form, as in every train-mode test above).  Observed with floor 0.25: the ill-conditioned tensor named
     # in the next test sat at 2.7e-5 (1.08 of that bound) on two boxes of the pool and at 1.5e-6 on four others - same GPU code,
-    # same seeds, the same value again on the same box.  The reference is an fp32 CPU computation whose summation order follows
-    # the host (the model name is printed for the record); the relative bound stays in force
+    # same seeds, the same value again on the same box.  The reference is a multi-threaded fp32 CPU computation (the host's model
+    # name is printed for the record: the boxes seen so far were all EPYC 9575F, so it is the run, not the CPU type); the relative
+    # bound stays in force
     try:
         with open("/proc/cpuinfo") as f:
             print("host CPU: %s" % next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "?"))
