@@ -514,7 +514,7 @@ def test_first_bucket_allreduce_overlaps_second_phase():
         step = DataParallelStep(net, x, tgt, graph=True)
         assert step.two_phase and len(step.flat.buckets) == 2
         step.force_collective = True
-        probe = step.pick_side_stream(collective=True)      # the side stream is chosen by measurement (hardware queues are shared)
+        probe = step.pick_side_stream(collective=True, tries=16, new_groups=4)      # the side stream is chosen by measurement (hardware queues are shared)
         print("side stream probe: %s" % probe)
         assert probe["independent"], "no stream found that runs beside the main stream: %s" % probe
         for _ in range(3):
