@@ -18,7 +18,7 @@
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
 // tile of a workgroup: [KcM channels][PT positions] with KcM * PT = 4096 (16 floats per thread and staged tensor):
-// PT = 64 for 49..64 slabs, 128 for 17..32, 256 up to 16
+// PT = 64 for 33..64 slabs (KcM = 64), 128 for 17..32, 256 up to 16
 #define CG_ADJ_THREADS 256
 #define CG_ADJ_REPLICAS 32
 
@@ -689,9 +689,12 @@ __global__ void cg_adj_finish_kernel(CgAdjTailPair pr) {
 static unsigned cg_adj_magic(int d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
 // tiles per workgroup: long workgroups amortise their prologue (weights, tables) when the batch alone fills the chip
 static int cg_adj_tpw(int B) { return B >= 128 ? CG_ADJ_TPW_MAX : B >= 64 ? 4 : B >= 32 ? 2 : 1; }
+// padded slab count of a tile: 16 / 32 / 64.  The staging code hands every thread 16 floats of a [KcM][PT] tile
+// (KcM * PT == 4096), which has no 48-row form: 33..48 slabs take the 64-row tile with zero rows behind Kc
+static int cg_adj_kcm(int Kc) { return Kc > 32 ? 64 : (Kc + 15) & ~15; }
 static CgAdjGeom cg_adj_geometry(int B, int Kc, int J) {
   CgAdjGeom g;
-  g.KcM = (Kc + 15) & ~15;
+  g.KcM = cg_adj_kcm(Kc);
   g.WS = g.KcM + 4;
   g.JS = J + 1;
   g.Pn = J * J;
@@ -712,7 +715,7 @@ static int cg_adj_dbg() { static const int v = getenv("CG_ADJ_DBG") ? atoi(geten
 #else
 static int cg_adj_dbg() { return 0; }
 #endif
-static int cg_adj_tile(int Kc) { const int KcM = (Kc + 15) & ~15; return KcM > 32 ? 64 : KcM > 16 ? 128 : 256; }
+static int cg_adj_tile(int Kc) { const int KcM = cg_adj_kcm(Kc); return KcM > 32 ? 64 : KcM > 16 ? 128 : 256; }
 
 static int cg_adj_check(const CgAdjTail* it, int n) {
   if (!it || n <= 0 || n > 2) return CG_EARG;
@@ -728,7 +731,7 @@ static int cg_adj_check(const CgAdjTail* it, int n) {
 static size_t cg_adj_lds(const CgAdjTail* it, int n, int phase, bool bwd) {
   size_t best = 0;
   for (int i = 0; i < n; ++i) {
-    const int KcM = (it[i].Kc + 15) & ~15, WS = KcM + 4, JS = it[i].J + 1, PS = cg_adj_tile(it[i].Kc) + 4;
+    const int KcM = cg_adj_kcm(it[i].Kc), WS = KcM + 4, JS = it[i].J + 1, PS = cg_adj_tile(it[i].Kc) + 4;
     size_t f;
     if (!bwd && phase == 1) f = (size_t)2 * KcM * JS + (size_t)KcM * WS + 2 + (size_t)4 * KcM;                 // tables, W0, f64 sums
     else if (!bwd) f = (size_t)KcM * PS + (size_t)KcM * WS + (size_t)8 * KcM;

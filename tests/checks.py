@@ -846,7 +846,7 @@ def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
-def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6))):
+def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6), (2, 40, 6), (2, 6, 36))):
     """ops.map2adj_tail (phase kernels of csrc/map2adj_tail.hip) against the same chain built from the rank-1 kernel, the
     generic contraction and the row kernels (pinned to the oracle by the model tests): identical dropout draws, train and eval
     mode, both adjacencies, the PReLU taps, every input / parameter gradient, running statistics.  shapes: (B, T, V)."""

@@ -28,7 +28,7 @@ def test_operator(check):
     elif check is checks.check_pointwise_maps:
         check("cpu", shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 33), 6, 6), (2, 10, (20, 16), 4, 6), (2, 32, (10, 10, 10), 3, 4), (2, 1, (20, 20), 5, 6), (2, 12, (16, 5), 3, 14)))
     elif check is checks.check_map2adj_tail:
-        check("cpu", shapes=((3, 7, 9), (2, 6, 17)))
+        check("cpu", shapes=((3, 7, 9), (2, 6, 17), (2, 40, 6)))      # 40 slabs: the 33..48 range takes the 64-row tile
     else:
         check("cpu")
 
