@@ -123,6 +123,14 @@ class RowsConv(ctypes.Structure):
                 ("dy", c_void_p), ("dx", c_void_p), ("dW", c_void_p), ("ws", c_void_p)]
 
 
+class CtxHeads(ctypes.Structure):
+    _fields_ = [("B", c_int), ("P", c_int), ("C", c_int), ("train", c_int), ("x", c_void_p), ("xstats", c_void_p),
+                ("w", c_void_p * 2), ("bn", TailBN * 2), ("alpha", c_void_p * 2),
+                ("y", c_void_p * 2), ("arg", c_void_p), ("xsave", c_void_p), ("tap", c_void_p * 2),
+                ("dy", c_void_p * 2), ("red", c_void_p), ("dx", c_void_p),
+                ("dw", c_void_p * 2), ("dgamma", c_void_p * 2), ("dbeta", c_void_p * 2), ("dalpha", c_void_p * 2)]
+
+
 P = c_void_p
 LL = c_longlong
 _SIGNATURES = {
@@ -175,6 +183,9 @@ _SIGNATURES = {
     "cg_pointwise_maps_fwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_bwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_ws_floats": [c_int],
+    "cg_context_heads_fwd": [POINTER(CtxHeads), P],
+    "cg_context_heads_bwd": [POINTER(CtxHeads), P],
+    "cg_context_heads_red_doubles": [c_int],
     "cg_map2adj_tail_fwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_bwd": [POINTER(AdjTail), c_int, c_int, P],
     "cg_map2adj_tail_ws_floats": [c_int],

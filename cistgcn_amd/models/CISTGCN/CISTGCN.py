@@ -226,6 +226,7 @@ class CISTGCN(nn.Module):
         self.fused_tail = __import__("os").environ.get("CISTGCN_FUSED_TAIL", "1") != "0"
         self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
+        self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
         self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
@@ -598,6 +599,17 @@ class CISTGCN(nn.Module):
         c1, c2, c3 = m.context_conv1, m.context_conv2, m.context_conv3
         tr = self.training
         w13 = [c[0].weight.view(c[0].out_channels, c[0].in_channels) for c in (c1, c3)]
+        if self.fused_context and c1[0].bias is None and c3[0].bias is None and ops.context_heads_ok(x, c1[0].out_channels):
+            # heads 1 and 3 (max / mean over the positions of a 1 -> hidden_dim map, BatchNorm, PReLU) from the one-channel sequence
+            # itself: their (B, hidden_dim, To, 3V) activations are never stored (csrc/context_heads.hip)
+            xa, xb = ops.fanout(x, 2)
+            taps = [] if self.act_trace is not None else None
+            y1, ym = ops.context_heads(xa, c1, c3, tr, taps=taps)
+            if taps is not None:
+                self.act_trace[c1[2]], self.act_trace[c3[2]] = (taps[0], None), (taps[1], None)
+            y2 = ops.max_bc(self._na(_run_items([_rows_item(xb, c2[0], tr)])[0], bn=c2[1], prelu=c2[2]))
+            self._site += 2          # the composite path numbers two more (dropout-free) sites: later layers draw the same masks on either path
+            return self._context_tail(m, x7, y1, y2, ym)
         if self.fused_maps and B * To * V * 3 * sum(w.shape[0] for w in w13) >= self.stack_min_elements and ops.pointwise_maps_ok(x, w13):
             # the two 1 -> hidden_dim maps read the sequence once and write their (B, hidden_dim, To, 3V) results from one kernel
             xa, xb = ops.fanout(x, 2)
@@ -606,7 +618,12 @@ class CISTGCN(nn.Module):
         else:
             o = _run_items([_pw_item(x, c1[0], tr), _rows_item(x, c2[0], tr), _pw_item(x, c3[0], tr)])
         r = self._na_many([dict(x=o[i], bn=c[1], prelu=c[2]) for i, c in enumerate((c1, c2, c3))])
-        y1, y2, ym = ops.max_bc(r[0]), ops.max_bc(r[1]), ops.mean_bc(r[2])
+        return self._context_tail(m, x7, ops.max_bc(r[0]), ops.max_bc(r[1]), ops.mean_bc(r[2]))
+
+    def _context_tail(self, m, x7, y1, y2, ym):
+        """ContextLayer.forward behind the three pooled heads, CISTGCN.py:468-475"""
+        B, To, V, _ = x7.shape
+        tr = self.training
         o = _run_items([_lin_item(y, h[0], False) for y, h in ((y1, m.map1), (y2, m.map2), (ym, m.map3))])
         heads = self._na_many([dict(x=o[i][0], drop=True, prelu=h[2]) for i, h in enumerate((m.map1, m.map2, m.map3))])
         y = ops.cat_channels(heads)

@@ -1694,6 +1694,101 @@ def map2adj_tail(seeds, expansors, train, drop_p=0.0, salts=(0, 0), taps=None):
     return _Map2AdjTail.apply(cfg, *ts)
 
 
+def context_heads_ok(x, hidden):
+    """True when `context_heads` takes the two one-channel heads of x (B,1,H,W)."""
+    return x.dim() == 4 and x.shape[1] == 1 and x.is_contiguous() and hidden <= 64 and x.shape[2] * x.shape[3] <= 16384
+
+
+class _ContextHeads(torch.autograd.Function):
+    """(max_p, mean_p) of PReLU(BN(w_h x)) for the two 1 -> C heads of the ContextLayer, CISTGCN.py:408-418 / :465 / :467
+    (see csrc/context_heads.hip).  Tensor inputs: x | w gamma beta alpha of head 0 | of head 1."""
+
+    @staticmethod
+    def _block(x, ts, bns, saves, train):
+        B, _, H, W = x.shape
+        t = _lib.CtxHeads()
+        t.B, t.P, t.C, t.train = B, H * W, ts[0].numel(), 1 if train else 0
+        t.x = x.data_ptr()
+        for h in range(2):
+            w, gamma, beta, alpha = ts[4 * h:4 * h + 4]
+            t.w[h], t.alpha[h] = w.data_ptr(), alpha.data_ptr()
+            _tail_bn(t.bn[h], bns[h], None, saves[h], train)
+        return t
+
+    @staticmethod
+    def forward(ctx, cfg, x, *ts):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        dev, f32, train = x.device, torch.float32, bool(cfg["train"])
+        B, _, H, W = x.shape
+        C = ts[0].numel()
+        saves = torch.empty(2, 2, C, dtype=f32, device=dev)
+        xsave = torch.empty(2, dtype=f32, device=dev)
+        t = _ContextHeads._block(x, ts, cfg["bn"], saves, train)
+        stream = _stream(x)
+        if train:
+            if B * H * W <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            xstats = _arena(dev).take(2 * _lib.STAT_REPLICAS)
+            it = _lib.StatsArgs()
+            it.x, it.xv, it.pre, it.stats = x.data_ptr(), _view4(x), None, xstats.data_ptr()
+            _lib.call("cg_chan_stats_many", (_lib.StatsArgs * 1)(it), 1, stream)
+            t.xstats = xstats.data_ptr()
+        y = torch.empty(2, B, C, dtype=f32, device=dev)
+        arg = torch.empty(B, C, dtype=torch.int32, device=dev)
+        t.y[0], t.y[1], t.arg, t.xsave = y[0].data_ptr(), y[1].data_ptr(), arg.data_ptr(), xsave.data_ptr()
+        taps = cfg.get("taps")
+        if taps is not None:
+            for h in range(2):
+                taps.append(torch.empty(B, C, H, W, dtype=f32, device=dev))
+                t.tap[h] = taps[-1].data_ptr()
+        _lib.call("cg_context_heads_fwd", ctypes.byref(t), stream)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, *ts, arg, saves, xsave)
+        ctx.mark_non_differentiable(arg)
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        sv = ctx.saved_tensors
+        x, ts, arg, saves, xsave = sv[0], sv[1:9], sv[9], sv[10], sv[11]
+        dev, f32, train = x.device, torch.float32, bool(ctx.cfg["train"])
+        B, _, H, W = x.shape
+        C = ts[0].numel()
+        t = _ContextHeads._block(x, ts, ctx.cfg["bn"], saves, False)
+        t.train = 1 if train else 0
+        t.arg, t.xsave = arg.data_ptr(), xsave.data_ptr()
+        dys = []
+        for h, d in enumerate((dy0, dy1)):
+            if d is None:                                         # a head that does not reach the loss
+                d = _zeros(B * C, dev)[0].view(B, C)
+            d = d if d.is_contiguous() else _copy(d)
+            dys.append(d)
+            t.dy[h] = d.data_ptr()
+        red = _arena(dev).take(int(_lib.lib().cg_context_heads_red_doubles(C)))
+        dx = torch.empty_like(x)
+        small = torch.empty(2, 4, C, dtype=f32, device=dev)     # per head: dw, dgamma, dbeta, dalpha (one number)
+        t.red, t.dx = red.data_ptr(), dx.data_ptr()
+        for h in range(2):
+            t.dw[h], t.dgamma[h], t.dbeta[h], t.dalpha[h] = (small[h, k].data_ptr() for k in range(4))
+        _lib.call("cg_context_heads_bwd", ctypes.byref(t), _stream(x))
+        del dys
+        grads = []
+        for h in range(2):
+            grads += [small[h, 0].view(ts[4 * h].shape), small[h, 1], small[h, 2], small[h, 3, :1].reshape(1)]
+        return (None, dx if ctx.needs_input_grad[1] else None) + tuple(g if ctx.needs_input_grad[2 + k] else None for k, g in enumerate(grads))
+
+
+def context_heads(x, head_max, head_mean, train, taps=None):
+    """(max over positions, mean over positions) of the two Conv2d(1, C, 1) -> BatchNorm2d -> PReLU heads `head_max` / `head_mean`
+    (holders with [0] conv, [1] BatchNorm, [2] PReLU) of x (B,1,H,W); the (B,C,H,W) activations are never stored."""
+    cfg = {"train": bool(train), "bn": (head_max[1], head_mean[1]), "taps": taps}
+    ts = []
+    for hd in (head_max, head_mean):
+        ts += [hd[0].weight, hd[1].weight, hd[1].bias, hd[2].weight]
+    return _ContextHeads.apply(cfg, x, *ts)
+
+
 def pointwise_maps_ok(x, weights):
     """True when `pointwise_maps` takes this problem (else the caller batches the maps through the generic contraction)."""
     if x.dim() != 4 or not x.is_contiguous() or len(weights) > 4:

@@ -318,6 +318,33 @@ long long cg_map2adj_tail_ws_floats(int Kc);
 long long cg_map2adj_tail_part_floats(int B, int Kc, int J);
 long long cg_map2adj_tail_red_doubles(int Kc);
 
+/* ---- ContextLayer heads 1 and 3, CISTGCN.py:408-418 with :465 / :467 ---------------------------------
+ * Conv2d(1, C, 1, bias=False) -> BatchNorm2d(C) -> PReLU of the one-channel tensor x (B,1,T_out,3V), reduced over the positions:
+ *   head 0 (context_conv1): y[0][b,c] = max_p z (first arg-max in `arg`), head 1 (context_conv3): y[1][b,c] = mean_p z.
+ * The (B,C,P) activations are functions of x[b,p] and per-channel constants (batch statistics of w[c] x are w[c] mean(x),
+ * w[c]^2 var(x)); they are never stored.  x (B,P) contiguous, C <= 64, P <= 16384 (else CG_ESHAPE: the caller composes the heads
+ * from cg_pointwise_maps / cg_norm_act / cg_reduce_bc).  Train mode needs `xstats` = [CG_STAT_REPLICAS][1][2] f64 sums of x
+ * (cg_chan_stats_many on the (B,1,P) view).  bn[h].save ([2][C]) and xsave ([2]) are written by the forward, read by the backward.
+ * Backward: two launches (per-channel sums, then dx and the parameter gradients in closed form); `red`:
+ * cg_context_heads_red_doubles(C) f64 words, zero on entry. */
+typedef struct CgCtxHeads {
+  int B, P, C, train;
+  const float* x;
+  const double* xstats;
+  const float* w[2]; CgTailBN bn[2]; const float* alpha[2];
+  float* y[2];
+  int32_t* arg;
+  float* xsave;
+  float* tap[2];                /* optional (B,C,P): the PReLU outputs (diagnostics / branch records) */
+  const float* dy[2];
+  double* red;
+  float* dx;
+  float* dw[2]; float* dgamma[2]; float* dbeta[2]; float* dalpha[2];
+} CgCtxHeads;
+int cg_context_heads_fwd(const CgCtxHeads* t, void* stream);
+int cg_context_heads_bwd(const CgCtxHeads* t, void* stream);
+long long cg_context_heads_red_doubles(int C);
+
 /* ---- evaluation harness counterpart, environment/test.py:97-132 ----------------------
  * y[r,k,:] = x[r,idx[k],:] : `inputs[:, :, dim_used]` (32 -> 22 joints); x (rows,Jin,3), y (rows,Jout,3) contiguous */
 int cg_gather_joints(const float* x, float* y, const int32_t* idx, long long rows, int Jin, int Jout, void* stream);

@@ -324,9 +324,11 @@ def check_reduce_and_gate(device):
     _run(ops.max_bc, lambda t: t.flatten(2).max(-1)[0], [x], device, what="max_bc")
     _run(lambda t: ops.max_bc(t.permute(0, 2, 3, 1)), lambda t: t.permute(0, 2, 3, 1).flatten(2).max(-1)[0], [x], device,
          what="max_bc permuted")
-    C, H = 9, 2
-    _run(ops.se_gate, lambda p, w1, w2: torch.sigmoid(F.linear(F.relu(F.linear(p, w1)), w2)),
-         [_rand(g, 4, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate")
+    # (B, C, H): a batch larger than the grid of the sliced backward (several samples per workgroup, register dW sums), the 3 -> 1 gate of
+    # the output block, a gate wider than one row of threads
+    for B, C, H in ((4, 9, 2), (150, 64, 8), (70, 3, 1), (5, 300, 4)):
+        _run(ops.se_gate, lambda p, w1, w2: torch.sigmoid(F.linear(F.relu(F.linear(p, w1)), w2)),
+             [_rand(g, B, C), _rand(g, H, C), _rand(g, C, H)], device, what="se_gate B%d C%d H%d" % (B, C, H), rel=3e-5)
 
 
 def check_contract_kred(device, quick=False):
@@ -897,6 +899,69 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6), (2, 4
                 assert_close(a, b, "%s grad[%d]" % (what, k), rel=5e-5, floor=max(1e-3, float(b.abs().max())))
             for k, (a, b) in enumerate(zip(results[0][3], results[1][3])):
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
+
+
+def check_context_heads(device, shapes=((3, 5, 12, 7), (4, 25, 66, 64), (2, 3, 10, 33))):
+    """ops.context_heads (csrc/context_heads.hip) against stock PyTorch modules Conv2d(1, C, 1) -> BatchNorm2d -> PReLU and the
+    reference's reductions (CISTGCN.py:465, :467): outputs, the PReLU taps, input gradient, every parameter gradient, running
+    statistics; train and eval mode.  shapes: (B, H, W, C)."""
+    from cistgcn_amd.models.CISTGCN.CISTGCN import Stage, _conv
+    g = _gen(61)
+    for (B, H, W, C) in shapes:
+        for train in (True, False):
+            def make():
+                gg = _gen(300 + B + C)
+                heads = []
+                for k in range(2):
+                    hd = Stage(s0=_conv(1, C, 1), s1=nn.BatchNorm2d(C), s2=nn.PReLU())
+                    with torch.no_grad():
+                        hd[0].weight.copy_(torch.randn(hd[0].weight.shape, generator=gg) * 0.7)
+                        hd[1].weight.copy_(1 + 0.3 * torch.randn(C, generator=gg)); hd[1].bias.copy_(0.3 * torch.randn(C, generator=gg))
+                        hd[1].running_mean.copy_(0.2 * torch.randn(C, generator=gg)); hd[1].running_var.copy_(0.5 + torch.rand(C, generator=gg))
+                        hd[2].weight.fill_(0.15 + 0.2 * k)
+                    heads.append(hd)
+                return nn.ModuleList(heads)
+            x0 = 1.5 + 3.0 * _rand(g, B, 1, H, W)
+            g0, g1 = _rand(g, B, C), _rand(g, B, C)
+            what = "context_heads B%d H%d W%d C%d %s" % (B, H, W, C, "train" if train else "eval")
+            # stock PyTorch
+            ref = make().train(train)
+            xr = _leaf(x0, "cpu")
+            z0 = ref[0][2](ref[0][1](ref[0][0](xr)))
+            z1 = ref[1][2](ref[1][1](ref[1][0](xr)))
+            r0, r1 = z0.max(-1)[0].max(-1)[0], z1.mean((2, 3))
+            torch.autograd.backward([r0, r1], [g0, g1])
+            # HIP
+            net = make().to(device).train(train)
+            xd = _leaf(x0, device)
+            ops.begin_step(device)
+            taps = []
+            y0, y1 = ops.context_heads(xd, net[0], net[1], train, taps=taps)
+            torch.autograd.backward([y0, y1], [g0.to(device), g1.to(device)])
+            assert_close(y0, r0, what + " max", rel=2e-5)
+            assert_close(y1, r1, what + " mean", rel=2e-5)
+            assert_close(taps[0], z0, what + " tap 0", rel=2e-5)
+            assert_close(taps[1], z1, what + " tap 1", rel=2e-5)
+            assert_close(xd.grad, xr.grad, what + " dx", rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
+            for (k, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
+                floor = max(1e-3, float(pb.grad.abs().max()))
+                if train and k.endswith("0.weight"):
+                    # a weight in front of a train-mode BatchNorm: its gradient is what is left (~eps / var) of cancelling terms of the size
+                    # of the BatchNorm weight's gradient - stock fp32 PyTorch is itself 1e-6 .. 3e-6 off its fp64 run here
+                    floor = max(floor, float(ref[int(k[0])][1].weight.grad.abs().max()))
+                assert_close(pa.grad, pb.grad, "%s grad %s" % (what, k), rel=5e-5, floor=floor)
+            for (k, ba), (_, bb) in zip(net.named_buffers(), ref.named_buffers()):
+                assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, k), rel=1e-5)
+            # a head that does not reach the loss
+            net.zero_grad()
+            xd2 = _leaf(x0, device)
+            ops.begin_step(device)
+            y0, y1 = ops.context_heads(xd2, net[0], net[1], False)
+            y1.backward(g1.to(device))
+            ref.eval(); ref.zero_grad()
+            xr2 = _leaf(x0, "cpu")
+            ref[1][2](ref[1][1](ref[1][0](xr2))).mean((2, 3)).backward(g1)
+            assert_close(xd2.grad, xr2.grad, what + " dx (mean head only)", rel=5e-5, floor=max(1e-3, float(xr2.grad.abs().max())))
 
 
 def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6),

@@ -28,20 +28,34 @@ def build(force=False):
 
 
 def _build_locked(force):
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h")]
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]
+    deps = srcs + hdrs + [os.path.join(HERE, "emu_runtime.cpp")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(p) <= os.path.getmtime(OUT) for p in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    objs = []
-    for s in srcs + [os.path.join(HERE, "emu_runtime.cpp")]:
+    hdr_time = max(os.path.getmtime(p) for p in hdrs)
+
+    def compile_one(s):
+        # one object per source, reused while neither the source nor a header changed
         o = os.path.join(HERE, "_build", os.path.basename(s) + (".asan.o" if SANITIZE else ".o"))
+        if not force and os.path.exists(o) and os.path.getmtime(o) > max(os.path.getmtime(s), hdr_time):
+            return o, None
         cmd = ["g++", "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-Wno-unknown-pragmas", "-Wno-attributes",
-               "-I", HERE, "-I", CSRC, "-c", s, "-o", o] + (["-fsanitize=address", "-fno-omit-frame-pointer"] if SANITIZE else [])
+               "-I", HERE, "-I", CSRC, "-c", s, "-o", o + ".tmp"] + (["-fsanitize=address", "-fno-omit-frame-pointer"] if SANITIZE else [])
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
-            raise RuntimeError("g++ failed on %s:\n%s" % (s, res.stderr[-4000:]))
-        objs.append(o)
+            return o, "g++ failed on %s:\n%s" % (s, res.stderr[-4000:])
+        os.replace(o + ".tmp", o)
+        return o, None
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, srcs + [os.path.join(HERE, "emu_runtime.cpp")]))
+    errors = [e for _, e in results if e]
+    if errors:
+        raise RuntimeError("\n".join(errors))
+    objs = [o for o, _ in results]
     tmp = OUT + ".tmp.%d" % os.getpid()
     res = subprocess.run(["g++", "-shared", "-pthread", "-o", tmp] + objs + (["-fsanitize=address"] if SANITIZE else []), capture_output=True, text=True)
     if res.returncode != 0:
