@@ -258,6 +258,7 @@ class CISTGCN(nn.Module):
         self._site = 0
         self.backward_cut = None      # (input block index, fn): the step runtime cuts the autograd graph behind that block
         self.act_trace = None         # dict: PReLU module -> (output, post-activation addend) of the last forward (diagnostics)
+        self.drop_trace = None        # dict: module naming a dropout site (the BatchNorm in front of it, else the PReLU behind it) -> site id of the last forward (diagnostics)
         self.branch_streams = False   # True: independent branches of a block run on forked HIP streams (runtime.GraphedStep)
         self._streams, self._next_stream = [], 0
 
@@ -369,6 +370,8 @@ class CISTGCN(nn.Module):
             self._site += 1
             drop = kw.pop("drop", False)
             kw.update(train=self.training, drop_p=self.dropout if drop else 0.0, salt=self._site)
+            if drop and self.drop_trace is not None:
+                self.drop_trace[kw.get("bn") if kw.get("bn") is not None else kw.get("prelu")] = self._site
             out.append(kw)
         ys = ops.norm_act_many(out)
         if self.act_trace is not None:
@@ -531,6 +534,8 @@ class CISTGCN(nn.Module):
             o = _run_items([_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)])
             m.w1, m.w2 = o[0][0], o[1][0]
             self._site += 2
+            if self.drop_trace is not None:
+                self.drop_trace[maps[0].expansor[1]], self.drop_trace[maps[1].expansor[1]] = self._site - 1, self._site
             taps = [] if self.act_trace is not None else None
             adj = ops.map2adj_tail(seeds, [a.expansor for a in maps], tr, drop_p=self.dropout, salts=(self._site - 1, self._site), taps=taps)
             adj = [(a, None) for a in adj]
@@ -565,6 +570,8 @@ class CISTGCN(nn.Module):
         if self.fused_tail and c[0].out_channels <= 64 and all(isinstance(y, tuple) and (y[1] is not None or not tr) for y in ys):
             # everything behind the two tcn convolutions in five phase launches (csrc/dstd_tail.hip)
             self._site += 2
+            if self.drop_trace is not None:
+                self.drop_trace[doms[0].tcn[1]], self.drop_trace[doms[1].tcn[1]] = self._site - 1, self._site
             taps = [] if self.act_trace is not None else None
             out, ost = ops.dstd_tail([y[0] for y in ys], [y[1] for y in ys], res, (m.w1, m.w2),
                                      (doms[0].tcn[1], doms[1].tcn[1], m.prelu1[0], m.prelu2[0], c[1]),

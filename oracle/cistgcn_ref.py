@@ -252,7 +252,14 @@ class CISTGCN(nn.Module):
         speed = torch.norm(vel, dim=-1, keepdim=True)
         return torch.cat((x, acc, vel, speed), dim=-1).permute(0, 3, 1, 2)
 
-    def _drop(self, x):
+    # Dropout sites (the reference's nn.Dropout(p, inplace=True) layers, CISTGCN.py:143, 150, 167, 236, 327, 333, 346, 424-436, 440-449).
+    # `site` names the site: the BatchNorm in front of it, or - where there is none (ContextLayer.map1-3) - the PReLU behind it.
+    # `drop_hook` (tests only): callable (x, site) -> dropped x, lets a checker apply the very masks another implementation drew.
+    drop_hook = None
+
+    def _drop(self, x, site=None):
+        if self.drop_hook is not None and self.training and self.dropout > 0.0:
+            return self.drop_hook(x, site)
         return F.dropout(x, self.dropout, self.training)
 
     # ---- row G: CISTGCN.py:183-189 -----------------------------------------------------------
@@ -260,7 +267,7 @@ class CISTGCN(nn.Module):
         tr = self.training
         def tower(t):
             h = _act(_bn(_conv(x, t[0]), t[1], tr), t[2])
-            h = self._drop(_bn(_conv(h, t[3]), t[4], tr))
+            h = self._drop(_bn(_conv(h, t[3]), t[4], tr), t[4])
             return _conv(h, t[6])
         q = tower(m.time_compress)    # (B, T, 1, V)
         s = tower(m.joint_compress)   # (B, V, T, 1)
@@ -274,7 +281,7 @@ class CISTGCN(nn.Module):
         else:
             o = s.permute(0, 2, 1, 3) * q              # o[b,t,v,w]  = s[b,v,t] q[b,t,w]
         e = m.expansor
-        h = _act(self._drop(_bn(_conv(o, e[0]), e[1], self.training)), e[3])
+        h = _act(self._drop(_bn(_conv(o, e[0]), e[1], self.training), e[1]), e[3])
         return _conv(h, e[4])
 
     # ---- rows E,F: CISTGCN.py:259-269, 122-124 -------------------------------------------------
@@ -292,7 +299,7 @@ class CISTGCN(nn.Module):
             layer.Adj = x
             eq = "nctv,vtq->ncqv" if layer.domain == "space" else "nctv,tvw->nctw"
             g = torch.einsum(eq, x, layer.gcn.A)
-        y = self._drop(_bn(_conv(g.contiguous(), layer.tcn[0]), layer.tcn[1], tr))
+        y = self._drop(_bn(_conv(g.contiguous(), layer.tcn[0]), layer.tcn[1], tr), layer.tcn[1])
         return _act(y + res, layer.prelu)
 
     # ---- row C: CISTGCN.py:360-371 -----------------------------------------------------------
@@ -304,10 +311,10 @@ class CISTGCN(nn.Module):
     # ---- row D: CISTGCN.py:378-384 -----------------------------------------------------------
     def gate(self, conv, mp, xn, stats):
         tr = self.training
-        h = _act(self._drop(_bn(_conv(xn, conv[0]), conv[1], tr)), conv[3])
-        h = _act(self._drop(_bn(_conv(h, conv[4]), conv[5], tr)), conv[7])
+        h = _act(self._drop(_bn(_conv(xn, conv[0]), conv[1], tr), conv[1]), conv[3])
+        h = _act(self._drop(_bn(_conv(h, conv[4]), conv[5], tr), conv[5]), conv[7])
         h = torch.cat((h.flatten(1), stats), dim=1)
-        h = _act(self._drop(_bn(F.linear(h, mp[0].weight), mp[1], tr)), mp[3])
+        h = _act(self._drop(_bn(F.linear(h, mp[0].weight), mp[1], tr), mp[1]), mp[3])
         return F.linear(h, mp[4].weight)
 
     # ---- row B: CISTGCN.py:373-390 -----------------------------------------------------------
@@ -347,15 +354,15 @@ class CISTGCN(nn.Module):
         y2 = cc(m.context_conv2).flatten(2).max(-1)[0]
         ym = cc(m.context_conv3).mean((2, 3))
         def mp(y, mm):
-            return _act(self._drop(F.linear(y, mm[0].weight)), mm[2])
+            return _act(self._drop(F.linear(y, mm[0].weight), mm[2]), mm[2])
         y = torch.cat((mp(y1, m.map1), mp(y2, m.map2), mp(ym, m.map3)), dim=1)
-        m.joints = self._drop(_bn(F.linear(y, m.fmap_s[0].weight), m.fmap_s[1], tr))
-        m.displacements = self._drop(_bn(F.linear(y, m.fmap_t[0].weight), m.fmap_t[1], tr))
+        m.joints = self._drop(_bn(F.linear(y, m.fmap_s[0].weight), m.fmap_s[1], tr), m.fmap_s[1])
+        m.displacements = self._drop(_bn(F.linear(y, m.fmap_t[0].weight), m.fmap_t[1], tr), m.fmap_t[1])
         m.seq_joints = m.displacements[:, :, None] * m.joints[:, None, :]
         n = m.norm_map
-        h = _act(self._drop(_bn(_conv(m.seq_joints, n[0]), n[1], tr)), n[3])
+        h = _act(self._drop(_bn(_conv(m.seq_joints, n[0]), n[1], tr), n[1]), n[3])
         h = _se(h, n[4])
-        h = _act(self._drop(_bn(_conv(h, n[5]), n[6], tr)), n[8])
+        h = _act(self._drop(_bn(_conv(h, n[5]), n[6], tr), n[6]), n[8])
         m.seq_joints_n = h
         f = m.fconv
         h = _act(_bn(_conv(h.view(b, 1, To, V), f[0]), f[1], tr), f[2])

@@ -99,9 +99,12 @@ class BranchReplay:
     def __init__(self, net, ora, trace):
         from oracle import cistgcn_ref as O
         self.O = O
+        self.masks = {}
+        self.flips, self.elements, self.worst, self.sites = 0, 0, 0.0, 0
+        if net is None:
+            return
         names = {m: n for n, m in net.named_modules()}
         omods = dict(ora.named_modules())
-        self.masks = {}
         for mod, (y, add) in trace.items():
             y = y.detach().cpu()
             if add is None:
@@ -110,7 +113,19 @@ class BranchReplay:
                 d = y - add.detach().cpu().expand_as(y)
                 pos, known = d > 0, d != 0
             self.masks[omods[names[mod]]] = (pos, known)
-        self.flips, self.elements, self.worst, self.sites = 0, 0, 0.0, 0
+
+    @classmethod
+    def from_golden(cls, rec, ora, prefix="train/branch/"):
+        """the branches the REAL reference took on this fixture (tools/gen_golden.py: forward hooks on its nn.PReLU modules, `input > 0`
+        bit-packed under `<prefix><module name>`)"""
+        self = cls(None, ora, None)
+        omods = dict(ora.named_modules())
+        for k, bits in rec.items():
+            if k.startswith(prefix):
+                pos = torch.from_numpy(np.unpackbits(bits).astype(bool))
+                self.masks[omods[k[len(prefix):]]] = (pos, None)
+        assert self.masks, "the fixture holds no branch record"
+        return self
 
     def __enter__(self):
         self._orig = self.O._act
@@ -119,10 +134,14 @@ class BranchReplay:
             alpha = m.weight.reshape((1, -1) + (1,) * (x.dim() - 2)) if m.weight.numel() > 1 else m.weight
             own = x > 0
             rec = self.masks.get(m)
-            if rec is None or not bool((m.weight > 0).all()):
+            # a record read off the sign of an OUTPUT needs a positive slope; a recorded input sign (fixture bits) does not
+            if rec is None or (rec[1] is not None and not bool((m.weight > 0).all())):
                 return self._orig(x, m)
             pos, known = rec
-            pos = torch.where(known.view_as(own), pos.view_as(own), own)
+            if known is None:           # bit-packed record: padded to a multiple of eight
+                pos = pos[:own.numel()].view_as(own)
+            else:
+                pos = torch.where(known.view_as(own), pos.view_as(own), own)
             diff = pos != own
             n = int(diff.sum())
             self.sites += 1
@@ -141,7 +160,59 @@ class BranchReplay:
         return False
 
 
-def assert_grads_strict(named_got, named_ref, what="", rel=1e-4, floor=1.0, rel_bound=None, rel_min_ref=1e-4, report=None, rel_abs=3e-7):
+# ---------------------------------------------------------------------------------------------------------
+# dropout: the oracle applies the very masks the HIP run drew
+# ---------------------------------------------------------------------------------------------------------
+def hip_keep_scale(seed, salt, p, n):
+    """numpy restatement of cg_drop_scale (cistgcn_amd/csrc/cg_common.h: cg_drop_bits / cg_drop_pick) for the flat element indices
+    0 .. n-1 of a tensor: splitmix64 of (seed word, site id, index / 4), 16 bits per element, keep when bits >= p * 65536;
+    returns the float32 factors 0 or 1 / (1 - p)."""
+    mask64 = (1 << 64) - 1
+    base = ((int(seed) & mask64) * 0x9E3779B97F4A7C15 + ((int(salt) & 0xFFFFFFFF) << 40) + 0x632BE59BD9B4E019) & mask64
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (idx >> np.uint64(2)) + np.uint64(base)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    bits = (z >> (np.uint64(16) * (idx & np.uint64(3)))) & np.uint64(0xFFFF)
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return np.where(bits >= thr, scale, np.float32(0.0)).astype(np.float32)
+
+
+class DropReplay:
+    """Context manager around an oracle forward/backward in train mode with dropout: every dropout site of the oracle multiplies by the
+    keep factors the HIP kernels generated for that site (`net.drop_trace`: site module -> site id; `seed`: the device seed word the HIP
+    forward ran with; element index = flat index of the site's logical (B, C, ...) tensor), so both implementations evaluate the same
+    function and the fp32 bound applies to the configuration the benchmark times (dropout 0.1)."""
+
+    def __init__(self, net, ora, drop_trace, seed, p):
+        names = {m: n for n, m in net.named_modules()}
+        omods = dict(ora.named_modules())
+        self.salts = {omods[names[mod]]: salt for mod, salt in drop_trace.items()}
+        self.ora, self.seed, self.p = ora, seed, float(p)
+        self.sites, self.elements, self.dropped = 0, 0, 0
+
+    def __enter__(self):
+        def hook(x, site):
+            salt = self.salts.get(site)
+            assert salt is not None, "dropout site %r of the oracle has no counterpart in the HIP run" % (site,)
+            keep = torch.from_numpy(hip_keep_scale(self.seed, salt, self.p, x.numel())).view(x.shape).to(x.dtype)
+            self.sites += 1
+            self.elements += x.numel()
+            self.dropped += int((keep == 0).sum())
+            return x * keep
+
+        self.ora.drop_hook = hook
+        return self
+
+    def __exit__(self, *exc):
+        self.ora.drop_hook = None
+        return False
+
+
+def assert_grads_strict(named_got, named_ref, what="", rel=1e-4, floor=1.0, rel_bound=None, rel_min_ref=1e-4, report=None, rel_abs=3e-7, rel_min_size=16):
     """north_star tolerance on every parameter gradient: max|a-b| <= rel * max(floor, max|ref|) per tensor.
     Most gradient tensors of this network are far smaller than the floor (median max|g| ~ 1e-2), so the rule above alone is an
     ABSOLUTE bound for them.  `rel_bound` adds a relative one: max|a-b| <= rel_bound * max|ref| + rel_abs for every tensor of at least 16
@@ -170,7 +241,7 @@ def assert_grads_strict(named_got, named_ref, what="", rel=1e-4, floor=1.0, rel_
         if err / bound > worst[0]:
             worst = (err / bound, k)
         mx = float(np.abs(ref).max()) if ref.size else 0.0
-        if mx >= rel_min_ref and ref.size >= 16:     # single numbers (the gradient of a shared PReLU slope: one fp32 sum over the negative side
+        if mx >= rel_min_ref and ref.size >= rel_min_size:     # single numbers (the gradient of a shared PReLU slope: one fp32 sum over the negative side
             rels.append((err / mx, k, mx))           # of a whole tensor on the reference side) stay under the absolute rule: seen at 0.5 % of
             if rel_bound is not None:                # 5.5e-4 in one run and at 0.01 % in the others, same code, same seeds, same box type
                 assert err <= rel_bound * mx + rel_abs, "%s grad %s: error %.3e > %.1e * max|ref| (%.3e) + %.1e" % (what, k, err, rel_bound, mx, rel_abs)

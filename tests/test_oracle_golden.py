@@ -9,7 +9,9 @@ from oracle import cistgcn_ref as O
 
 # parameter gradients live on very different scales (BN-fed conv biases are analytically 0):
 # compare each against the global gradient scale of the model.
-def _check_attrs(net, rec, mode):
+def _check_attrs(net, rec, mode, truth=None, **tol):
+    """interpretation attributes against `<mode>/attr/*`; with `truth` (the prefix of the reference's fp64 run of the same step) the
+    bound is 1e-4 * max(1, max|ref64|) + 3 * max|ref32 - ref64|: the reference's own fp32 error on this fixture is part of it"""
     for k, ref in rec.items():
         if not k.startswith(mode + "/attr/"):
             continue
@@ -17,7 +19,15 @@ def _check_attrs(net, rec, mode):
         for part in k[len(mode + "/attr/"):].split("."):
             obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
         got = obj.detach()
-        assert_close(got[: ref.shape[0]] if got.shape[0] != ref.shape[0] else got, ref, k)
+        got = got[: ref.shape[0]] if got.shape[0] != ref.shape[0] else got
+        if truth is None:
+            assert_close(got, ref, k, **tol)
+            continue
+        ref64 = rec[truth + k[len(mode):]]
+        noise = float(np.abs(ref.astype(np.float64) - ref64).max())
+        err = float(np.abs(got.numpy().astype(np.float64) - ref64).max())
+        bound = 1e-4 * max(1.0, float(np.abs(ref64).max())) + 3.0 * noise
+        assert err <= bound, "%s: err vs fp64 %.3e > bound %.3e (the reference's own fp32 error: %.3e)" % (k, err, bound, noise)
 
 
 def _build(name, rec):
@@ -51,29 +61,87 @@ def test_eval_forward_and_input_grad(name):
     _check_attrs(net, rec, "eval")
 
 
-@pytest.mark.parametrize("name", CASES)
-def test_train_forward_backward(name):
-    rec = load_case(name)
+def _train_step(name, rec, dtype, threads, branch_prefix):
+    from helpers import BranchReplay
     net = _build(name, rec).train()
-    x = torch.from_numpy(rec["x"]).requires_grad_(True)
-    pred, = net(x)
-    loss = O.mpjpe(pred, torch.from_numpy(rec["target"]))
-    loss.backward()
+    if dtype == torch.float64:
+        net = net.double()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        x = torch.from_numpy(rec["x"]).to(dtype).requires_grad_(True)
+        with BranchReplay.from_golden(rec, net, prefix=branch_prefix) as rep:
+            pred, = net(x)
+            loss = O.mpjpe(pred, torch.from_numpy(rec["target"]).to(dtype))
+            loss.backward()
+    finally:
+        torch.set_num_threads(prev)
+    assert rep.sites == sum(1 for m in net.modules() if isinstance(m, torch.nn.PReLU))
+    return net, x, pred, loss, rep
+
+
+@pytest.mark.parametrize("threads", [1, 4, 8, 16])
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_in_fp64_equals_the_reference_in_fp64(name, threads):
+    """THE PIN.  The real reference ran this train-mode step in fp64 (tools/gen_golden.py, `train64/*`: prediction, loss, dL/dx, all
+    698 parameter gradients, the branch every PReLU element took).  The oracle in fp64 on those branches must reproduce all of it
+    to 1e-9 * max|ref| per tensor - five orders below any fp32 effect, so an algorithmic difference cannot hide behind rounding,
+    PReLU kinks or the summation order: the result does not depend on the thread count (round 3: the fp32 comparison failed
+    3 of 4 cases under OMP_NUM_THREADS=4)."""
+    rec = load_case(name)
+    net, x, pred, loss, rep = _train_step(name, rec, torch.float64, threads, "train64/branch/")
+    assert rep.flips == 0, "oracle and reference take different branches at %d of %d elements in fp64" % (rep.flips, rep.elements)
+    tight = dict(rel=1e-9, floor=1e-30)
+    assert_close(pred, rec["train64/pred"], "pred", **tight)
+    assert_close(loss, rec["train64/loss"], "loss", **tight)
+    assert_close(x.grad, rec["train64/dx"], "dL/dx", **tight)
+    _check_attrs(net, rec, "train64", **tight)
+    grads = dict(net.named_parameters())
+    full = {k[len("train64/grad/"):]: v for k, v in rec.items() if k.startswith("train64/grad/")}
+    assert set(full) == set(grads) and len(full) == 698
+    gmax = max(float(np.abs(v).max()) for v in full.values())
+    worst = 0.0
+    for k, ref in full.items():
+        # gradients that are analytically zero (a bias in front of a train-mode BatchNorm) are fp64 rounding residue of size 1e-17:
+        # they are held to 1e-9 of the largest gradient of the model instead of their own maximum
+        err = float(np.abs(grads[k].grad.numpy() - ref).max())
+        bound = 1e-9 * max(float(np.abs(ref).max()), 1e-6 * gmax)
+        assert err <= bound, "grad %s: err %.3e > %.3e (max|ref| %.3e)" % (k, err, bound, float(np.abs(ref).max()))
+        worst = max(worst, err / bound)
+    print("%s fp64, %d threads: worst gradient at %.3f of the 1e-9 bound" % (name, threads, worst))
+
+
+@pytest.mark.parametrize("threads", [1, 4, 8, 16])
+@pytest.mark.parametrize("name", CASES)
+def test_train_forward_backward(name, threads):
+    """Train mode in fp32 against the real reference's fp32 run, on the branches the reference took (the fixtures sit on PReLU kinks -
+    batch-statistic BatchNorm over four samples -, so the reference's branch bits are replayed: both sides differentiate the same
+    piecewise-linear function).  Prediction, loss, dL/dx: 1e-4 * max(1, max|ref|).  Gradients, all 698 of all four cases: what is left
+    after the kinks is the fp32 noise of a BatchNorm over four samples, and the fixture measures it: the reference's own fp32 run is
+    up to 2.2 x 1e-4 * max(0.25, max|ref|) away from its fp64 run (`train64/*`).  Bound per tensor:
+    1e-4 * max(0.25, max|ref64|) + 3 * max|ref32 - ref64| against the fp64 truth, whatever the thread count."""
+    rec = load_case(name)
+    net, x, pred, loss, rep = _train_step(name, rec, torch.float32, threads, "train/branch/")
+    assert rep.flips <= 2e-5 * rep.elements and rep.worst <= 1e-2, "oracle and reference disagree on %d of %d branches (worst |x| %.1e of the mean)" % (rep.flips, rep.elements, rep.worst)
     assert_close(pred, rec["train/pred"], "pred")
     assert_close(loss, rec["train/loss"], "loss")
     assert_close(x.grad, rec["train/dx"], "dL/dx", floor=float(np.abs(rec["train/dx"]).max()))
-    _check_attrs(net, rec, "train")
+    _check_attrs(net, rec, "train", truth="train64")
     grads = dict(net.named_parameters())
     full = {k[len("train/grad/"):]: v for k, v in rec.items() if k.startswith("train/grad/")}
-    summ = {k[len("train/gradsum/"):]: v for k, v in rec.items() if k.startswith("train/gradsum/")}
-    assert set(full) | set(summ) == set(grads)
-    for k, ref in full.items():
-        assert_close(grads[k].grad, ref, "grad " + k, rel=1e-3, floor=1e-2)
-    for k, ref in summ.items():
-        got = grad_summary(grads[k].grad)
-        scale = max(1e-2, ref[2])          # L2 norm of the reference gradient tensor; floor for analytically-zero grads
-        assert np.abs(got[3:] - ref[3:]).max() <= 1e-3 * scale, k
-        assert abs(got[2] - ref[2]) <= 1e-3 * scale, k
+    assert set(full) == set(grads) and len(full) == 698
+    worst, noise = (0.0, None), 0.0
+    for k, ref32 in full.items():
+        ref64 = rec["train64/grad/" + k]
+        ref_noise = float(np.abs(ref32.astype(np.float64) - ref64).max())
+        base = 1e-4 * max(0.25, float(np.abs(ref64).max()))
+        err = float(np.abs(grads[k].grad.numpy().astype(np.float64) - ref64).max())
+        assert err <= base + 3.0 * ref_noise, "grad %s: err vs fp64 %.3e > %.3e + 3 * %.3e (the reference's own fp32 error)" % (k, err, base, ref_noise)
+        if err / (base + 3.0 * ref_noise) > worst[0]:
+            worst = (err / (base + 3.0 * ref_noise), k)
+        noise = max(noise, ref_noise / base)
+    print("%s fp32, %d threads: %d of %d branches differ from the reference's; worst gradient at %.2f of its bound (%s); the reference's own fp32 "
+          "run is up to %.2f x 1e-4 * max(0.25, |ref|) from its fp64 run" % (name, threads, rep.flips, rep.elements, worst[0], worst[1], noise))
     after = {k[len("train/state_after/"):]: v for k, v in rec.items() if k.startswith("train/state_after/")}
     sd = net.state_dict()
     assert after

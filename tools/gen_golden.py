@@ -31,7 +31,25 @@ CASES = {
     "amass_c16_t10_v18": (16, 10, 18, 4),  # reference-YAML AMASS joints (train_amass.yaml:5)
     "cmu_c8_t50_v25": (8, 50, 25, 4),      # BASELINE.json "25-joint" shape
 }
-FULL_GRADS = {"h36m_c8_t10_v22"}
+FULL_GRADS = {"h36m_c8_t10_v22"}      # these also keep the unit-scale run and the Adj maps of every block
+
+
+class BranchRecorder:
+    """Forward hooks on every nn.PReLU of the reference: the branch each element took (input > 0), bit-packed.  The train-mode
+    fixtures sit on PReLU kinks (batch-statistic BatchNorm over 4 samples): another summation order - a different OMP thread count is
+    enough - lands a rounding-sized pre-activation on the other side of 0 and moves whole gradient tensors by percents.  With the
+    branches recorded, a checker differentiates the SAME piecewise-linear function and the fp32 bound applies to every gradient."""
+
+    def __init__(self, net):
+        self.bits, self.handles = {}, []
+        for name, m in net.named_modules():
+            if isinstance(m, torch.nn.PReLU):
+                self.handles.append(m.register_forward_hook(lambda mod, inp, out, name=name: self.bits.__setitem__(name, inp[0].detach() > 0)))
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        return {k: np.packbits(v.numpy().reshape(-1)) for k, v in self.bits.items()}
 
 
 def import_reference():
@@ -137,16 +155,18 @@ def main():
         net.train()
         net.zero_grad()
         xt = x.clone().requires_grad_(True)
+        recorder = BranchRecorder(net)
         pred, = net(xt)
+        for k, v in recorder.close().items():
+            rec["train/branch/" + k] = v
         loss = ref_losses.mpjpe(pred, tgt)
         loss.backward()
         rec["train/pred"], rec["train/loss"], rec["train/dx"] = pred.detach().numpy(), loss.detach().numpy(), xt.grad.numpy().copy()
         for k, v in attrs(net, blocks_with_adj).items():
             rec["train/attr/" + k] = v
         for k, p in net.named_parameters():
-            if name in FULL_GRADS:
-                rec["train/grad/" + k] = p.grad.numpy().copy()
-            else:
+            rec["train/grad/" + k] = p.grad.numpy().copy()            # every gradient of every case (round 4; was: 64-element summaries)
+            if name not in FULL_GRADS:
                 rec["train/gradsum/" + k] = grad_summary(p.grad)
         for k, v in net.state_dict().items():
             if "running_" in k and (k.startswith("st_gcnns.1.") or k.startswith("st_gcnns_o.0.ts") or k.startswith("context_layer.f")):
@@ -163,6 +183,28 @@ def main():
             loss.backward()
             rec["unit/x"], rec["unit/target"] = xu.numpy(), tu.numpy()
             rec["unit/pred"], rec["unit/loss"], rec["unit/dx"] = pred.detach().numpy(), loss.detach().numpy(), xu_.grad.numpy().copy()
+
+        # ---- the same train-mode step by the reference in fp64 (round 4): the ground truth of this fixture.  An fp64 restatement of the
+        # algorithm on the fp64 reference's branches must reproduce it to ~1e-10 whatever the thread count (the algorithmic pin proper);
+        # |fp32 reference - fp64 reference| per tensor is the noise floor of every fp32 comparison against this fixture.
+        arch64, learn64 = make_cfg(C, T, V)
+        net64 = ref_model.CISTGCN(arch64, learn64).double()      # (built last: its init draws from the global RNG, nothing above may move)
+        net64.load_state_dict({k: torch.from_numpy(v).double() if v.dtype.kind == "f" else torch.from_numpy(v) for k, v in
+                               ((k[len("state/"):], rec[k]) for k in rec if k.startswith("state/"))})
+        net64.train()
+        net64.zero_grad()
+        x64 = x.double().requires_grad_(True)
+        recorder = BranchRecorder(net64)
+        pred64, = net64(x64)
+        for k, v in recorder.close().items():
+            rec["train64/branch/" + k] = v
+        loss64 = ref_losses.mpjpe(pred64, tgt.double())
+        loss64.backward()
+        rec["train64/pred"], rec["train64/loss"], rec["train64/dx"] = pred64.detach().numpy(), loss64.detach().numpy(), x64.grad.numpy().copy()
+        for k, p in net64.named_parameters():
+            rec["train64/grad/" + k] = p.grad.numpy().copy()
+        for k, v in attrs(net64, blocks_with_adj).items():
+            rec["train64/attr/" + k] = v
 
         path = os.path.join(OUT_DIR, name + ".npz")
         np.savez_compressed(path, **rec)
