@@ -823,7 +823,8 @@ def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=35
         po, = ora(xo)
         lo = O.mpjpe(po, tgt.to(odt))
         lo.backward()
-    assert rep.sites == sum(1 for m in ora.modules() if isinstance(m, nn.PReLU)), "a PReLU was not replayed (%d sites)" % rep.sites
+    # (a slope <= 0 - two PReLUs of the cmu fixture - hides the branch in the sign of the output: those layers take their own branches)
+    assert rep.sites == sum(1 for m in ora.modules() if isinstance(m, nn.PReLU) and bool((m.weight > 0).all())), "a PReLU was not replayed (%d sites)" % rep.sites
     if dropping:
         # 14 sites per DSTD_GC block + 7 in the ContextLayer (91 in the shipped configuration); the drop rate must be p
         assert drp.sites == 14 * (len(ora.st_gcnns) + len(ora.st_gcnns_o)) + 7, "dropout sites replayed: %d" % drp.sites
