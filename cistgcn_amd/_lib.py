@@ -123,6 +123,13 @@ class RowsConv(ctypes.Structure):
                 ("dy", c_void_p), ("dx", c_void_p), ("dW", c_void_p), ("ws", c_void_p)]
 
 
+class BlockInput(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("T", c_int), ("V", c_int), ("train", c_int), ("ng", c_int),
+                ("x", c_void_p), ("bn", TailBN), ("xn", c_void_p), ("rm", c_void_p), ("rq", c_void_p), ("out", c_void_p),
+                ("g", c_void_p * 8), ("dout", c_void_p * 2), ("pq", c_void_p), ("gsum", c_void_p), ("red", c_void_p),
+                ("dx", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
 class CtxHeads(ctypes.Structure):
     _fields_ = [("B", c_int), ("P", c_int), ("C", c_int), ("train", c_int), ("x", c_void_p), ("xstats", c_void_p),
                 ("w", c_void_p * 2), ("bn", TailBN * 2), ("alpha", c_void_p * 2),
@@ -183,6 +190,9 @@ _SIGNATURES = {
     "cg_pointwise_maps_fwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_bwd": [POINTER(PwMaps), P],
     "cg_pointwise_maps_ws_floats": [c_int],
+    "cg_block_input_fwd": [POINTER(BlockInput), P],
+    "cg_block_input_bwd": [POINTER(BlockInput), P],
+    "cg_block_input_supported": [c_int, c_int, c_int, c_int],
     "cg_context_heads_fwd": [POINTER(CtxHeads), P],
     "cg_context_heads_bwd": [POINTER(CtxHeads), P],
     "cg_context_heads_red_doubles": [c_int],

@@ -4,7 +4,7 @@
 #define CG_PWM_MAXN 4        // maps per launch
 #define CG_PWM_MAXROWS 128   // sum of the maps' output channels, each rounded up to 16
 
-// n pointwise (1x1) maps of ONE input: y_i[b,o,p] = sum_c W_i[o,c] x[b,c,p], x (B,Cin,P) contiguous, P % 2 == 0, Cin <= 64,
+// n pointwise (1x1) maps of ONE input: y_i[b,o,p] = sum_c W_i[o,c] x[b,c,p], x (B,Cin,P) contiguous, P % 2 == 0, Cin <= 128,
 // M_i <= 64, sum of ceil16(M_i) <= 128.  Forward reads x once for all maps; backward reads x and every dy once and produces the
 // input gradient of all maps (summed) and every weight gradient.
 struct CgPwMaps {

@@ -189,7 +189,7 @@ extern "C" int cg_pwm_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SY
 #define CG_PSTAMP_END() do { } while (0)
 #endif
 
-#define CG_PWM_MAXW 4        // weight-gradient register tiles per wave: (128 / 16) * (64 / 16) / 8 waves
+#define CG_PWM_MAXW 4        // weight-gradient register tiles per wave: (stacked rows / 16) * (Cin / 16) <= 32 over 8 waves (128 x 64, 64 x 128, 32 x 112 ...)
 
 __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) {
   const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
@@ -353,7 +353,7 @@ __global__ void cg_pwm_fold_kernel(CgPwArgs a) {
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   if (!t || t->n <= 0 || t->n > CG_PWM_MAXN) return CG_EARG;
-  if (t->B <= 0 || t->Cin <= 0 || t->Cin > 64 || t->P <= 0 || (t->P & 1)) return CG_ESHAPE;
+  if (t->B <= 0 || t->Cin <= 0 || t->Cin > 128 || t->P <= 0 || (t->P & 1)) return CG_ESHAPE;
   g->vw = (t->P & 3) == 0 ? 4 : 2;
   if (!t->x) return CG_EARG;
   int rows = 0, tile = 0;
@@ -367,6 +367,7 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   for (int k = tile; k < CG_PWM_MAXROWS / 16; ++k) { g->tile_map[k] = 0; g->tile_row0[k] = 1 << 20; }
   for (int i = t->n; i < CG_PWM_MAXN; ++i) g->row_base[i] = 0;
   g->CinM = (t->Cin + 15) & ~15; g->MM = rows; g->WS = g->CinM + 4; g->NT = rows / 16; g->CT = g->CinM / 16;
+  if (g->NT * g->CT > CG_PWM_MAXW * (CG_PWM_THREADS / 64)) return CG_ESHAPE;      // weight-gradient register tiles: NT * CT over eight waves
   const int big = bwd ? (g->MM > g->CinM ? g->MM : g->CinM) : g->CinM;
   int pt = 256;                                   // largest power of two with big * pt <= 16 * threads (the staging registers), at most 256:
   while (big * pt > 16 * CG_PWM_THREADS) pt >>= 1; // a 48-row stack (three 10-channel maps, or 40 input channels) gets 128, not 170

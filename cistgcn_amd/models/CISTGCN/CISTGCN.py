@@ -152,9 +152,16 @@ class ContextLayer(nn.Module):
 def _pointwise(x, conv, stats=False):
     """1x1 convolution over the channel axis of a 3-D or 4-D (possibly strided) tensor."""
     w = conv.weight.view(conv.out_channels, conv.in_channels)
+    if x.dim() == 4 and x.shape[0] * x.shape[2] * x.shape[3] >= _PWM_MIN_POSITIONS and ops.pointwise_maps_ok(x, [w]):
+        # long position axis: the stacked pointwise kernel with one map (x, dy read once each backward; the generic contraction split the
+        # weight gradient of a 3-channel map over 265 workgroups with atomics: 41 us for 3.4 MB)
+        return ops.pointwise_maps(x, [w], stats, biases=[conv.bias])[0]
     spec = "oc,bchw->bohw" if x.dim() == 4 else "oc,bcv->bov"
     bl = "o" if conv.bias is not None else None
     return ops.contract_stats(spec, w, x, conv.bias, bl) if stats else (ops.contract(spec, w, x, conv.bias, bl), None)
+
+
+_PWM_MIN_POSITIONS = int(__import__("os").environ.get("CISTGCN_PWM_MIN_POSITIONS", "32768"))     # B * H * W from which single 1x1 maps take the stacked kernel
 
 
 def _collapse_rows(x, conv, stats=False):
@@ -227,6 +234,7 @@ class CISTGCN(nn.Module):
         self.fused_adj = __import__("os").environ.get("CISTGCN_FUSED_ADJ", "1") != "0"
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
         self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
+        self.fused_input = __import__("os").environ.get("CISTGCN_FUSED_INPUT", "1") != "0"   # global_norm + block statistics (and their backward with the fan-in sum) as one operator
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
         self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
@@ -408,8 +416,10 @@ class CISTGCN(nn.Module):
         doms = (m.dsgn, m.tsgn)
         if not all(d.interpretable for d in doms):
             return self._block(m, x)
-        xn0 = self._na(x, bn=m.global_norm)
-        B, _, T, V = xn0.shape
+        x_in, x_sums = x if isinstance(x, tuple) else (x, None)       # (tensor, f64 channel sums) from the previous block's tail in train mode
+        fused_in = self.fused_input and ops.block_input_ok(x_in)
+        xn0 = None if fused_in else self._na(x, bn=m.global_norm)
+        B, _, T, V = x_in.shape
         has_res = not isinstance(m.dsgn.residual, nn.Identity)
         has_bres = not isinstance(m.residual, nn.Identity)
         # the normalised input feeds the statistics, the first-level maps, both graph stages and the identity residuals:
@@ -420,18 +430,25 @@ class CISTGCN(nn.Module):
         # the four tower convolutions read the block input in one pass, forward and backward (csrc/tower_maps.hip)
         # (both stackings below pay off once the block input is worth the two or three extra small launches: measured break-even
         # between the B=16 / C=8 and the B=256 / C=64 workloads)
-        big = xn0.numel() >= self.stack_min_elements
-        stacked = big and self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(xn0, tower_w)
+        big = x_in.numel() >= self.stack_min_elements
+        stacked = big and self.fused_maps and all(c.bias is None for c in tower_in) and ops.pointwise_maps_ok(x_in, tower_w)
         cs, ct = m.conv_s[0], m.conv_t[0]
         gates = big and self.fused_maps and cs.weight.shape == ct.weight.shape and cs.bias is None and ct.bias is None
-        rows_gate = gates and 2 * cs.out_channels <= 64 and ops.collapse_rows_ok(xn0, cs.weight.view(cs.out_channels, cs.in_channels, -1))
+        rows_gate = gates and 2 * cs.out_channels <= 64 and ops.collapse_rows_ok(x_in, cs.weight.view(cs.out_channels, cs.in_channels, -1))
         # the residual maps of a block that changes its width (1x1 convolutions WITH bias, CISTGCN.py:246-254 / :357-365) read the block
         # input in one pass per group as well (a group: up to 128 stacked output rows)
         res_convs = ([d.residual[0] for d in doms] if has_res else []) + ([m.residual[0]] if has_bres else [])
         res_w = [c.weight.view(c.out_channels, c.in_channels) for c in res_convs]
-        res_groups = self._map_groups(xn0, res_w) if (big and self.fused_maps and self.fused_res_maps and res_convs) else None
-        xa = list(ops.fanout(xn0, 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (len(res_groups) if res_groups else 0)
-                             + (0 if has_res else 2) + (0 if has_bres else 1)))
+        res_groups = self._map_groups(x_in, res_w) if (big and self.fused_maps and self.fused_res_maps and res_convs) else None
+        n_alias = 4 + (1 if stacked else 0) + (1 if rows_gate else 0) + (len(res_groups) if res_groups else 0) + (0 if has_res else 2) + (0 if has_bres else 1)
+        if fused_in:
+            # global_norm and the block statistics from one pass over the block input; in backward the gradients of all the consumers below,
+            # the statistics' gradient and the BatchNorm backward are two streaming passes (csrc/block_input.hip)
+            self._site += 1          # the row kernel of global_norm numbers a (dropout-free) site: later layers draw the same masks on either path
+            xa, (stats_s, stats_t) = ops.block_input(x_in, m.global_norm, tr, n_alias - 1, stats=x_sums if tr else None)
+            xa = [None] + xa
+        else:
+            xa = list(ops.fanout(xn0, n_alias))
         x_stats, xn, x_dom = xa[0], xa[1], xa[2:4]
         k = 4
         x_maps = x_gates = None
@@ -444,7 +461,8 @@ class CISTGCN(nn.Module):
             x_resmaps, k = xa[k:k + len(res_groups)], k + len(res_groups)
         x_res = xa[k:k + 2] if not has_res else None
         x_bres = xa[-1] if not has_bres else None
-        stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)        # one alias per gate path
+        if not fused_in:
+            stats_s, stats_t = ops.fanout(ops.dstd_stats(x_stats), 2)    # one alias per gate path
         # 1. every first-level map of xn
         # the two gate paths start with the same (T,1) convolution shape on the same input: one convolution of the stacked weights
         # (the block input travels once instead of twice, forward and in both gradients)

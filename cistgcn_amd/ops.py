@@ -1694,6 +1694,102 @@ def map2adj_tail(seeds, expansors, train, drop_p=0.0, salts=(0, 0), taps=None):
     return _Map2AdjTail.apply(cfg, *ts)
 
 
+def block_input_ok(x):
+    """True when `block_input` takes the block input x (B,C,T,V)."""
+    if x.dim() != 4 or not x.is_contiguous() or x.dtype != torch.float32:
+        return False
+    B, C, T, V = x.shape
+    return bool(_lib.lib().cg_block_input_supported(B, C, T, V))
+
+
+_BLOCK_INPUT_MAXG = 8
+
+
+class _BlockInput(torch.autograd.Function):
+    """xn = global_norm(x) and _get_stats_(xn) of a DSTD_GC block (CISTGCN.py:375-379, :360-371; csrc/block_input.hip).  Outputs: `n`
+    aliases of xn (one per consumer, as ops.fanout) and two of the statistics; backward takes the consumers' gradients as they are:
+    fan-in sum, statistics backward and BatchNorm backward are two streaming passes.  Tensor inputs: x gamma beta."""
+
+    @staticmethod
+    def _block(x, bn, save, train):
+        B, C, T, V = x.shape
+        t = _lib.BlockInput()
+        t.B, t.C, t.T, t.V, t.train = B, C, T, V, 1 if train else 0
+        t.x = x.data_ptr()
+        _tail_bn(t.bn, bn, None, save, train)
+        return t
+
+    @staticmethod
+    def forward(ctx, cfg, x, gamma, beta):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        dev, f32, train, n = x.device, torch.float32, bool(cfg["train"]), int(cfg["n"])
+        B, C, T, V = x.shape
+        save = torch.empty(2, C, dtype=f32, device=dev)
+        t = _BlockInput._block(x, cfg["bn"], save, train)
+        stream = _stream(x)
+        if train:
+            if B * T * V <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(x.shape),))
+            stats = cfg.get("stats")
+            if stats is None:
+                stats = _arena(dev).take(2 * C * _lib.STAT_REPLICAS)
+                it = _lib.StatsArgs()
+                it.x, it.xv, it.pre, it.stats = x.data_ptr(), _view4(x), None, stats.data_ptr()
+                _lib.call("cg_chan_stats_many", (_lib.StatsArgs * 1)(it), 1, stream)
+            t.bn.stats = stats.data_ptr()
+        xn = torch.empty_like(x)
+        rows = torch.empty(2, B, C, T, dtype=f32, device=dev)
+        out = torch.empty(B, 2 + 2 * T, dtype=f32, device=dev)
+        t.xn, t.rm, t.rq, t.out = xn.data_ptr(), rows[0].data_ptr(), rows[1].data_ptr(), out.data_ptr()
+        _lib.call("cg_block_input_fwd", ctypes.byref(t), stream)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, gamma, beta, rows, save)
+        return tuple(xn.view_as(xn) for _ in range(n)) + (out.view_as(out), out.view_as(out))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, gamma, beta, rows, save = ctx.saved_tensors
+        cfg = ctx.cfg
+        n = int(cfg["n"])
+        gs = [g for g in grads[:n] if g is not None]
+        douts = [g for g in grads[n:n + 2] if g is not None]
+        if not gs and not douts:
+            return None, None, None, None
+        dev, f32 = x.device, torch.float32
+        B, C, T, V = x.shape
+        gs = [g if g.is_contiguous() else _copy(g) for g in gs]
+        douts = [g if g.is_contiguous() else _copy(g) for g in douts]
+        while len(gs) > _BLOCK_INPUT_MAXG:                      # more consumers than pointer slots: fold the tail first
+            gs = gs[:_BLOCK_INPUT_MAXG - 1] + [_sum_tensors(gs[_BLOCK_INPUT_MAXG - 1:])]
+        t = _BlockInput._block(x, cfg["bn"], save, False)
+        t.train = 1 if cfg["train"] else 0
+        t.rm, t.rq = rows[0].data_ptr(), rows[1].data_ptr()
+        t.ng = len(gs)
+        for i, g in enumerate(gs):
+            t.g[i] = g.data_ptr()
+        for i, g in enumerate(douts):
+            t.dout[i] = g.data_ptr()
+        pq = torch.empty(B, C, T, 2, dtype=f32, device=dev) if douts else None
+        gsum = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        small = torch.empty(2, C, dtype=f32, device=dev)
+        red = _arena(dev).take(2 * C * _lib.STAT_REPLICAS)
+        t.pq, t.gsum, t.red, t.dx, t.dgamma, t.dbeta = _ptr(pq), gsum.data_ptr(), red.data_ptr(), dx.data_ptr(), small[0].data_ptr(), small[1].data_ptr()
+        _lib.call("cg_block_input_bwd", ctypes.byref(t), _stream(x))
+        del gs, douts, gsum, pq
+        return (None, dx if ctx.needs_input_grad[1] else None, small[0] if ctx.needs_input_grad[2] else None,
+                small[1] if ctx.needs_input_grad[3] else None)
+
+
+def block_input(x, bn, train, n, stats=None):
+    """(aliases of xn = bn(x) [n of them, one per consumer], (stats_a, stats_b) = two aliases of _get_stats_(xn)) for the block input x
+    (B,C,T,V); `stats`: f64 channel sums of x when the producer emitted them (train mode)."""
+    cfg = {"train": bool(train), "n": int(n), "bn": bn, "stats": stats}
+    out = _BlockInput.apply(cfg, x, bn.weight, bn.bias)
+    return list(out[:n]), (out[n], out[n + 1])
+
+
 def context_heads_ok(x, hidden):
     """True when `context_heads` takes the two one-channel heads of x (B,1,H,W)."""
     return x.dim() == 4 and x.shape[1] == 1 and x.is_contiguous() and hidden <= 64 and x.shape[2] * x.shape[3] <= 16384
@@ -1795,7 +1891,7 @@ def pointwise_maps_ok(x, weights):
         return False
     B, C, H, W = x.shape
     rows = sum((w.shape[0] + 15) // 16 * 16 for w in weights)
-    return C <= 64 and (H * W) % 2 == 0 and rows <= 128 and all(w.shape[0] <= 64 for w in weights)
+    return C <= 128 and (H * W) % 2 == 0 and rows <= 128 and (rows // 16) * ((C + 15) // 16) <= 32 and all(w.shape[0] <= 64 for w in weights)
 
 
 class _PointwiseMaps(torch.autograd.Function):

@@ -273,8 +273,8 @@ long long cg_fpn_conv_ws_floats(int B, int C, int O, int n);
 /* ---- stacked pointwise maps of one input: the first convolutions of the Map2Adj towers of a block, CISTGCN.py:138-163 applied
  * to the normalised block input by :183-186 (up to four 1x1 convolutions of the same (B,C,T,V) tensor).  Forward: every y_i =
  * W_i x from one read of x, with the f64 channel sums of y_i (train-mode BatchNorm behind it).  Backward: dx = sum_i W_i^T dy_i and
- * every dW_i = dy_i x^T from one read of x and of each dy_i.  x (B,Cin,P) contiguous, P = T*V with P % 2 == 0 (rows of 16- or 8-byte alignment), Cin <= 64,
- * M_i <= 64, sum of ceil16(M_i) <= 128; other shapes: CG_ESHAPE (the caller uses cg_contract_many). */
+ * every dW_i = dy_i x^T from one read of x and of each dy_i.  x (B,Cin,P) contiguous, P = T*V with P % 2 == 0 (rows of 16- or 8-byte alignment), Cin <= 128,
+ * M_i <= 64, sum of ceil16(M_i) <= 128, (sum of ceil16(M_i) / 16) * ceil(Cin / 16) <= 32; other shapes: CG_ESHAPE (the caller uses cg_contract_many). */
 #define CG_PWM_MAXN 4
 typedef struct CgPwMaps {
   int B, Cin, P, n;
@@ -317,6 +317,32 @@ int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, void* stream);
 long long cg_map2adj_tail_ws_floats(int Kc);
 long long cg_map2adj_tail_part_floats(int B, int Kc, int J);
 long long cg_map2adj_tail_red_doubles(int Kc);
+
+/* ---- head of a DSTD_GC block, DSTD_GC.forward CISTGCN.py:375-379 with _get_stats_ :360-371 ---------------
+ * xn = global_norm(x) (BatchNorm2d) and the block statistics of xn from one pass over x; backward: the gradients of all consumers of
+ * xn (g[0..ng-1], null entries skipped), the gradient of the statistics (dout[0] + dout[1]) and the BatchNorm backward in two
+ * streaming passes.  x (B,C,T,V) contiguous with T*V <= 4608 (cg_block_input_supported; else CG_ESHAPE: cg_norm_act + cg_dstd_stats).
+ * Forward (two launches) writes xn, rm / rq ((B,C,T) row means and centred sums of squares, read again by the backward), out
+ * (B, 2+2T) and bn.save; train mode needs bn.stats = f64 sums of x.  Backward (three launches) needs pq (B,C,T,2) and gsum (B,C,T,V)
+ * scratch and red = [CG_STAT_REPLICAS][C][2] zeroed f64 words; writes dx, dgamma, dbeta. */
+#define CG_BIN_MAXG 8
+typedef struct CgBlockInput {
+  int B, C, T, V, train, ng;
+  const float* x;
+  CgTailBN bn;
+  float* xn;
+  float* rm; float* rq;
+  float* out;
+  const float* g[CG_BIN_MAXG];
+  const float* dout[2];
+  float* pq;
+  float* gsum;
+  double* red;
+  float* dx; float* dgamma; float* dbeta;
+} CgBlockInput;
+int cg_block_input_fwd(const CgBlockInput* t, void* stream);
+int cg_block_input_bwd(const CgBlockInput* t, void* stream);
+int cg_block_input_supported(int B, int C, int T, int V);
 
 /* ---- ContextLayer heads 1 and 3, CISTGCN.py:408-418 with :465 / :467 ---------------------------------
  * Conv2d(1, C, 1, bias=False) -> BatchNorm2d(C) -> PReLU of the one-channel tensor x (B,1,T_out,3V), reduced over the positions:

@@ -979,6 +979,74 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6), (2, 4
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
+def check_block_input(device, shapes=((3, 5, 4, 6, 3), (2, 10, 10, 22, 7), (4, 64, 5, 22, 8), (2, 6, 5, 5, 2), (3, 3, 22, 25, 4))):
+    """ops.block_input (csrc/block_input.hip) against stock PyTorch BatchNorm2d + the oracle's block statistics (CISTGCN.py:360-379):
+    the aliases of xn, the statistics, running statistics; backward with a different gradient on every alias and on both statistics
+    outputs: dx, dgamma, dbeta.  Train and eval mode, with and without channel sums handed over by the producer, plane sizes of
+    16-, 8- and 4-byte alignment.  shapes: (B, C, T, V, n aliases)."""
+    g = _gen(71)
+    for (B, C, T, V, n) in shapes:
+        for train in (True, False):
+            for given_stats in ((False, True) if train else (False,)):
+                def make(dt=torch.float32):
+                    gg = _gen(400 + C)
+                    bn = nn.BatchNorm2d(C)
+                    with torch.no_grad():
+                        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=gg)); bn.bias.copy_(0.3 * torch.randn(C, generator=gg))
+                        bn.running_mean.copy_(0.2 * torch.randn(C, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(C, generator=gg))
+                    return bn.to(dt)
+                x0 = 0.7 + 2.0 * _rand(g, B, C, T, V)
+                gxs = [_rand(g, B, C, T, V) if i != 1 else None for i in range(n)]          # one consumer without a gradient
+                gst = [_rand(g, B, 2 + 2 * T), _rand(g, B, 2 + 2 * T)]
+                what = "block_input B%d C%d T%d V%d %s%s" % (B, C, T, V, "train" if train else "eval", " (sums given)" if given_stats else "")
+                # reference in fp64
+                ref = make(torch.float64).train(train)
+                xr = _leaf(x0.double(), "cpu")
+                xnr = ref(xr)
+                sr = O.CISTGCN.block_stats(xnr)
+                torch.autograd.backward([xnr, sr], [sum(t.double() for t in gxs if t is not None), (gst[0] + gst[1]).double()])
+                # HIP
+                bn = make().to(device).train(train)
+                xd = _leaf(x0, device)
+                ops.begin_step(device)
+                stats = None
+                if given_stats:
+                    stats = ops._arena(device).take(2 * C * ops._lib.STAT_REPLICAS)
+                    xc = x0.double()
+                    stats.view(ops._lib.STAT_REPLICAS, C, 2)[3] = torch.stack((xc.sum((0, 2, 3)), (xc * xc).sum((0, 2, 3))), 1).to(device)
+                xs, (sa, sb) = ops.block_input(xd, bn, train, n, stats=stats)
+                outs = [t for t, gg_ in zip(xs, gxs) if gg_ is not None] + [sa, sb]
+                torch.autograd.backward(outs, [gg_.to(device) for gg_ in gxs if gg_ is not None] + [t.to(device) for t in gst])
+                for t in xs:
+                    assert_close(t, xnr, what + " xn", rel=2e-5)
+                assert_close(sa, sr, what + " statistics", rel=2e-5)
+                assert_close(sb, sr, what + " statistics (2)", rel=2e-5)
+                assert_close(xd.grad, xr.grad, what + " dx", rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
+                assert_close(bn.weight.grad, ref.weight.grad, what + " dgamma", rel=5e-5)
+                assert_close(bn.bias.grad, ref.bias.grad, what + " dbeta", rel=5e-5)
+                for (k, ba), (_, bb) in zip(bn.named_buffers(), ref.named_buffers()):
+                    assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, k), rel=1e-5)
+    # only the statistics reach the loss / only one alias does
+    bn = nn.BatchNorm2d(6).to(device).train()
+    x0, gx = _rand(g, 3, 6, 4, 6), _rand(g, 3, 6, 4, 6)
+    for only in ("stats", "alias"):
+        ref = nn.BatchNorm2d(6).double().train()
+        xr = _leaf(x0.double(), "cpu")
+        xnr = ref(xr)
+        if only == "stats":
+            O.CISTGCN.block_stats(xnr).sum().backward()
+        else:
+            xnr.backward(gx.double())
+        xd = _leaf(x0, device)
+        ops.begin_step(device)
+        xs, (sa, sb) = ops.block_input(xd, bn, True, 3)
+        if only == "stats":
+            sa.backward(torch.ones_like(sa))
+        else:
+            xs[2].backward(gx.to(device))
+        assert_close(xd.grad, xr.grad, "block_input dx (%s only)" % only, rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
+
+
 def check_context_heads(device, shapes=((3, 5, 12, 7), (4, 25, 66, 64), (2, 3, 10, 33))):
     """ops.context_heads (csrc/context_heads.hip) against stock PyTorch modules Conv2d(1, C, 1) -> BatchNorm2d -> PReLU and the
     reference's reductions (CISTGCN.py:465, :467): outputs, the PReLU taps, input gradient, every parameter gradient, running
@@ -1045,7 +1113,7 @@ def check_context_heads(device, shapes=((3, 5, 12, 7), (4, 25, 66, 64), (2, 3, 1
 
 
 def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6),
-                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6), (2, 1, (64, 64), 25, 66), (3, 32, (16, 16, 16, 16), 5, 10))):      # the last two: P % 4 == 2
+                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6), (2, 1, (64, 64), 25, 66), (3, 32, (16, 16, 16, 16), 5, 10), (3, 100, (25,), 10, 22), (2, 128, (3,), 6, 6))):      # P % 4 == 2: (25, 66) and (5, 10); the last two: more than 64 input channels (FPN compress)
     """ops.pointwise_maps (csrc/tower_maps.hip) against one generic contraction per map: outputs, f64 channel sums, the summed
     input gradient, every weight gradient; every other shape with biases on all maps but the last (the residual maps of a block,
     nn.Conv2d(cin, cout, 1) with its default bias) and their gradients.  shapes: (B, Cin, (M_i), T, V)."""
