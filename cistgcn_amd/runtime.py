@@ -497,24 +497,49 @@ class DataParallelStep(_StepBase):
                     return True
             return False
 
-        groups = 0
+        last = self._choose_group(probe, collective, new_groups, dev, lambda: last)
+        self._side, self.overlap_probe = kept[-1], last
+        return last
+
+    def _choose_group(self, probe, collective, new_groups, dev, result, backend="nccl"):
+        """The regrouping loop of `pick_side_stream` (separate so that a test can drive it with a stubbed probe over gloo):
+        probe the group; when a rank found no independent stream with the collective in the chain, ALL ranks replace the
+        group together.  `dist.new_group` must be entered by every rank of the default group, so only a step that runs on the
+        default group (group None / WORLD) regroups - a step on a sub-group keeps its group and says so in the record.  Whether
+        the replacement worked is agreed by a second MIN all-reduce (one rank's exception must not make the ranks diverge);
+        a replaced group that this object created is destroyed."""
+        import torch.distributed as dist
+        groups, made = 0, None
         while True:
             ok = probe(self.group)
+            last = result()
             if not collective:
                 break
             flag = torch.tensor([1.0 if ok else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)        # every rank has to have found one
             if float(flag.item()) > 0.0 or groups >= new_groups:
                 break
-            try:                                                # every rank reaches this line or none does (the MIN above)
-                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
-                self.group = dist.new_group(ranks=ranks, backend="nccl")
-            except (RuntimeError, ValueError) as e:             # keep the group: the step is correct either way, only not overlapped
-                last["new_group_error"] = str(e)[:200]
+            if self.group is not None and self.group is not dist.group.WORLD and self.group is not made:
+                last["regroup_skipped"] = "the step runs on a sub-group: new_group needs every rank of the default group"
                 break
+            err, fresh = None, None
+            try:
+                ranks = dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD)
+                fresh = dist.new_group(ranks=ranks, backend=backend)
+            except (RuntimeError, ValueError) as e:             # keep the group: the step is correct either way, only not overlapped
+                err = str(e)[:200]
+            agreed = torch.tensor([0.0 if err else 1.0], device=dev)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)      # the outcome of new_group, agreed by all ranks
+            if float(agreed.item()) <= 0.0:
+                if fresh is not None:
+                    dist.destroy_process_group(fresh)
+                last["new_group_error"] = err or "another rank could not create the group"
+                break
+            if made is not None:
+                dist.destroy_process_group(made)               # only groups this loop created; the caller's group is the caller's
+            self.group = made = fresh
             groups += 1
         last["groups"] = groups
-        self._side, self.overlap_probe = kept[-1], last
         return last
 
     # ---- the two phases ---------------------------------------------------------------------------------------

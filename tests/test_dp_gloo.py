@@ -128,3 +128,75 @@ def test_model_step_matches_oracle_per_shard(SHARDS):
         assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
     for r in range(1, world):
         assert np.array_equal(res[0][4], res[r][4]), "replicas diverged after the optimizer step"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the group-replacement branch of DataParallelStep.pick_side_stream (only reachable under nccl with N > 1 on hardware):
+# driven here over gloo with a stubbed probe
+# ---------------------------------------------------------------------------------------------------------------
+def _regroup_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        from cistgcn_amd.runtime import DataParallelStep
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        out = {}
+
+        def run(group, fails_on):
+            """a step object with only the state the loop touches; `fails_on[rank]` = probes that find no independent stream"""
+            step = DataParallelStep.__new__(DataParallelStep)
+            step.group = group
+            calls, seen = [0], []
+            record = {}
+
+            def probe(g):
+                seen.append(g)
+                calls[0] += 1
+                record.clear()
+                record.update({"independent": calls[0] > fails_on[rank], "tried": calls[0]})
+                return record["independent"]
+
+            last = step._choose_group(probe, True, 3, torch.device("cpu"), lambda: record, backend="gloo")
+            return step, last, seen
+
+        # (a) default group, rank 1 fails once: BOTH ranks regroup once, then agree
+        step, last, seen = run(None, {0: 0, 1: 1})
+        out["a"] = (last["groups"], len(seen), seen[0] is None, seen[-1] is step.group and step.group is not None)
+        t = torch.ones(1) * (rank + 1)
+        dist.all_reduce(t, group=step.group)               # the replacement works as a group
+        out["a_sum"] = float(t.item())
+        # (b) nobody ever finds a stream: three replacements, then the loop gives up (the earlier replacements are destroyed)
+        step, last, seen = run(None, {0: 99, 1: 99})
+        out["b"] = (last["groups"], len(seen))
+        # (c) a step on a sub-group never calls new_group (it would hang the ranks outside the sub-group)
+        sub = dist.new_group(ranks=[0, 1], backend="gloo")
+        step, last, seen = run(sub, {0: 99, 1: 99})
+        out["c"] = (last["groups"], len(seen), "regroup_skipped" in last, step.group is sub)
+        q.put((rank, "ok", out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def test_side_stream_regrouping_is_collective_and_bounded():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_regroup_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        rank, status, payload = q.get(timeout=300)
+        assert status == "ok", payload
+        res[rank] = payload
+    for p in procs:
+        p.join(60)
+    for rank in (0, 1):
+        assert res[rank]["a"] == (1, 2, True, True), res[rank]
+        assert res[rank]["a_sum"] == 3.0
+        assert res[rank]["b"] == (3, 4), res[rank]
+        assert res[rank]["c"] == (0, 1, True, True), res[rank]
