@@ -18,6 +18,8 @@
 //   sWt[Cin][Coutp]  W transposed (fwd) / sW [Cout][Cinp] (bwd)
 #include "cg_common.h"
 #include "stgcn_domain.h"
+#include <atomic>
+#include <cstdlib>
 #include <stdlib.h>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
@@ -30,12 +32,15 @@ static const char* cg_dom_env(const char* name) {
   return ablation ? getenv(name) : nullptr;
 }
 // grid size from which the plane kernels fill the chip
-static long long cg_dom_planes_min = 256;
-static long long cg_dom_planes_min_wgs() { return cg_dom_planes_min; }
+// A process-wide switch read by every forward and backward launch: atomic, and changes are refused (the current value is returned, nothing
+// moves) unless the process runs with CISTGCN_ABLATION=1 like the other kernel-generation switches - a test or tool that dies between
+// setting and restoring it cannot silently change what production launches and captured HIP graphs run.
+static std::atomic<long long> cg_dom_planes_min{256};
+static long long cg_dom_planes_min_wgs() { return cg_dom_planes_min.load(std::memory_order_relaxed); }
 extern "C" long long cg_stgcn_domain_planes_min_workgroups(long long n) {
-  const long long prev = cg_dom_planes_min;
-  if (n >= 0) cg_dom_planes_min = n;
-  return prev;
+  static const bool allowed = [] { const char* e = getenv("CISTGCN_ABLATION"); return e && e[0] == '1'; }();
+  if (n >= 0 && allowed) return cg_dom_planes_min.exchange(n);
+  return cg_dom_planes_min_wgs();
 }
 
 struct CgDomainGeom {

@@ -161,8 +161,11 @@ __global__ __launch_bounds__(CG_DOMP_THREADS, 2) void cg_stgcn_planes_fwd_kernel
   float bv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) { const int co = o0 + 4 * slot + r; bv[r] = (bias && co < g.Cout) ? bias[co] : 0.f; }
-  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+  // BatchNorm channel sums: fp32 inside one group (at most J values per lane), f64 across the groups and lanes - the variance is formed as
+  // E[y^2] - E[y]^2, activations with |mean| >> std would lose it in fp32 sums over the whole plane
+  double st1[4] = {0.0, 0.0, 0.0, 0.0}, st2[4] = {0.0, 0.0, 0.0, 0.0};
   for (int gi = wave; gi < g.NG; gi += CG_DOMP_NW) {
+    float gs1[4] = {0.f, 0.f, 0.f, 0.f}, gs2[4] = {0.f, 0.f, 0.f, 0.f};
     const float* ag = adj + ((long long)b * g.NG + gi) * J * J;
     float* zs = sZ + gi * g.GSTR;
     const float* za = zs + l15 * g.JS + slot;
@@ -213,18 +216,20 @@ __global__ __launch_bounds__(CG_DOMP_THREADS, 2) void cg_stgcn_planes_fwd_kernel
 #pragma unroll
           for (int i = 0; i < VWB; ++i) {
             v[i] = acc[m * VWB + i][r] + bv[r];
-            st1[r] += v[i]; st2[r] += v[i] * v[i];
+            gs1[r] += v[i]; gs2[r] += v[i] * v[i];
           }
           cg_domp_st<VWB>(zs + (4 * slot + r) * g.JS + q0, v);
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st1[r] += (double)gs1[r]; st2[r] += (double)gs2[r]; }
   }
   if (ystats) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float a = cg_row16_sum(st1[r]), c = cg_row16_sum(st2[r]);
-      if (l15 == 0) { atomicAdd(&sStat[2 * (4 * slot + r)], (double)a); atomicAdd(&sStat[2 * (4 * slot + r) + 1], (double)c); }
+      const double a = cg_row16_sum(st1[r]), c = cg_row16_sum(st2[r]);
+      if (l15 == 0) { atomicAdd(&sStat[2 * (4 * slot + r)], a); atomicAdd(&sStat[2 * (4 * slot + r) + 1], c); }
     }
   }
   __syncthreads();

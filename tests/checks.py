@@ -562,6 +562,8 @@ def check_stgcn_domain(device, shapes=((3, 10, 8, 5, 7), (2, 8, 8, 10, 22), (2, 
     from cistgcn_amd import _lib
     g = _gen(7)
     prev = _lib.lib().cg_stgcn_domain_planes_min_workgroups(1 if planes else -1)
+    if planes:
+        assert _lib.lib().cg_stgcn_domain_planes_min_workgroups(-1) == 1, "the kernel-generation switch is locked: run the tests with CISTGCN_ABLATION=1 (tests/conftest.py sets it)"
     try:
         for (B, Cin, Cout, T, V) in shapes:
             for domain in (0, 1):
