@@ -126,7 +126,7 @@ class RowsConv(ctypes.Structure):
 class BlockInput(ctypes.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("T", c_int), ("V", c_int), ("train", c_int), ("ng", c_int),
                 ("x", c_void_p), ("bn", TailBN), ("xn", c_void_p), ("rm", c_void_p), ("rq", c_void_p), ("out", c_void_p),
-                ("g", c_void_p * 8), ("dout", c_void_p * 2), ("pq", c_void_p), ("gsum", c_void_p), ("red", c_void_p),
+                ("g", c_void_p * 8), ("dout", c_void_p * 2), ("dout_ld", c_longlong * 2), ("pq", c_void_p), ("gsum", c_void_p), ("red", c_void_p),
                 ("dx", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
 
 

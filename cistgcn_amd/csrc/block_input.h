@@ -16,6 +16,7 @@ struct CgBlockInput {
   // backward
   const float* g[CG_BIN_MAXG];  // gradients with respect to xn from its consumers, (B,C,T,V) contiguous, ng of them (null entries skipped)
   const float* dout[2];         // gradients of `out` from its (up to two) consumers, (B, 2 + 2T); null entries skipped
+  long long dout_ld[2];         // their row strides in floats (column slices of a wider tensor are taken as they are)
   float* pq;                    // (B,C,T,2) scratch: slope / offset of the statistics' gradient per row
   float* gsum;                  // (B,C,T,V) scratch: the summed gradient in front of the BatchNorm (eval mode: may alias dx)
   double* red;                  // [CG_STAT_REPLICAS][C][2] f64, zero on entry

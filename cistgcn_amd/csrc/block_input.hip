@@ -144,8 +144,8 @@ __global__ __launch_bounds__(CG_BIN_THREADS) void cg_bin_coef_kernel(CgBlockInpu
   const int b = blockIdx.x;
   for (int i = threadIdx.x; i < 2 + 2 * T; i += blockDim.x) {
     float v = 0.f;
-    if (t.dout[0]) v += t.dout[0][(long long)b * (2 + 2 * T) + i];
-    if (t.dout[1]) v += t.dout[1][(long long)b * (2 + 2 * T) + i];
+    if (t.dout[0]) v += t.dout[0][(long long)b * t.dout_ld[0] + i];
+    if (t.dout[1]) v += t.dout[1][(long long)b * t.dout_ld[1] + i];
     sg[i] = v;
   }
   cg_bin_channel_stats(t, b, rm, rq, cm, cs);

@@ -16,7 +16,7 @@
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
-#define CG_CTX_THREADS 256
+#define CG_CTX_THREADS 1024                                 // sixteen slices of the positions: a sample's loop is 100 iterations per lane, not 400
 #define CG_CTX_SLICES (CG_CTX_THREADS / CG_CTX_MAXC)      // a wave = one slice of the positions, a lane = one channel
 
 struct CgCtxChan { float w, m, r, s, beta, alpha; };      // s = gamma * r

@@ -1759,7 +1759,7 @@ class _BlockInput(torch.autograd.Function):
         dev, f32 = x.device, torch.float32
         B, C, T, V = x.shape
         gs = [g if g.is_contiguous() else _copy(g) for g in gs]
-        douts = [g if g.is_contiguous() else _copy(g) for g in douts]
+        douts = [g if g.stride(1) == 1 else _copy(g) for g in douts]       # column slices of the gate inputs' gradient are taken as they are
         while len(gs) > _BLOCK_INPUT_MAXG:                      # more consumers than pointer slots: fold the tail first
             gs = gs[:_BLOCK_INPUT_MAXG - 1] + [_sum_tensors(gs[_BLOCK_INPUT_MAXG - 1:])]
         t = _BlockInput._block(x, cfg["bn"], save, False)
@@ -1769,7 +1769,7 @@ class _BlockInput(torch.autograd.Function):
         for i, g in enumerate(gs):
             t.g[i] = g.data_ptr()
         for i, g in enumerate(douts):
-            t.dout[i] = g.data_ptr()
+            t.dout[i], t.dout_ld[i] = g.data_ptr(), g.stride(0)
         pq = torch.empty(B, C, T, 2, dtype=f32, device=dev) if douts else None
         gsum = torch.empty_like(x)
         dx = torch.empty_like(x)

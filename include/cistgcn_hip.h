@@ -335,6 +335,7 @@ typedef struct CgBlockInput {
   float* out;
   const float* g[CG_BIN_MAXG];
   const float* dout[2];
+  long long dout_ld[2];         /* row strides of dout[i] in floats */
   float* pq;
   float* gsum;
   double* red;

@@ -999,7 +999,7 @@ def check_block_input(device, shapes=((3, 5, 4, 6, 3), (2, 10, 10, 22, 7), (4, 6
                     return bn.to(dt)
                 x0 = 0.7 + 2.0 * _rand(g, B, C, T, V)
                 gxs = [_rand(g, B, C, T, V) if i != 1 else None for i in range(n)]          # one consumer without a gradient
-                gst = [_rand(g, B, 2 + 2 * T), _rand(g, B, 2 + 2 * T)]
+                gst = [_rand(g, B, 2 + 2 * T), _rand(g, B, 7 + 2 * T)[:, 3:5 + 2 * T]]         # the second one: a column slice (the gate inputs' gradient)
                 what = "block_input B%d C%d T%d V%d %s%s" % (B, C, T, V, "train" if train else "eval", " (sums given)" if given_stats else "")
                 # reference in fp64
                 ref = make(torch.float64).train(train)
