@@ -328,7 +328,7 @@ extern "C" int cg_block_input_fwd(const CgBlockInput* t, void* stream_) {
   st = cg_launch_status();
   if (st != CG_OK) return st;
   const size_t lds2 = (size_t)(2 * t->C * t->T + 2 * t->C) * sizeof(float);
-  if (lds2 > 64 * 1024 && hipFuncSetAttribute((const void*)cg_bin_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess) return CG_ESHAPE;
+  if (lds2 > 64 * 1024 && cg_lds_limit((const void*)cg_bin_stats_kernel, lds2) != hipSuccess) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_bin_stats_kernel, dim3((unsigned)t->B), block, lds2, stream, *t);
   return cg_launch_status();
 }
@@ -346,7 +346,7 @@ extern "C" int cg_block_input_bwd(const CgBlockInput* t, void* stream_) {
   CgBlockInput a = *t;
   if (stats_grad) {
     const size_t lds = (size_t)(2 * t->C * t->T + 2 * t->C + 4 * t->T + 2) * sizeof(float);
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)cg_bin_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return CG_ESHAPE;
+    if (lds > 64 * 1024 && cg_lds_limit((const void*)cg_bin_coef_kernel, lds) != hipSuccess) return CG_ESHAPE;
     hipLaunchKernelGGL(cg_bin_coef_kernel, dim3((unsigned)t->B), block, lds, stream, a);
     st = cg_launch_status();
     if (st != CG_OK) return st;

@@ -34,6 +34,27 @@ struct CgView4 {
 // graph it was not reliably ordered against the neighbouring kernels (see cg_zero in rowops.hip).
 int cg_zero_fill(void* p, long long bytes, hipStream_t stream);
 
+// Dynamic LDS above the default limit needs hipFuncAttributeMaxDynamicSharedMemorySize raised on the kernel.  That is a driver call:
+// it used to run in front of EVERY launch of the LDS-heavy kernels (invisible under graph replay, pure host overhead in eager
+// small-batch steps).  The limit a kernel has been given is remembered here (per translation unit: kernels are file-local), the driver
+// is called only when a launch needs more than was granted before.
+#include <mutex>
+static inline hipError_t cg_lds_limit(const void* fn, size_t bytes) {
+  struct Slot { const void* fn; size_t bytes; };
+  static Slot slots[64];
+  static int used = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int at = -1;
+  for (int i = 0; i < used; ++i) if (slots[i].fn == fn) { at = i; break; }
+  if (at >= 0 && slots[at].bytes >= bytes) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  if (at < 0 && used < 64) at = used++;
+  if (at >= 0) { slots[at].fn = fn; slots[at].bytes = bytes; }
+  return hipSuccess;
+}
+
 static inline int cg_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? CG_OK : (int)e;

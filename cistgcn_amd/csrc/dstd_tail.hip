@@ -809,7 +809,7 @@ extern "C" int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream_) {
     const int tps = (P + CG_TAIL_PT - 1) / CG_TAIL_PT, total = t->B * tps;
     const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
     const size_t lds = cg_tail_gemm_lds(t->C, false);
-    hipError_t e = hipFuncSetAttribute((const void*)cg_tail_f2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_tail_f2_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_tail_f2_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per);
   } else if (phase == 3) {
@@ -841,7 +841,7 @@ extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
     const int tps = (P + CG_TAIL_PT3 - 1) / CG_TAIL_PT3, total = t->B * tps;
     const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
     const size_t lds = cg_tail_gemm_lds(C, true);
-    hipError_t e = hipFuncSetAttribute((const void*)cg_tail_k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_tail_k3_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_tail_k3_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per, CG_TAIL_REPLICAS);
     st = cg_launch_status();

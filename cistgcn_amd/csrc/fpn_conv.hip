@@ -354,7 +354,7 @@ extern "C" int cg_fpn_conv_fwd(const CgFpnConv* t, void* stream_) {
   for (int i = 0; i < t->n; ++i) if (!t->w[i] || !t->y[i]) return CG_EARG;
   const size_t lds = cg_fpn_lds_fwd(t, a.g);
   if (lds > 160 * 1024) return CG_ESHAPE;
-  hipError_t e = hipFuncSetAttribute((const void*)cg_fpn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = cg_lds_limit((const void*)cg_fpn_fwd_kernel, lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(cg_fpn_fwd_kernel, dim3((unsigned)t->B, (unsigned)t->n), dim3(CG_FPN_THREADS), lds, (hipStream_t)stream_, a);
   return cg_launch_status();
@@ -371,7 +371,7 @@ extern "C" int cg_fpn_conv_bwd(const CgFpnConv* t, void* stream_) {
   if (t->dx) {
     const size_t lds = cg_fpn_lds_dx(t, a.g);
     if (lds > 160 * 1024) return CG_ESHAPE;
-    hipError_t e = hipFuncSetAttribute((const void*)cg_fpn_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_fpn_dx_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_fpn_dx_kernel, dim3((unsigned)t->B), dim3(CG_FPN_THREADS), lds, stream, a);
     st = cg_launch_status();
@@ -379,7 +379,7 @@ extern "C" int cg_fpn_conv_bwd(const CgFpnConv* t, void* stream_) {
   }
   const size_t lds = cg_fpn_lds_dw(t, a.g);
   if (lds > 160 * 1024) return CG_ESHAPE;
-  hipError_t e = hipFuncSetAttribute((const void*)cg_fpn_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = cg_lds_limit((const void*)cg_fpn_dw_kernel, lds);
   if (e != hipSuccess) return (int)e;
   const int nwg = (t->B + a.g.per - 1) / a.g.per;
   hipLaunchKernelGGL(cg_fpn_dw_kernel, dim3((unsigned)nwg, (unsigned)t->n), dim3(CG_FPN_THREADS), lds, stream, a);

@@ -134,7 +134,7 @@ extern "C" int cg_augment_sequences(const float* raw, const float* params, float
   const size_t lds = (size_t)L * J * 3 * sizeof(float);
   if (lds > 150 * 1024) return CG_ESHAPE;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)cg_augment_sequences_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_augment_sequences_kernel, lds);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(cg_augment_sequences_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream_, raw, params, sample, target,

@@ -771,11 +771,11 @@ extern "C" int cg_map2adj_tail_fwd(const CgAdjTail* items, int n, int phase, voi
   dim3 grid((unsigned)(items[0].B * pr.nch_max), (unsigned)n), block(CG_ADJ_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
   if (phase == 1) {
-    hipError_t e = hipFuncSetAttribute((const void*)cg_adj_m1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_adj_m1_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_adj_m1_kernel, grid, block, lds, stream, pr);
   } else if (phase == 2) {
-    hipError_t e = hipFuncSetAttribute((const void*)cg_adj_m2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_adj_m2_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_adj_m2_kernel, grid, block, lds, stream, pr);
   } else return CG_EARG;
@@ -798,11 +798,11 @@ extern "C" int cg_map2adj_tail_bwd(const CgAdjTail* items, int n, int phase, voi
   dim3 grid((unsigned)(items[0].B * pr.nch_max), (unsigned)n), block(CG_ADJ_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
   if (phase == 1) {
-    hipError_t e = hipFuncSetAttribute((const void*)cg_adj_n1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_adj_n1_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_adj_n1_kernel, grid, block, lds, stream, pr);
   } else if (phase == 2) {
-    hipError_t e = hipFuncSetAttribute((const void*)cg_adj_n2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit((const void*)cg_adj_n2_kernel, lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cg_adj_n2_kernel, grid, block, lds, stream, pr);
     st = cg_launch_status();

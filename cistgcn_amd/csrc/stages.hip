@@ -234,7 +234,7 @@ static size_t cg_dstd_lds(int C, int T) { return (size_t)(4 * C * T + 2 * C + 2 
 extern "C" int cg_dstd_stats_fwd(const float* x, float* out, int B, int C, int T, int V, void* stream_) {
   if (!x || !out) return CG_EARG;
   if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
-  if (hipFuncSetAttribute((const void*)cg_dstd_stats_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
+  if (cg_lds_limit((const void*)cg_dstd_stats_fwd_kernel, cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_dstd_stats_fwd_kernel, dim3(B), dim3(1024), cg_dstd_lds(C, T), (hipStream_t)stream_, x, out, C, T, V);
   return cg_launch_status();
 }
@@ -242,7 +242,7 @@ extern "C" int cg_dstd_stats_fwd(const float* x, float* out, int B, int C, int T
 extern "C" int cg_dstd_stats_bwd(const float* x, const float* dout, float* dx, int B, int C, int T, int V, void* stream_) {
   if (!x || !dout || !dx) return CG_EARG;
   if (B <= 0 || C < 2 || T <= 0 || V < 2 || cg_dstd_lds(C, T) > 160 * 1024) return CG_ESHAPE;
-  if (hipFuncSetAttribute((const void*)cg_dstd_stats_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
+  if (cg_lds_limit((const void*)cg_dstd_stats_bwd_kernel, cg_dstd_lds(C, T)) != hipSuccess) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_dstd_stats_bwd_kernel, dim3(B), dim3(1024), cg_dstd_lds(C, T), (hipStream_t)stream_, x, dout, dx, C, T, V);
   return cg_launch_status();
 }

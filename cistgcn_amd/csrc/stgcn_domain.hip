@@ -643,7 +643,7 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
     dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
     if (lds > 48 * 1024) {
       const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_mfma_kernel<0> : (const void*)cg_stgcn_domain_fwd_mfma_kernel<1>;
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = cg_lds_limit(fn, lds);
       if (e != hipSuccess) return (int)e;
     }
     if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_fwd_mfma_kernel<0>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
@@ -655,7 +655,7 @@ extern "C" int cg_stgcn_domain_fwd(const float* x, const float* adj, const float
   dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
   if (lds > 48 * 1024) {
     const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_kernel<0> : (const void*)cg_stgcn_domain_fwd_kernel<1>;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = cg_lds_limit(fn, lds);
     if (e != hipSuccess) return (int)e;
   }
   if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_fwd_kernel<0>, grid, block, lds, (hipStream_t)stream_, x, adj, W, bias, y, ystats, g);
@@ -719,7 +719,7 @@ extern "C" int cg_stgcn_domain_bwd(const float* x, const float* adj, const float
   dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(256);
   if (lds > 48 * 1024) {
     const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_bwd_kernel<0> : (const void*)cg_stgcn_domain_bwd_kernel<1>;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    e = cg_lds_limit(fn, lds);
     if (e != hipSuccess) return (int)e;
   }
   float* wsb = ws + n_w;   // non-null marker: bias partials live behind the weight partials of each replica

@@ -530,8 +530,8 @@ int cg_domm_bwd_launch(const float* x, const float* adj, const float* W, const f
   const int maxw = (tilesW + 3) / 4;
 #define CG_DOMM_LAUNCH(D, M)                                                                                              \
   do {                                                                                                                    \
-    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_domain_bwd_mfma_kernel<D, M>,                                \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                             \
+    hipError_t e = cg_lds_limit((const void*)cg_stgcn_domain_bwd_mfma_kernel<D, M>,                                \
+                                       lds);                             \
     if (e != hipSuccess) return (int)e;                                                                                   \
     hipLaunchKernelGGL((cg_stgcn_domain_bwd_mfma_kernel<D, M>), grid, block, lds, stream, x, adj, W, dy, dx, dadj, ws,    \
                        replicas, g);                                                                                      \
@@ -554,7 +554,7 @@ int cg_domm_fwd_launch(const float* x, const float* adj, const float* W, const f
   const long long nwg = ((long long)g.total + g.per - 1) / g.per;
   dim3 grid((unsigned)(((nwg + 7) / 8) * 8)), block(CG_DOMM_THREADS);
   const void* fn = domain == 0 ? (const void*)cg_stgcn_domain_fwd_mfma2_kernel<0> : (const void*)cg_stgcn_domain_fwd_mfma2_kernel<1>;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = cg_lds_limit(fn, lds);
   if (e != hipSuccess) return (int)e;
   if (domain == 0) hipLaunchKernelGGL(cg_stgcn_domain_fwd_mfma2_kernel<0>, grid, block, lds, stream, x, adj, W, bias, y, ystats, g);
   else hipLaunchKernelGGL(cg_stgcn_domain_fwd_mfma2_kernel<1>, grid, block, lds, stream, x, adj, W, bias, y, ystats, g);

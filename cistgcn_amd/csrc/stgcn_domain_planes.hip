@@ -775,8 +775,8 @@ int cg_domp_fwd_launch(const float* x, const float* adj, const float* W, const f
   dim3 grid((unsigned)(8 * ((B + 7) / 8) * g.NOC)), block(CG_DOMP_THREADS);
 #define CG_DOMP_FWD(D, VW_, VWB_, NL_)                                                                                              \
   if (domain == D && g.VW == VW_ && g.VWB == VWB_ && g.NL == NL_) {                                                               \
-    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_fwd_kernel<D, VW_, VWB_, NL_>,                                \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+    hipError_t e = cg_lds_limit((const void*)cg_stgcn_planes_fwd_kernel<D, VW_, VWB_, NL_>,                                \
+                                       lds);                                       \
     if (e != hipSuccess) return (int)e;                                                                                             \
     hipLaunchKernelGGL((cg_stgcn_planes_fwd_kernel<D, VW_, VWB_, NL_>), grid, block, lds, stream, x, adj, W, bias, y, ystats, g);   \
     return cg_launch_status();                                                                                                      \
@@ -1203,8 +1203,8 @@ int cg_domp_bwd_launch(const float* x, const float* adj, const float* W, const f
   const int ndxw = ((g.CinR / 16) * ((g.TC * V + 15) / 16) + CG_DOMPB_NW - 1) / CG_DOMPB_NW;      // dx tiles per wave
 #define CG_DOMP_BWD(VWP_, VWY_, VWA_, NJW_, PF_, NDX_)                                                                             \
   if (g.VWP == VWP_ && g.VWY == VWY_ && g.VWA == VWA_ && njw <= NJW_ && pfn <= PF_ && ndxw <= NDX_) {                             \
-    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_, NDX_>,                \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    hipError_t e = cg_lds_limit((const void*)cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_, NDX_>,                \
+                                       lds);                                      \
     if (e != hipSuccess) return (int)e;                                                                                            \
     hipLaunchKernelGGL((cg_stgcn_planes_bwd_kernel<VWP_, VWY_, VWA_, NJW_, PF_, NDX_>), grid, block, lds, stream, x, adj, W, dy,  \
                        dx, dadj, ws, replicas, g);                                                                                 \
@@ -1241,8 +1241,8 @@ int cg_domp_bwd_time_launch(const float* x, const float* adj, const float* W, co
   dim3 grid((unsigned)(8 * ((B + 7) / 8) * g.NTC)), block(CG_DOMPT_THREADS);
 #define CG_DOMP_BWDT(VWP_, VWA_)                                                                                                   \
   if (g.VWP == VWP_ && g.VWA == VWA_) {                                                                                            \
-    hipError_t e = hipFuncSetAttribute((const void*)cg_stgcn_planes_bwd_time_kernel<VWP_, VWA_>,                                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                      \
+    hipError_t e = cg_lds_limit((const void*)cg_stgcn_planes_bwd_time_kernel<VWP_, VWA_>,                                   \
+                                       lds);                                      \
     if (e != hipSuccess) return (int)e;                                                                                            \
     hipLaunchKernelGGL((cg_stgcn_planes_bwd_time_kernel<VWP_, VWA_>), grid, block, lds, stream, x, adj, W, dy, dx, dadj, ws,       \
                        replicas, g);                                                                                               \

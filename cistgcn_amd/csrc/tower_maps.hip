@@ -394,7 +394,7 @@ extern "C" int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream_) {
     if ((t->stats[i] != nullptr) != (t->stats[0] != nullptr)) return CG_EARG;
   }
   const size_t lds = ((size_t)a.g.CinM * a.g.PS + (size_t)a.g.MM * a.g.WS + 2 + (size_t)5 * a.g.MM) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)cg_pwm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = cg_lds_limit((const void*)cg_pwm_fwd_kernel, lds);
   if (e != hipSuccess) return (int)e;
   const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
   hipLaunchKernelGGL(cg_pwm_fwd_kernel, dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, (hipStream_t)stream_, a);
@@ -409,7 +409,7 @@ extern "C" int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream_) {
   if (!t->dx || !t->dW_ws) return CG_EARG;
   for (int i = 0; i < t->n; ++i) if (!t->dy[i] || !t->dW[i]) return CG_EARG;
   const size_t lds = ((size_t)(a.g.MM + a.g.CinM) * a.g.PS + (size_t)a.g.MM * a.g.WS) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)cg_pwm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = cg_lds_limit((const void*)cg_pwm_bwd_kernel, lds);
   if (e != hipSuccess) return (int)e;
   const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
   hipStream_t stream = (hipStream_t)stream_;
