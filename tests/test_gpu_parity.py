@@ -504,9 +504,10 @@ def _dp_gpu_worker_body(rank, world, port, q):
     eager_flat = step.flat.flat.clone()
     step.replay()
     torch.cuda.synchronize()
+    ora = ora.double()                      # fp64: the reference gradient of a shard does not depend on the host's summation order
     with BranchReplay(net, ora, trace):
-        po, = ora(x.clone())
-        O.mpjpe(po, tgt).backward()
+        po, = ora(x.clone().double())
+        O.mpjpe(po, tgt.double()).backward()
     q.put((rank, step.flat.flat.cpu().numpy(), eager_flat.cpu().numpy(), [p.grad.numpy().copy() for p in ora.parameters()],
            [int(o) for o in step.flat.offsets[:-1]], step.weight))
     dist.barrier()
@@ -543,10 +544,13 @@ def test_two_ranks_on_one_gpu_match_oracle_per_shard():
     for i, _ in enumerate(res[0][2]):
         ref = sum(shards[r] / tot * res[r][2][i] for r in range(2))
         got = res[0][0][offs[i]:offs[i] + ref.size].reshape(ref.shape)
-        # floor 1 (the north_star form, as in the train-mode single-GPU tests): batch statistics over 6 and 10 samples amplify the
-        # fp32 atomics order - the worst tensor sat at 0.7 .. 1.04 of a 0.1 floor and at 0.8 .. 1.03 of a 0.25 floor from run to run
-        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(1.0, float(np.abs(ref).max()))
+        # against the fp64 oracle per shard (round 3 compared with the fp32 CPU run and needed floor 1): floor 0.25 plus the relative bound
+        # of the single-GPU tests on every tensor with max|ref| >= 1e-4
+        mx = float(np.abs(ref).max())
+        err, bound = float(np.abs(got - ref).max()), 1e-4 * max(0.25, mx)
         assert err <= bound, "gradient %d: %.3e > %.3e" % (i, err, bound)
+        if mx >= 1e-4 and ref.size >= 16:
+            assert err <= REL_BOUND * mx + 3e-7, "gradient %d: %.3e > %.1e * max|ref| (%.3e)" % (i, err, REL_BOUND, mx)
 
 
 def test_first_bucket_allreduce_overlaps_second_phase():
@@ -633,18 +637,23 @@ def test_rccl_single_rank_allreduce_runs():
         dist.destroy_process_group()
 
 
-def test_every_kernel_of_a_step_is_ours():
+@pytest.mark.parametrize("cfg", [(8, 10, 22, 4), (64, 50, 22, 256)], ids=str)
+def test_every_kernel_of_a_step_is_ours(cfg):
     """One training step (forward + MPJPE + backward: the launches the HIP graph captures) under the profiler: every device
     kernel comes from libcistgcn_hip.so (names cg_*) - no stock aten / rocclr kernels, no device memcpy / memset.  (A graph
     replay shows up as one opaque event, so the same launches are traced eagerly; the flat gradient gather that follows the
-    graph is cg_multi_copy, its pointer table is uploaded once per capture.)"""
+    graph is cg_multi_copy, its pointer table is uploaded once per capture.)  At the small size the stacked / plane / whole-sample
+    kernel generations are off; the second case is BASELINE configs[2], the size the benchmark times (round 3's kernel statistics
+    of the bench COMMAND list aten add kernels and rocclr copies: they come from the benchmark's own probes around the step -
+    dp_overhead's flat-buffer set-up, the eval forward's input copy -, not from a step: this test is the proof)."""
     from torch.profiler import ProfilerActivity, profile
     from cistgcn_amd.runtime import EagerStep, FlatGrads
-    net, _ = checks.build_pair(8, 10, 22, "cuda")
+    C, T, V, B = cfg
+    net, _ = checks.build_pair(C, T, V, "cuda", dropout=0.1)
     net.train()
     g = torch.Generator().manual_seed(5)
-    x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
-    tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
+    x = (50 + 350 * torch.randn(B, T, V, 3, generator=g)).cuda()
+    tgt = (x[:, -1:].cpu() + 20 * torch.randn(B, 25, V, 3, generator=g)).cuda()
     step = EagerStep(net, x, tgt)
     for _ in range(2):
         step.replay()
