@@ -634,9 +634,22 @@ def check_model_golden(device, name, modes=("eval", "train"), fused=True, staged
             trace = net.act_trace
         finally:
             net.act_trace = None
-        assert_close(pred, rec[mode + "/pred"], "%s %s pred" % (name, mode))
-        assert_close(loss, rec[mode + "/loss"], "%s %s loss" % (name, mode))
-        assert_close(x.grad, rec[mode + "/dx"], "%s %s dL/dx" % (name, mode), floor=1e-1)
+        if mode == "train":
+            # train mode: batch statistics over the fixture's four samples; the reference's own fp32 run is 1e-5 .. 4e-4 * max|ref| away from its
+            # fp64 run of the same step (`train64/*`), so the comparison is with the fp64 truth and the reference's fp32 error is part of the bound
+            def near_truth(got, key, what, floor):
+                ref32, ref64 = np.asarray(rec["train/" + key], dtype=np.float64), np.asarray(rec["train64/" + key], dtype=np.float64)
+                noise = float(np.abs(ref32 - ref64).max())
+                err = float(np.abs(got.detach().cpu().double().numpy() - ref64).max())
+                bound = 1e-4 * max(floor, float(np.abs(ref64).max())) + 3.0 * noise
+                assert err <= bound, "%s train %s: err vs the reference's fp64 run %.3e > bound %.3e (reference fp32 error %.3e)" % (name, what, err, bound, noise)
+            near_truth(pred, "pred", "pred", 1.0)
+            near_truth(loss, "loss", "loss", 1.0)
+            near_truth(x.grad, "dx", "dL/dx", 1e-1)
+        else:
+            assert_close(pred, rec[mode + "/pred"], "%s %s pred" % (name, mode))
+            assert_close(loss, rec[mode + "/loss"], "%s %s loss" % (name, mode))
+            assert_close(x.grad, rec[mode + "/dx"], "%s %s dL/dx" % (name, mode), floor=1e-1)
         for k, ref in rec.items():
             if k.startswith(mode + "/attr/"):
                 got = _attr(net, k[len(mode + "/attr/"):]).detach()
