@@ -95,7 +95,8 @@ FAM_ROWS = "row kernels (cg_norm_act_fwd/bwd, cg_chan_stats)"
 FAM_PWM = "stacked tower maps (cg_pointwise_maps_fwd/bwd)"
 FAM_ROWSCONV = "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)"
 FAM_FPN = "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)"
-FAM_STATS = "block statistics (cg_dstd_stats_fwd/bwd)"
+FAM_STATS = "block input: global_norm + statistics (cg_block_input_fwd/bwd, cg_dstd_stats_fwd/bwd)"
+FAM_CTX = "ContextLayer heads (cg_context_heads_fwd/bwd)"
 FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as rocprofv3 --kernel-trace reports them
     FAM_STGCN: ("cg_stgcn_", "cg_dom_fold"),
     FAM_TAIL: ("cg_tail_",),
@@ -105,9 +106,10 @@ FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as roc
     FAM_PWM: ("cg_pwm_",),
     FAM_ROWSCONV: ("cg_rows_",),
     FAM_FPN: ("cg_fpn_",),
-    FAM_STATS: ("cg_dstd_stats",),
+    FAM_STATS: ("cg_bin_", "cg_dstd_stats"),
+    FAM_CTX: ("cg_ctx_",),
 }
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")      # HBM bytes per family from rocprofv3 PMC passes (tools/collect_profiles_r03.py)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")      # HBM bytes per family / per block from rocprofv3 PMC passes (tools/collect_profiles_r04.py)
 
 
 def _numel(v):
@@ -175,6 +177,16 @@ def _call_bytes(name, args):
     if name in ("cg_dstd_stats_fwd", "cg_dstd_stats_bwd"):
         B, C, T, V = args[-5:-1]
         return FAM_STATS, 4 * B * C * T * V * (1 if name.endswith("fwd") else 3)
+    if name in ("cg_block_input_fwd", "cg_block_input_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.BlockInput)).contents
+        n = 4 * t.B * t.C * t.T * t.V
+        # forward: x -> xn; backward: the consumers' gradients and x -> dx (the stored sum G travels twice more: not algorithmic)
+        return FAM_STATS, 2 * n if name.endswith("fwd") else (sum(1 for i in range(t.ng) if t.g[i]) + 2) * n
+    if name in ("cg_context_heads_fwd", "cg_context_heads_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.CtxHeads)).contents
+        return FAM_CTX, 4 * t.B * (t.P + 4 * t.C) * (1 if name.endswith("fwd") else 2)
     return "other (%s)" % name, 0
 
 
@@ -619,17 +631,29 @@ def main():
             del net
             torch.cuda.synchronize()
             blk = block_roofline(C, B, T, V, device, args.dropout)
-            out["roofline"] = {"bound": "hbm", "achieved": f["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": f["frac"],
-                               "traffic": (f["traffic_per_step"] / max(1, f["launches"])) if f["traffic_per_step"] else None, "family": dom, "kernel": ", ".join(f["kernels"]),
-                               "launches_per_step": f["launches"], "avg_us": f["us"] / max(1, f["launches"]), "us_per_step": f["us"],
-                               "algorithmic_bytes_per_launch_avg": f["algorithmic_bytes"] / max(1, f["launches"]),
-                               "how": "largest family by summed time of one eager step (forward + backward entry points of a stage "
-                                      "form ONE family, for every stage); HIP events around every C-ABI call on the launch stream; "
-                                      "algorithmic bytes = each operand / result of each call once",
-                               # SURVEY 8(d)'s unit: bytes of ONE DSTD_GC invocation (read x, write out, both adjacency maps, gates;
-                               # backward: x, dOut, maps, dx) over the time of ALL kernels of the block
-                               "vs_8d": {"block": blk["block"], "algorithmic_bytes": blk["algorithmic_bytes_fwd"] + blk["algorithmic_bytes_bwd"],
-                                         "us": blk["fwd_us"] + blk["bwd_us"], "achieved": blk["achieved"], "frac": blk["frac"]},
+            blk_traffic = None
+            if os.path.exists(TRAFFIC_FILE):
+                blk_traffic = (json.load(open(TRAFFIC_FILE)).get(args.workload, {}).get("_block") or {}).get("bytes")
+            # `roofline` is SURVEY 8(d)'s quantity (round-3 review): the unit is ONE DSTD_GC invocation (64 -> 64 on (T, V): three of the six
+            # blocks and the bulk of the step), its algorithmic bytes (read x, write out, both adjacency maps, the gates; backward: x, dOut,
+            # the maps, dx - times the batch) over the summed duration of ALL its kernels, forward + backward, HIP events on the launch stream.
+            # `traffic`: HBM bytes of one such invocation from the PMC passes over tools/prof_block.py (profiles/r04_traffic.json).
+            out["roofline"] = {"bound": "hbm", "achieved": blk["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": blk["frac"],
+                               "traffic": blk_traffic,
+                               "kernel": "every kernel of one DSTD_GC block invocation, forward + backward (cg_bin_*, cg_pwm_*, cg_rows_*, cg_contract*, "
+                                         "cg_norm_act_*, cg_adj_*, cg_stgcn_*, cg_tail_*, cg_se_gate_*)",
+                               "unit_of_work": blk["block"],
+                               "algorithmic_bytes_per_launch": blk["algorithmic_bytes_fwd"] + blk["algorithmic_bytes_bwd"],
+                               "avg_us": blk["fwd_us"] + blk["bwd_us"], "fwd_us": blk["fwd_us"], "bwd_us": blk["bwd_us"],
+                               "traffic_over_algorithmic": (blk_traffic / (blk["algorithmic_bytes_fwd"] + blk["algorithmic_bytes_bwd"])) if blk_traffic else None,
+                               "f32_mfma_frac_fwd": blk["f32_frac_fwd"],
+                               "how": "SURVEY 8(d) bytes of one block invocation x batch / summed time of all its kernels (eager launches, HIP events); "
+                                      "the whole step by the same rule is `step_roofline`",
+                               # the largest kernel family of the step on its OWN operand bytes (every operand / result of each call once): how well
+                               # the kernels stream what they are given, not a SURVEY 8(d) figure
+                               "dominant_family": {"family": dom, "kernel": ", ".join(f["kernels"]), "achieved": f["GBps"], "frac_of_peak_on_operand_bytes": f["frac"],
+                                                   "launches_per_step": f["launches"], "avg_us": f["us"] / max(1, f["launches"]), "us_per_step": f["us"],
+                                                   "traffic_per_launch": (f["traffic_per_step"] / max(1, f["launches"])) if f["traffic_per_step"] else None},
                                "per_family": fams}
             out["block_roofline"] = blk
         else:

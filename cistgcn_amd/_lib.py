@@ -108,7 +108,9 @@ class PwMaps(ctypes.Structure):
     _fields_ = [("B", c_int), ("Cin", c_int), ("P", c_int), ("n", c_int), ("x", c_void_p),
                 ("W", c_void_p * 4), ("M", c_int * 4), ("y", c_void_p * 4), ("stats", c_void_p * 4),
                 ("dy", c_void_p * 4), ("dx", c_void_p), ("dW", c_void_p * 4), ("dW_ws", c_void_p),
-                ("bias", c_void_p * 4), ("db", c_void_p * 4)]
+                ("bias", c_void_p * 4), ("db", c_void_p * 4),
+                ("yraw", c_void_p * 4), ("bn_save", c_void_p * 4), ("bn_gamma", c_void_p * 4), ("bn_beta", c_void_p * 4),
+                ("bn_red", c_void_p * 4), ("prelu", c_void_p * 4), ("bn_train", c_int), ("pad", c_int)]
 
 
 class FpnConv(ctypes.Structure):
@@ -148,6 +150,7 @@ _SIGNATURES = {
     "cg_chan_stats_many": [POINTER(StatsArgs), c_int, P],
     "cg_norm_act_fwd_many": [POINTER(NormAct), c_int, P],
     "cg_norm_act_bwd_many": [POINTER(NormAct), POINTER(c_int), c_int, P],
+    "cg_norm_act_bwd_reduce_many": [POINTER(NormAct), c_int, P],
     "cg_copy_many": [POINTER(CopyItem), c_int, P],
     "cg_chan_sum": [P, POINTER(View4), P, P],
     "cg_norm_act_fwd": [POINTER(NormAct), P],

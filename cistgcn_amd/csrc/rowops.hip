@@ -547,6 +547,41 @@ extern "C" int cg_norm_act_bwd_many(const CgNormAct* arr, const int* need_reduce
   return cg_norm_act_launch(arr, nullptr, n, 2, (hipStream_t)stream_);
 }
 
+// per-channel parameter gradients from `red` alone (the apply pass writes them otherwise)
+__global__ void cg_norm_act_params_kernel(CgNormActBatch batch) {
+  const CgNormAct& a = batch.a[blockIdx.x];
+  const long long C = a.xv.n[1];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (a.bn_mode != 0) {
+      if (a.dgamma) a.dgamma[c] = (float)a.red[2 * c + 1];
+      if (a.dbeta) a.dbeta[c] = (float)a.red[2 * c];
+    }
+    if (a.alpha && a.dalpha) {
+      if (a.alpha_n == 1) { if (c == 0) a.dalpha[0] = (float)cg_alpha_sum(a.red + 2 * C); }
+      else a.dalpha[c] = (float)a.red[2 * C + c];
+    }
+  }
+}
+
+// include/cistgcn_hip.h : cg_norm_act_bwd_reduce_many - pass 1 of the backward only (sums of g and g * xhat, slope gradient) plus the
+// parameter gradients; for a consumer that applies the BatchNorm / PReLU backward itself while it loads the gradient
+// (cg_pointwise_maps_bwd with `yraw`).  dx / dadd / dpre are not written.
+extern "C" int cg_norm_act_bwd_reduce_many(const CgNormAct* arr, int n, void* stream_) {
+  if (!arr || n <= 0 || n > CG_ROW_MAX_BATCH) return CG_EARG;
+  for (int i = 0; i < n; ++i) {
+    int st = cg_norm_act_check(&arr[i], false);
+    if (st != CG_OK) return st;
+    if (!arr[i].dy || !arr[i].red) return CG_EARG;
+  }
+  int st = cg_norm_act_launch(arr, nullptr, n, 1, (hipStream_t)stream_);
+  if (st != CG_OK) return st;
+  CgNormActBatch batch;
+  batch.n = n; batch.pad = 0;
+  for (int i = 0; i < n; ++i) { batch.a[i] = arr[i]; batch.rb[i] = 1; batch.vec[i] = 0; }
+  hipLaunchKernelGGL(cg_norm_act_params_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
+}
+
 extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) { return cg_norm_act_fwd_many(a, 1, stream_); }
 
 extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream_) {

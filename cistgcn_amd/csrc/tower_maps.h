@@ -20,4 +20,11 @@ struct CgPwMaps {
   float* dW_ws;                     // cg_pointwise_maps_ws_floats(Cin) zeroed floats (replicated accumulators)
   const float* bias[CG_PWM_MAXN];   // optional (M_i): y_i += bias_i (the residual convolutions, CISTGCN.py:246-254, :357-365)
   float* db[CG_PWM_MAXN];           // backward, optional (M_i): sum over (b, p) of dy_i
+  // backward, optional (all maps or none): the maps are followed by BatchNorm2d + PReLU (the Map2Adj towers, CISTGCN.py:138-141) and dy_i is
+  // the gradient BEHIND them.  The kernel undoes both while it loads dy_i: it needs the raw map outputs, the BatchNorm's saved mean / rstd
+  // ([2][M_i]), gamma, beta, the reduced sums `red` of cg_norm_act_bwd_reduce_many ([M_i][2] f64: sum g, sum g xhat) and the slope.
+  const float* yraw[CG_PWM_MAXN];
+  const float* bn_save[CG_PWM_MAXN]; const float* bn_gamma[CG_PWM_MAXN]; const float* bn_beta[CG_PWM_MAXN];
+  const double* bn_red[CG_PWM_MAXN]; const float* prelu[CG_PWM_MAXN];
+  int bn_train, pad;                // 1: batch statistics (the sums enter dy), 0: running statistics
 };

@@ -204,16 +204,33 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   float xbuf[16], dbuf[16];
   // Row pointers of the four staging slots, resolved once: looking the map of a stacked row up in the kernel arguments (three
   // dependent loads indexed by a lane value) per tile kept the prefetch ISSUE at 9 k cycles of a 24 k-cycle tile (tools/stamps_pwm.py)
-  const float* xrow[4]; const float* drow[4];
+  const float* xrow[4]; const float* drow[4]; const float* yrow[4];
   long long dstr[4];
+  // BatchNorm + PReLU behind the maps (optional, see CgPwMaps.yraw): constants of the four staging rows of this thread
+  const bool undo = t.yraw[0] != nullptr;
+  float k_mean[4], k_rstd[4], k_scale[4], k_beta[4], k_m1[4], k_m2[4], k_alpha[4];
+  float ybuf[16];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = ((int)threadIdx.x + CG_PWM_THREADS * r) >> g.lgq;
     xrow[r] = row < t.Cin ? t.x + (long long)row * t.P : nullptr;
-    drow[r] = nullptr; dstr[r] = 0;
+    drow[r] = nullptr; yrow[r] = nullptr; dstr[r] = 0;
+    k_mean[r] = 0.f; k_rstd[r] = 0.f; k_scale[r] = 0.f; k_beta[r] = 0.f; k_m1[r] = 0.f; k_m2[r] = 0.f; k_alpha[r] = 1.f;
     if (row < g.MM) {
       const int tile = row >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (row & 15);
-      if (m < t.M[i]) { drow[r] = t.dy[i] + (long long)m * t.P; dstr[r] = (long long)t.M[i] * t.P; }
+      if (m < t.M[i]) {
+        drow[r] = t.dy[i] + (long long)m * t.P; dstr[r] = (long long)t.M[i] * t.P;
+        if (undo) {
+          yrow[r] = t.yraw[i] + (long long)m * t.P;
+          k_mean[r] = t.bn_save[i][m]; k_rstd[r] = t.bn_save[i][t.M[i] + m];
+          k_scale[r] = t.bn_gamma[i][m] * k_rstd[r]; k_beta[r] = t.bn_beta[i][m];
+          k_alpha[r] = t.prelu[i][0];
+          if (t.bn_train) {
+            const double cnt = (double)t.B * (double)t.P;
+            k_m1[r] = (float)(t.bn_red[i][2 * m] / cnt); k_m2[r] = (float)(t.bn_red[i][2 * m + 1] / cnt);
+          }
+        }
+      }
     }
   }
   auto fetch = [&](int lid) {
@@ -223,6 +240,23 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
     for (int r = 0; r < 4; ++r) { xo[r] = (long long)b * t.Cin * t.P + p0; doff[r] = (long long)b * dstr[r] + p0; }
     cg_pwm_fetch_rows(g, np, xbuf, xrow, xo);
     cg_pwm_fetch_rows(g, np, dbuf, drow, doff);
+    if (undo) cg_pwm_fetch_rows(g, np, ybuf, yrow, doff);
+  };
+  // gradient in front of the BatchNorm from the one behind the PReLU (cg_norm_act's backward, applied to the staged values; zeros of the
+  // padding stay zeros only where dy AND the sums' terms vanish: rows / positions outside the tensor are masked by their null row pointer)
+  auto undo_rows = [&](int np) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << g.lgq) - 1));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = ybuf[4 * r + j] - k_mean[r];
+        const float u = d * k_scale[r] + k_beta[r];
+        const float gu = u > 0.f ? dbuf[4 * r + j] : k_alpha[r] * dbuf[4 * r + j];
+        const float v = k_scale[r] * (gu - k_m1[r] - d * k_rstd[r] * k_m2[r]);
+        dbuf[4 * r + j] = (yrow[r] != nullptr && pp + j < np) ? v : 0.f;
+      }
+    }
   };
   fetch(lid0);
   cg_pwm_weights(a, sW);
@@ -237,6 +271,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
     __syncthreads();
     CG_PSTAMP();
+    if (undo) undo_rows(np);
     cg_pwm_commit(g, g.MM, dbuf, sD);                              // rows of the padding and positions beyond the tensor arrive as zeros
     cg_pwm_commit(g, t.Cin, xbuf, sX);
     __syncthreads();
@@ -407,7 +442,11 @@ extern "C" int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream_) {
   if (st != CG_OK) return st;
   a.t = *t;
   if (!t->dx || !t->dW_ws) return CG_EARG;
-  for (int i = 0; i < t->n; ++i) if (!t->dy[i] || !t->dW[i]) return CG_EARG;
+  for (int i = 0; i < t->n; ++i) {
+    if (!t->dy[i] || !t->dW[i]) return CG_EARG;
+    if ((t->yraw[i] != nullptr) != (t->yraw[0] != nullptr)) return CG_EARG;
+    if (t->yraw[i] && (!t->bn_save[i] || !t->bn_gamma[i] || !t->bn_beta[i] || !t->prelu[i] || (t->bn_train && !t->bn_red[i]))) return CG_EARG;
+  }
   const size_t lds = ((size_t)(a.g.MM + a.g.CinM) * a.g.PS + (size_t)a.g.MM * a.g.WS) * sizeof(float);
   hipError_t e = cg_lds_limit((const void*)cg_pwm_bwd_kernel, lds);
   if (e != hipSuccess) return (int)e;

@@ -235,6 +235,7 @@ class CISTGCN(nn.Module):
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
         self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
         self.fused_input = __import__("os").environ.get("CISTGCN_FUSED_INPUT", "1") != "0"   # global_norm + block statistics (and their backward with the fan-in sum) as one operator
+        self.fused_towers = __import__("os").environ.get("CISTGCN_FUSED_TOWERS", "1") != "0"   # first tower level + BatchNorm + PReLU as one operator (backward without the BatchNorm input gradient)
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
         self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
@@ -486,8 +487,20 @@ class CISTGCN(nn.Module):
         if gates:
             yg = gate_rows if gate_rows is not None else o.pop(0)[0]
             o = [(g.unsqueeze(2), None) for g in ops.split_channels(yg, (O, O))] + o
+        towers_done = None
         if stacked:
-            o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
+            tb = [b for a in maps for b in (a.time_compress[1], a.joint_compress[1])]
+            tp = [b for a in maps for b in (a.time_compress[2], a.joint_compress[2])]
+            if self.fused_towers and ops.tower_maps_ok(x_maps, tower_w, tp):
+                # first level of the four towers with its BatchNorm + PReLU as one operator: backward never stores the gradient in front of
+                # the BatchNorm (the pointwise backward undoes BatchNorm and PReLU while loading)
+                towers_done = ops.tower_maps(x_maps, tower_w, tb, tp, tr)
+                if self.act_trace is not None:
+                    for mod, h in zip(tp, towers_done):
+                        self.act_trace[mod] = (h.detach(), None)
+                o = o[:2] + [None] * 4 + o[2:]
+            else:
+                o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
         if res_groups:
             ro = [None] * len(res_convs)
             for xg, grp in zip(x_resmaps, res_groups):
@@ -497,16 +510,22 @@ class CISTGCN(nn.Module):
         gs, gt, tc = o[0], o[1], o[2:6]
         # 2. their BatchNorm / PReLU tails
         calls = [dict(x=gs, bn=m.conv_s[1], drop=True, prelu=m.conv_s[3]), dict(x=gt, bn=m.conv_t[1], drop=True, prelu=m.conv_t[3])]
-        for i, a in enumerate(maps):
-            calls += [dict(x=tc[2 * i], bn=a.time_compress[1], prelu=a.time_compress[2]),
-                      dict(x=tc[2 * i + 1], bn=a.joint_compress[1], prelu=a.joint_compress[2])]
+        if towers_done is None:
+            for i, a in enumerate(maps):
+                calls += [dict(x=tc[2 * i], bn=a.time_compress[1], prelu=a.time_compress[2]),
+                          dict(x=tc[2 * i + 1], bn=a.joint_compress[1], prelu=a.joint_compress[2])]
         k = 6
         if has_res:
             calls += [dict(x=o[k + i], bn=d.residual[1]) for i, d in enumerate(doms)]
             k += 2
         if has_bres:
             calls.append(dict(x=o[k], bn=m.residual[1]))
-        r = self._na_many(calls)
+        if towers_done is None:
+            r = self._na_many(calls)
+        else:                        # site numbers as on the row-kernel path: gates, four (dropout-free) tower sites, residual maps
+            r = self._na_many(calls[:2])
+            self._site += 4
+            r = r + towers_done + (self._na_many(calls[2:]) if len(calls) > 2 else [])
         gs, gt, t1 = r[0], r[1], r[2:6]
         res = r[6:8] if has_res else x_res
         bres = r[-1] if has_bres else x_bres

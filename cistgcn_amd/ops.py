@@ -1962,6 +1962,100 @@ def pointwise_maps(x, weights, want_stats=False, biases=None):
     return [(out[i], out[n + i] if want_stats else None) for i in range(n)]
 
 
+class _TowerMaps(torch.autograd.Function):
+    """h_i = PReLU(BN(W_i x)) for up to four 1x1 maps of one input followed by BatchNorm2d + PReLU: the first level of the Map2Adj
+    towers of a block (CISTGCN.py:138-141 / :156-158 applied by :183-186).  Forward = cg_pointwise_maps_fwd + cg_norm_act_fwd_many, as
+    the two operators do; backward: ONE reduction pass over (dh_i, y_i) and the pointwise backward undoing BatchNorm and PReLU while
+    it loads dh_i - the gradient in front of the BatchNorm is never stored (as two operators: reduce + apply passes of cg_norm_act_bwd,
+    432 MB written and read again per block at B = 256).  Tensor inputs: x | W_1..n | gamma_1..n | beta_1..n | alpha_1..n."""
+
+    @staticmethod
+    def forward(ctx, cfg, n, x, *ts):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        B, C, H, W = x.shape
+        dev, f32, train = x.device, torch.float32, bool(cfg["train"])
+        ws = [w if w.is_contiguous() else _copy(w) for w in ts[:n]]
+        gammas, betas, alphas = ts[n:2 * n], ts[2 * n:3 * n], ts[3 * n:4 * n]
+        t = _PointwiseMaps._block(x, ws, [None] * n)
+        ys = [torch.empty(B, w.shape[0], H, W, dtype=f32, device=dev) for w in ws]
+        stats = [_arena(dev).take(2 * w.shape[0] * _lib.STAT_REPLICAS) for w in ws] if train else [None] * n
+        for i in range(n):
+            t.y[i], t.stats[i] = ys[i].data_ptr(), _ptr(stats[i])
+        stream = _stream(x)
+        _lib.call("cg_pointwise_maps_fwd", ctypes.byref(t), stream)
+        arr = (NormAct * n)()
+        hs, saves, pending = [], [], []
+        for i in range(n):
+            h, save, _, _ = _na_fill_fwd(arr[i], ys[i], None, None, gammas[i], betas[i], alphas[i],
+                                         {"bn": cfg["bn"][i], "train": train, "stats": stats[i]}, pending)
+            hs.append(h); saves.append(save)
+        assert not pending
+        _lib.call("cg_norm_act_fwd_many", arr, n, stream)
+        ctx.cfg, ctx.n = cfg, n
+        ctx.save_for_backward(x, *ws, *gammas, *betas, *alphas, *ys, *saves)
+        return tuple(hs)
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        n, cfg = ctx.n, ctx.cfg
+        sv = ctx.saved_tensors
+        x, ws, gammas, betas, alphas, ys, saves = sv[0], sv[1:1 + n], sv[1 + n:1 + 2 * n], sv[1 + 2 * n:1 + 3 * n], sv[1 + 3 * n:1 + 4 * n], sv[1 + 4 * n:1 + 5 * n], sv[1 + 5 * n:1 + 6 * n]
+        if any(d is None for d in dhs):
+            raise RuntimeError("tower_maps: every map needs a gradient")
+        dhs = [d if d.is_contiguous() else _copy(d) for d in dhs]
+        dev, f32, train = x.device, torch.float32, bool(cfg["train"])
+        stream = _stream(x)
+        # pass 1: channel sums of the gradient in front of the BatchNorm, slope gradients, dgamma / dbeta
+        arr = (NormAct * n)()
+        reds, smalls = [], []
+        for i in range(n):
+            a, bn = arr[i], cfg["bn"][i]
+            M = ws[i].shape[0]
+            a.x, a.xv, a.dy, a.dyv = ys[i].data_ptr(), _view4(ys[i]), dhs[i].data_ptr(), _view4(dhs[i])
+            a.bn_mode = 1 if train else 2
+            a.gamma, a.beta = gammas[i].data_ptr(), betas[i].data_ptr()
+            a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            a.momentum, a.eps = bn.momentum, bn.eps
+            a.save_mean, a.save_rstd = saves[i][0].data_ptr(), saves[i][1].data_ptr()
+            a.alpha, a.alpha_n = alphas[i].data_ptr(), alphas[i].numel()
+            red = _arena(dev).take(2 * M + (_lib.ALPHA_SLOTS if alphas[i].numel() == 1 else alphas[i].numel()))
+            small = torch.empty(3, M, dtype=f32, device=dev)
+            a.red, a.dgamma, a.dbeta, a.dalpha = red.data_ptr(), small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
+            reds.append(red); smalls.append(small)
+        _lib.call("cg_norm_act_bwd_reduce_many", arr, n, stream)
+        # pass 2: dx and dW_i with BatchNorm / PReLU undone on load
+        t = _PointwiseMaps._block(x, ws, [None] * n)
+        dx = torch.empty_like(x)
+        dws = [torch.empty_like(w) for w in ws]
+        zb, _ = _zeros(int(_lib.lib().cg_pointwise_maps_ws_floats(x.shape[1])), dev)
+        for i in range(n):
+            t.dy[i], t.dW[i] = dhs[i].data_ptr(), dws[i].data_ptr()
+            t.yraw[i], t.bn_save[i], t.bn_gamma[i], t.bn_beta[i] = ys[i].data_ptr(), saves[i].data_ptr(), gammas[i].data_ptr(), betas[i].data_ptr()
+            t.bn_red[i], t.prelu[i] = reds[i].data_ptr(), alphas[i].data_ptr()
+        t.bn_train = 1 if train else 0
+        t.dx, t.dW_ws = dx.data_ptr(), zb.data_ptr()
+        _lib.call("cg_pointwise_maps_bwd", ctypes.byref(t), stream)
+        del dhs
+        need = ctx.needs_input_grad
+        grads = [dx if need[2] else None] + [dws[i] if need[3 + i] else None for i in range(n)]
+        grads += [smalls[i][0] if need[3 + n + i] else None for i in range(n)]
+        grads += [smalls[i][1] if need[3 + 2 * n + i] else None for i in range(n)]
+        grads += [smalls[i][2, :1].reshape(alphas[i].shape) if need[3 + 3 * n + i] else None for i in range(n)]
+        return (None, None) + tuple(grads)
+
+
+def tower_maps_ok(x, weights, prelus):
+    return pointwise_maps_ok(x, weights) and all(p.weight.numel() == 1 for p in prelus)
+
+
+def tower_maps(x, weights, bns, prelus, train):
+    """[h_i] = PReLU(BN(W_i x)) for the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W) with their BatchNorm2d / PReLU holders."""
+    n = len(weights)
+    cfg = {"train": bool(train), "bn": tuple(bns)}
+    return list(_TowerMaps.apply(cfg, n, x, *weights, *[b.weight for b in bns], *[b.bias for b in bns], *[p.weight for p in prelus]))
+
+
 class _SplitChannels(torch.autograd.Function):
     """Inverse of `cat_channels`: channel ranges of one tensor as views (no copy); backward gathers the pieces' gradients."""
 

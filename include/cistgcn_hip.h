@@ -123,6 +123,9 @@ int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream);
 /* the same for up to 6 independent row problems per launch (branches of one block at the same depth) */
 int cg_norm_act_fwd_many(const CgNormAct* arr, int n, void* stream);
 int cg_norm_act_bwd_many(const CgNormAct* arr, const int* need_reduce, int n, void* stream);
+/* pass 1 of the backward alone (channel sums, slope gradient) + dgamma / dbeta / dalpha: for a consumer that applies the BatchNorm / PReLU
+ * backward itself while loading the gradient (cg_pointwise_maps_bwd with yraw) */
+int cg_norm_act_bwd_reduce_many(const CgNormAct* arr, int n, void* stream);
 
 /* per-(b,c) mean (kind 0), max with first arg-max (kind 1) or sum (kind 2) over the positions; adjoints of 0/1.
  * Replaces AdaptiveAvgPool (SE.py:8,27; CISTGCN.py:69,76), .max(-1)[0] chains and .mean((2,3))
@@ -288,6 +291,13 @@ typedef struct CgPwMaps {
   float* dW_ws;                                          /* cg_pointwise_maps_ws_floats(Cin) zeroed floats */
   const float* bias[CG_PWM_MAXN];                        /* optional (M_i): y_i = W_i x + bias_i (nn.Conv2d(..., 1) with bias: the residual maps) */
   float* db[CG_PWM_MAXN];                                /* backward, optional (M_i): bias gradient, sum of dy_i over batch and positions */
+  /* backward, optional (all maps or none): BatchNorm2d + PReLU follow the maps (the Map2Adj towers, CISTGCN.py:138-141) and dy_i is the
+   * gradient BEHIND them; the kernel undoes both while it loads dy_i (raw outputs yraw, saved mean / rstd [2][M_i], gamma, beta, the sums
+   * `bn_red` [M_i][2] f64 of cg_norm_act_bwd_reduce_many, the slope) */
+  const float* yraw[CG_PWM_MAXN];
+  const float* bn_save[CG_PWM_MAXN]; const float* bn_gamma[CG_PWM_MAXN]; const float* bn_beta[CG_PWM_MAXN];
+  const double* bn_red[CG_PWM_MAXN]; const float* prelu[CG_PWM_MAXN];
+  int bn_train, pad;
 } CgPwMaps;
 int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream);
 int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream);

@@ -994,6 +994,49 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6), (2, 4
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
+def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14), (3, 64, (32, 32, 32, 32), 5, 12))):
+    """ops.tower_maps (pointwise maps + BatchNorm2d + PReLU as one operator; backward: cg_norm_act_bwd_reduce_many + cg_pointwise_maps_bwd
+    undoing BatchNorm / PReLU on load) against stock PyTorch in fp64: outputs, dx, every dW / dgamma / dbeta / dalpha, running statistics,
+    train and eval mode.  shapes: (B, Cin, (M_i), T, V)."""
+    g = _gen(83)
+    for (B, C, Ms, T, V) in shapes:
+        for train in (True, False):
+            def make(dt):
+                gg = _gen(500 + C)
+                mods = []
+                for k, M in enumerate(Ms):
+                    conv, bn, pr = nn.Conv2d(C, M, 1, bias=False), nn.BatchNorm2d(M), nn.PReLU()
+                    with torch.no_grad():
+                        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gg) * 0.4)
+                        bn.weight.copy_(1 + 0.3 * torch.randn(M, generator=gg)); bn.bias.copy_(0.3 * torch.randn(M, generator=gg))
+                        bn.running_mean.copy_(0.2 * torch.randn(M, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(M, generator=gg))
+                        pr.weight.fill_(0.1 + 0.1 * k)
+                    mods.append(nn.Sequential(conv, bn, pr))
+                return nn.ModuleList(mods).to(dt)
+            x0 = 0.3 + _rand(g, B, C, T, V)
+            gs = [_rand(g, B, M, T, V) for M in Ms]
+            what = "tower_maps B%d C%d M%s T%d V%d %s" % (B, C, Ms, T, V, "train" if train else "eval")
+            ref = make(torch.float64).train(train)
+            xr = _leaf(x0.double(), "cpu")
+            hr = [m(xr) for m in ref]
+            torch.autograd.backward(hr, [t.double() for t in gs])
+            net = make(torch.float32).to(device).train(train)
+            xd = _leaf(x0, device)
+            ops.begin_step(device)
+            hd = ops.tower_maps(xd, [m[0].weight.view(m[0].out_channels, C) for m in net], [m[1] for m in net], [m[2] for m in net], train)
+            torch.autograd.backward(hd, [t.to(device) for t in gs])
+            for a, b in zip(hd, hr):
+                assert_close(a, b, what + " output", rel=2e-5)
+            assert_close(xd.grad, xr.grad, what + " dx", rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
+            for (k, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
+                floor = max(1e-3, float(pb.grad.abs().max()))
+                if train and k.endswith("0.weight"):           # in front of a train-mode BatchNorm: the remainder of cancelling sums
+                    floor = max(floor, float(ref[int(k.split(".")[0])][1].weight.grad.abs().max()))
+                assert_close(pa.grad, pb.grad, "%s grad %s" % (what, k), rel=5e-5, floor=floor)
+            for (k, ba), (_, bb) in zip(net.named_buffers(), ref.named_buffers()):
+                assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, k), rel=1e-5)
+
+
 def check_block_input(device, shapes=((3, 5, 4, 6, 3), (2, 10, 10, 22, 7), (4, 64, 5, 22, 8), (2, 6, 5, 5, 2), (3, 3, 22, 25, 4))):
     """ops.block_input (csrc/block_input.hip) against stock PyTorch BatchNorm2d + the oracle's block statistics (CISTGCN.py:360-379):
     the aliases of xn, the statistics, running statistics; backward with a different gradient on every alias and on both statistics

@@ -15,7 +15,7 @@ def _emulated_kernels():
 
 @pytest.mark.parametrize("check", [checks.check_contract, checks.check_norm_act, checks.check_batched_ops, checks.check_dropout,
                                    checks.check_reduce_and_gate, checks.check_copies, checks.check_dilated_convs,
-                                   checks.check_stage_kernels, checks.check_flat_adam, checks.check_zero_pool, checks.check_contract_kred, checks.check_contract_stream, checks.check_rank1_adj, checks.check_eval_harness, checks.check_contract_chain, checks.check_dstd_tail, checks.check_map2adj_tail, checks.check_pointwise_maps, checks.check_collapse_rows, checks.check_context_heads, checks.check_block_input], ids=lambda f: f.__name__)
+                                   checks.check_stage_kernels, checks.check_flat_adam, checks.check_zero_pool, checks.check_contract_kred, checks.check_contract_stream, checks.check_rank1_adj, checks.check_eval_harness, checks.check_contract_chain, checks.check_dstd_tail, checks.check_map2adj_tail, checks.check_pointwise_maps, checks.check_collapse_rows, checks.check_context_heads, checks.check_block_input, checks.check_tower_maps], ids=lambda f: f.__name__)
 def test_operator(check):
     if check in (checks.check_contract, checks.check_norm_act, checks.check_contract_kred):
         check("cpu", quick=True)
@@ -27,6 +27,8 @@ def test_operator(check):
         check("cpu", shapes=((2, 5, 4, 10, 7), (3, 6, 5, 4, 6), (2, 20, 10, 6, 6)))
     elif check is checks.check_pointwise_maps:
         check("cpu", shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 33), 6, 6), (2, 10, (20, 16), 4, 6), (2, 32, (10, 10, 10), 3, 4), (2, 1, (20, 20), 5, 6), (2, 12, (16, 5), 3, 14), (2, 100, (25,), 3, 4)))
+    elif check is checks.check_tower_maps:
+        check("cpu", shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14)))
     elif check is checks.check_map2adj_tail:
         check("cpu", shapes=((3, 7, 9), (2, 6, 17), (2, 40, 6)))      # 40 slabs: the 33..48 range takes the 64-row tile
     else:
