@@ -290,15 +290,19 @@ def test_cpu_tensors_are_refused():
         ops.feature_lift(torch.zeros(2, 10, 22, 3))
 
 
-def test_graph_replay_matches_eager(branches=False):
-    """fwd+loss+bwd captured in a HIP graph replays to the same numbers (bench.py's step)."""
+@pytest.mark.parametrize("branches,cfg", [(False, (8, 10, 22, 4)), (True, (8, 10, 22, 4)), (True, (64, 50, 22, 64))], ids=str)
+def test_graph_replay_matches_eager(branches, cfg):
+    """fwd+loss+bwd captured in a HIP graph replays to the same numbers (bench.py's step); `branches`: the independent branches of a
+    block (gate paths, towers, the two domain stages; context layer beside the output block) captured on forked streams - the form
+    bench.py times at N = 1 -, also at a size where the stacked / plane / whole-sample kernels run."""
     from cistgcn_amd import ops
     from cistgcn_amd.runtime import GraphedStep
-    net, _ = checks.build_pair(8, 10, 22, "cuda")
+    C, T, V, B = cfg
+    net, _ = checks.build_pair(C, T, V, "cuda")
     net.train()
     g = torch.Generator().manual_seed(5)
-    x = (50 + 350 * torch.randn(4, 10, 22, 3, generator=g)).cuda()
-    tgt = (x[:, -1:].cpu() + 20 * torch.randn(4, 25, 22, 3, generator=g)).cuda()
+    x = (50 + 350 * torch.randn(B, T, V, 3, generator=g)).cuda()
+    tgt = (x[:, -1:].cpu() + 20 * torch.randn(B, 25, V, 3, generator=g)).cuda()
     net.dropout = 0.0
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     step = GraphedStep(net, x, tgt, warmup=2, branches=branches, tries=2)     # two captures, the faster one kept: its own grad buffers
