@@ -290,7 +290,7 @@ def test_cpu_tensors_are_refused():
         ops.feature_lift(torch.zeros(2, 10, 22, 3))
 
 
-@pytest.mark.parametrize("branches,cfg", [(False, (8, 10, 22, 4)), (True, (8, 10, 22, 4)), (True, (64, 50, 22, 64))], ids=str)
+@pytest.mark.parametrize("branches,cfg", [(False, (8, 10, 22, 4)), (True, (8, 10, 22, 4)), (False, (64, 50, 22, 64)), (True, (64, 50, 22, 64))], ids=str)
 def test_graph_replay_matches_eager(branches, cfg):
     """fwd+loss+bwd captured in a HIP graph replays to the same numbers (bench.py's step); `branches`: the independent branches of a
     block (gate paths, towers, the two domain stages; context layer beside the output block) captured on forked streams - the form
@@ -317,8 +317,20 @@ def test_graph_replay_matches_eager(branches, cfg):
     loss = ops.mpjpe(pred, tgt)
     loss.backward()
     assert abs(loss.item() - loss_g) <= 1e-5 * max(1.0, abs(loss.item()))
-    for a, p in zip(grads_g, net.parameters()):
-        assert torch.allclose(a, p.grad, rtol=1e-3, atol=max(1e-5, 1e-4 * float(p.grad.abs().max())))   # atomics reorder sums
+    if B <= 8:
+        for a, p in zip(grads_g, net.parameters()):
+            assert torch.allclose(a, p.grad, rtol=1e-3, atol=max(1e-5, 1e-4 * float(p.grad.abs().max())))   # atomics reorder sums
+        return
+    # 1e8 PReLU elements: the two fp32 runs (other atomics order) land a handful of rounding-sized pre-activations on different sides of 0 and
+    # each such element moves the gradients behind it by a finite step (no branch replay between two GPU runs): the criterion of the
+    # full-size dropout identity test - max|a-b| <= 1e-3 max(1, |g|) and relative L2 distance <= 2e-2 per tensor; a race between the forked
+    # streams would show as tens of per cent
+    for (k, p), a in zip(net.named_parameters(), grads_g):
+        a, r = a.double().cpu(), p.grad.double().cpu()
+        mx = float(r.abs().max())
+        assert float((a - r).abs().max()) <= 1e-3 * max(1.0, mx), k
+        if mx >= 1e-4 and r.numel() >= 64:
+            assert float((a - r).norm() / r.norm().clamp_min(1e-30)) <= 2e-2, "%s: relative L2 %.3e" % (k, float((a - r).norm() / r.norm()))
 
 
 def test_graph_replay_survives_allocator_churn():
