@@ -2,11 +2,8 @@
 // Map2Adj.time_compress, :138-150): y[b,o,v] = sum_{c,t} W[o,c,t] x[b,c,t,v].  Per sample this is Y_b (O x V) = W (O x K) X_b (K x V)
 // with K = C*T and X_b = x[b] as it lies in memory; the tensors are 36-72 MB, the outputs a few hundred KB.  The generic
 // contraction needed split-K with atomics and strided gathers for it (0.3 TB/s); here
-//   forward   512-thread workgroups, `ksplit` of them per sample (each takes a contiguous range of K): eight waves split the range,
-//             feed the matrix cores straight from global memory (W rows as float4 along k, x rows as 16-lane pieces along v),
-//             partial tiles are added in LDS; with ksplit > 1 the workgroups write partial outputs and a fold kernel adds them in a
-//             fixed order (deterministic) and forms the channel sums.  One workgroup per sample left two waves per SIMD, each waiting
-//             out an HBM round trip per 16 rows of x: 77 us for 72 MB at B = 256 (round 4: K split over four workgroups)
+//   forward   one 512-thread workgroup per sample: eight waves split K, feed the matrix cores straight from global memory
+//             (W rows as float4 along k, x rows as 16-lane pieces along v), partial tiles are added in LDS
 //   backward  a workgroup owns 64 rows k of W for a slice of the samples: dx[b,k,v] = sum_o W[o,k] dy[b,o,v] is written as one
 //             contiguous 64 x V piece per sample, dW[o,k] += sum_v dy[b,o,v] x[b,k,v] stays in registers over the slice
 #include "cg_common.h"
@@ -20,7 +17,7 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 #define CG_ROWS_KB 64            // rows of W per backward workgroup
 #define CG_ROWS_REPLICAS 8
 
-struct CgRowsGeom { int K, OT, slices, per, kranges, ksplit; };
+struct CgRowsGeom { int K, OT, slices, per, kranges; };
 struct CgRowsArgs { CgRowsConv t; CgRowsGeom g; };
 
 // ======================================================================================================================
@@ -39,11 +36,10 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
   for (int i = 0; i < 4; ++i) { acc[i][0] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
   // groups of 16 consecutive k: lane (l15, slot) takes k = k0 + 4 slot + s in MFMA step s (both operands agree, a sum does not
   // care about the order)
-  const int ngroups = (K + 15) >> 4, gper = (ngroups + g.ksplit - 1) / g.ksplit;
-  const int g0 = (int)blockIdx.y * gper, g1 = min(ngroups, g0 + gper);
+  const int ngroups = (K + 15) >> 4;
   const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
 #pragma unroll 4
-  for (int gi = g0 + wave; gi < g1; gi += nw) {
+  for (int gi = wave; gi < ngroups; gi += nw) {
     const int k = 16 * gi + 4 * slot;
     float4 wv[4];
     float x0[4], x1[4];
@@ -82,11 +78,6 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
     }
   }
   __syncthreads();
-  if (g.ksplit > 1) {                                  // partial output of this K range: [ksplit][B][O][V]
-    float* part = t.ws + ((long long)blockIdx.y * t.B + b) * t.O * V;
-    for (int e = tid; e < t.O * V; e += CG_ROWS_FWD_THREADS) { const int o = e / V, v = e - o * V; part[e] = sY[o * 33 + v]; }
-    return;
-  }
   for (int e = tid; e < t.O * V; e += CG_ROWS_FWD_THREADS) {
     const int o = e / V, v = e - o * V;
     t.y[(long long)b * t.O * V + e] = sY[o * 33 + v];
@@ -98,27 +89,6 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
       double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * t.O + o) * 2;
       atomicAdd(&rep[0], s1); atomicAdd(&rep[1], s2);
     }
-  }
-}
-
-// y[b] = sum over the K ranges of the partial outputs (fixed order), channel sums as above; one workgroup per sample
-__global__ void cg_rows_fwd_fold_kernel(CgRowsArgs a) {
-  const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
-  const int b = blockIdx.x, n = t.O * t.V;
-  float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [O * V]
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < g.ksplit; ++r) s += t.ws[((long long)r * t.B + b) * n + e];
-    t.y[(long long)b * n + e] = s;
-    sY[e] = s;
-  }
-  if (!t.stats) return;
-  __syncthreads();
-  for (int o = threadIdx.x; o < t.O; o += blockDim.x) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int v = 0; v < t.V; ++v) { const double y = (double)sY[o * t.V + v]; s1 += y; s2 += y * y; }
-    double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * t.O + o) * 2;
-    atomicAdd(&rep[0], s1); atomicAdd(&rep[1], s2);
   }
 }
 
@@ -240,25 +210,16 @@ static int cg_rows_geometry(const CgRowsConv* t, CgRowsGeom* g) {
   if (K > (1 << 20) || (K & 3)) return CG_ESHAPE;
   g->K = (int)K; g->OT = (t->O + 15) / 16;
   g->kranges = (g->K + CG_ROWS_KB - 1) / CG_ROWS_KB;
-  int slices = 768 / g->kranges;                        // ~768 backward workgroups
+  // backward workgroups: as many as fit the LDS of the chip at once (35 KB each at 64 outputs: four per CU), at most 1536 (every workgroup ends
+  // with 64 x 16 OT atomics into the replicated dW buffer)
+  const int lds_kb = (16 * g->OT * (CG_ROWS_KB + 4) + 2 * 16 * g->OT * 36) * 4 / 1024 + 1;
+  int target = 256 * (160 / lds_kb);
+  target = target > 1536 ? 1536 : (target < 768 ? 768 : target);
+  int slices = target / g->kranges;
   slices = slices < 1 ? 1 : (slices > t->B ? t->B : slices);
   g->per = (t->B + slices - 1) / slices;
   g->slices = (t->B + g->per - 1) / g->per;
-  // forward: ~1024 workgroups (four per CU) as long as a wave keeps a few groups of 16 rows
-  int ks = (1024 + t->B - 1) / t->B;
-  const int ngroups = (g->K + 15) >> 4;
-  while (ks > 1 && ngroups / ks < 8) --ks;
-  g->ksplit = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
   return CG_OK;
-}
-
-// floats of the forward's partial-output scratch `ws` (0: one workgroup per sample writes y itself)
-extern "C" long long cg_collapse_rows_fwd_ws_floats(int B, int C, int T, int V, int O) {
-  CgRowsConv t;
-  t.B = B; t.C = C; t.T = T; t.V = V; t.O = O; t.x = reinterpret_cast<const float*>(1); t.W = t.x;
-  CgRowsGeom g;
-  if (cg_rows_geometry(&t, &g) != CG_OK || g.ksplit <= 1) return 0;
-  return (long long)g.ksplit * B * O * V;
 }
 
 extern "C" long long cg_collapse_rows_ws_floats(int C, int T, int O) { return (long long)CG_ROWS_REPLICAS * O * C * T; }
@@ -269,14 +230,9 @@ extern "C" int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream_) {
   int st = cg_rows_geometry(t, &a.g);
   if (st != CG_OK) return st;
   if (!t->y) return CG_EARG;
-  if (a.g.ksplit > 1 && !t->ws) a.g.ksplit = 1;        // no scratch handed over: one workgroup per sample
   a.t = *t;
   const size_t lds = (size_t)16 * a.g.OT * 33 * sizeof(float);
-  hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3((unsigned)t->B, (unsigned)a.g.ksplit), dim3(CG_ROWS_FWD_THREADS), lds, stream, a);
-  st = cg_launch_status();
-  if (st != CG_OK || a.g.ksplit == 1) return st;
-  hipLaunchKernelGGL(cg_rows_fwd_fold_kernel, dim3((unsigned)t->B), dim3(256), (size_t)t->O * t->V * sizeof(float), stream, a);
+  hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3((unsigned)t->B), dim3(CG_ROWS_FWD_THREADS), lds, (hipStream_t)stream_, a);
   return cg_launch_status();
 }
 

@@ -2126,11 +2126,7 @@ class _CollapseRows(torch.autograd.Function):
         y = torch.empty(B, O, V, dtype=torch.float32, device=x.device)
         stats = _arena(x.device).take(2 * O * _lib.STAT_REPLICAS) if want_stats else None
         t.y, t.stats = y.data_ptr(), _ptr(stats)
-        nws = int(_lib.lib().cg_collapse_rows_fwd_ws_floats(B, C, T, V, O))
-        part = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None      # partial outputs of the K ranges
-        t.ws = _ptr(part)
         _lib.call("cg_collapse_rows_fwd", ctypes.byref(t), _stream(x))
-        del part
         ctx.save_for_backward(x, w)
         if stats is not None:
             ctx.mark_non_differentiable(stats)

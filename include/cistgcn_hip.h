@@ -252,9 +252,6 @@ typedef struct CgRowsConv {
 int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream);
 int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream);
 long long cg_collapse_rows_ws_floats(int C, int T, int O);
-/* forward: optional scratch `ws` of this many floats (no zeroing needed): K is then split over several workgroups per sample (partial outputs,
- * added in a fixed order by a fold launch); 0 or ws == NULL: one workgroup per sample */
-long long cg_collapse_rows_fwd_ws_floats(int B, int C, int T, int V, int O);
 
 /* ---- dilated 3x3 convolutions of the time extrapolator, FPN CISTGCN.py:54-79: n <= 3 convolutions with padding = dilation =
  * dil[i] of ONE input (B,C,H,W) = (batch, frames, channels, joints).  A sample fits in LDS with its halo: forward, input gradient
