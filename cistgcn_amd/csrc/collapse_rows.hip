@@ -210,12 +210,7 @@ static int cg_rows_geometry(const CgRowsConv* t, CgRowsGeom* g) {
   if (K > (1 << 20) || (K & 3)) return CG_ESHAPE;
   g->K = (int)K; g->OT = (t->O + 15) / 16;
   g->kranges = (g->K + CG_ROWS_KB - 1) / CG_ROWS_KB;
-  // backward workgroups: as many as fit the LDS of the chip at once (35 KB each at 64 outputs: four per CU), at most 1536 (every workgroup ends
-  // with 64 x 16 OT atomics into the replicated dW buffer)
-  const int lds_kb = (16 * g->OT * (CG_ROWS_KB + 4) + 2 * 16 * g->OT * 36) * 4 / 1024 + 1;
-  int target = 256 * (160 / lds_kb);
-  target = target > 1536 ? 1536 : (target < 768 ? 768 : target);
-  int slices = target / g->kranges;
+  int slices = 768 / g->kranges;                        // ~768 backward workgroups (1024-1536: 53 us against 46 us on the tower tensors, round 4)
   slices = slices < 1 ? 1 : (slices > t->B ? t->B : slices);
   g->per = (t->B + slices - 1) / slices;
   g->slices = (t->B + g->per - 1) / g->per;
