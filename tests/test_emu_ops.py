@@ -30,7 +30,7 @@ def test_operator(check):
     elif check is checks.check_tower_maps:
         check("cpu", shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14)))
     elif check is checks.check_map2adj_tail:
-        check("cpu", shapes=((3, 7, 9), (2, 6, 17), (2, 40, 6)))      # 40 slabs: the 33..48 range takes the 64-row tile
+        check("cpu", shapes=((2, 6, 17), (2, 40, 6)))      # slab counts 6 / 17 / 40: the 16-, 32- and 64-row tiles; 40: the 33..48 range takes the 64-row tile
     else:
         check("cpu")
 
