@@ -132,6 +132,20 @@ class BlockInput(ctypes.Structure):
                 ("dx", c_void_p), ("dgamma", c_void_p), ("dbeta", c_void_p)]
 
 
+class GatePath(ctypes.Structure):
+    _fields_ = [("z", c_void_p), ("stats", c_void_p), ("stats_ld", c_longlong),
+                ("bn2", TailBN), ("alpha2", c_void_p), ("Wl", c_void_p), ("bn3", TailBN), ("alpha3", c_void_p), ("W2", c_void_p),
+                ("salt2", c_uint), ("salt3", c_uint), ("y", c_void_p), ("w", c_void_p), ("tap2", c_void_p), ("tap3", c_void_p),
+                ("dw", c_void_p), ("dz", c_void_p), ("dstats", c_void_p), ("dWl", c_void_p), ("dW2", c_void_p),
+                ("dgamma2", c_void_p), ("dbeta2", c_void_p), ("dalpha2", c_void_p), ("dgamma3", c_void_p), ("dbeta3", c_void_p), ("dalpha3", c_void_p),
+                ("scratch", c_void_p)]
+
+
+class GateHead(ctypes.Structure):
+    _fields_ = [("B", c_int), ("C", c_int), ("S", c_int), ("train", c_int), ("n", c_int), ("pad", c_int),
+                ("drop_p", c_float), ("pad2", c_int), ("seed", c_void_p), ("p", GatePath * 2)]
+
+
 class CtxHeads(ctypes.Structure):
     _fields_ = [("B", c_int), ("P", c_int), ("C", c_int), ("train", c_int), ("x", c_void_p), ("xstats", c_void_p),
                 ("w", c_void_p * 2), ("bn", TailBN * 2), ("alpha", c_void_p * 2),
@@ -196,6 +210,10 @@ _SIGNATURES = {
     "cg_block_input_fwd": [POINTER(BlockInput), P],
     "cg_block_input_bwd": [POINTER(BlockInput), P],
     "cg_block_input_supported": [c_int, c_int, c_int, c_int],
+    "cg_gate_head_fwd": [POINTER(GateHead), P],
+    "cg_gate_head_bwd": [POINTER(GateHead), P],
+    "cg_gate_head_supported": [c_int, c_int, c_int],
+    "cg_gate_head_scratch_floats": [c_int, c_int, c_int],
     "cg_context_heads_fwd": [POINTER(CtxHeads), P],
     "cg_context_heads_bwd": [POINTER(CtxHeads), P],
     "cg_context_heads_red_doubles": [c_int],

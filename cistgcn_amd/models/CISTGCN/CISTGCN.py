@@ -236,6 +236,7 @@ class CISTGCN(nn.Module):
         self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
         self.fused_input = __import__("os").environ.get("CISTGCN_FUSED_INPUT", "1") != "0"   # global_norm + block statistics (and their backward with the fan-in sum) as one operator
         self.fused_towers = __import__("os").environ.get("CISTGCN_FUSED_TOWERS", "1") != "0"   # first tower level + BatchNorm + PReLU as one operator (backward without the BatchNorm input gradient)
+        self.fused_gates = __import__("os").environ.get("CISTGCN_FUSED_GATES", "1") != "0"    # the gate paths behind their (1,V) convolutions as one launch
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
         self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
@@ -549,18 +550,43 @@ class CISTGCN(nn.Module):
                 o.append(rows3[i] if i in rows3 else rest.pop(0))
                 o.append(rest.pop(0))
         # 4. BatchNorm tails
-        calls = [dict(x=o[0], bn=m.conv_s[5], drop=True, prelu=m.conv_s[7]), dict(x=o[1], bn=m.conv_t[5], drop=True, prelu=m.conv_t[7])]
+        Cg = m.conv_s[4].out_channels
+        gate_fused = (self.fused_gates and o[0][0].shape[1] == Cg and o[0][0].numel() == B * Cg and
+                      ops.gate_head_ok(B, Cg, stats_s.shape[1], (m.conv_s[7], m.conv_t[7], m.map_s[3], m.map_t[3])))
+        tower_calls = []
         for i, a in enumerate(maps):
-            calls += [dict(x=o[2 + 2 * i], bn=a.time_compress[4], drop=True), dict(x=o[3 + 2 * i], bn=a.joint_compress[4], drop=True)]
-        r = self._na_many(calls)
-        hs = ops.cat_channels([r[0].view(B, -1), stats_s])
-        ht = ops.cat_channels([r[1].view(B, -1), stats_t])
+            tower_calls += [dict(x=o[2 + 2 * i], bn=a.time_compress[4], drop=True), dict(x=o[3 + 2 * i], bn=a.joint_compress[4], drop=True)]
+        if gate_fused:
+            # everything of the two gate paths behind their (1,V) convolutions in ONE launch (csrc/gate_head.hip); the site ids are the ones
+            # the row-kernel chain numbers: conv_s.5 / conv_t.5 in front of the four tower sites, map_s.1 / map_t.1 behind them
+            s2 = (self._site + 1, self._site + 2)
+            self._site += 2
+            r = [None, None] + self._na_many(tower_calls)
+            s3 = (self._site + 1, self._site + 2)
+            self._site += 2
+            if self.drop_trace is not None:
+                self.drop_trace[m.conv_s[5]], self.drop_trace[m.conv_t[5]], self.drop_trace[m.map_s[1]], self.drop_trace[m.map_t[1]] = s2[0], s2[1], s3[0], s3[1]
+            taps = [] if self.act_trace is not None else None
+            m.w1, m.w2 = ops.gate_head([o[0][0].view(B, Cg), o[1][0].view(B, Cg)], [stats_s, stats_t], [m.conv_s, m.conv_t], [m.map_s, m.map_t], tr,
+                                       drop_p=self.dropout, salts=((s2[0], s3[0]), (s2[1], s3[1])), taps=taps)
+            if taps is not None:
+                self.act_trace[m.conv_s[7]], self.act_trace[m.map_s[3]] = (taps[0], None), (taps[1], None)
+                self.act_trace[m.conv_t[7]], self.act_trace[m.map_t[3]] = (taps[2], None), (taps[3], None)
+            items, g = [], None
+        else:
+            calls = [dict(x=o[0], bn=m.conv_s[5], drop=True, prelu=m.conv_s[7]), dict(x=o[1], bn=m.conv_t[5], drop=True, prelu=m.conv_t[7])]
+            r = self._na_many(calls + tower_calls)
+            hs = ops.cat_channels([r[0].view(B, -1), stats_s])
+            ht = ops.cat_channels([r[1].view(B, -1), stats_t])
+            items = [_lin_item(hs, m.map_s[0], tr), _lin_item(ht, m.map_t[0], tr)]
         # 5. gate Linear + last tower maps
-        items = [_lin_item(hs, m.map_s[0], tr), _lin_item(ht, m.map_t[0], tr)]
         for i, a in enumerate(maps):
             items += [_pw_item(r[2 + 2 * i], a.time_compress[6], False), _pw_item(r[3 + 2 * i], a.joint_compress[6], False)]
         o = _run_items(items)
-        g = self._na_many([dict(x=o[0], bn=m.map_s[1], drop=True, prelu=m.map_s[3]), dict(x=o[1], bn=m.map_t[1], drop=True, prelu=m.map_t[3])])
+        if gate_fused:
+            o = [None, None] + o
+        else:
+            g = self._na_many([dict(x=o[0], bn=m.map_s[1], drop=True, prelu=m.map_s[3]), dict(x=o[1], bn=m.map_t[1], drop=True, prelu=m.map_t[3])])
         # 6. rank-1 products  o[b,v,t,tau] = s[b,v,t] q[b,tau,v]  |  o[b,t,v,w] = s[b,v,t] q[b,t,w]
         seeds = []
         for i, d in enumerate(doms):
@@ -568,8 +594,9 @@ class CISTGCN(nn.Module):
             seeds.append((0 if d.domain == "space" else 1, s, q))
         if self.fused_adj and T <= 64 and V <= 64:
             # seed, expansor and adjacency of both towers in two phase launches (csrc/map2adj_tail.hip); the seed is never stored
-            o = _run_items([_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)])
-            m.w1, m.w2 = o[0][0], o[1][0]
+            if not gate_fused:
+                o = _run_items([_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)])
+                m.w1, m.w2 = o[0][0], o[1][0]
             self._site += 2
             if self.drop_trace is not None:
                 self.drop_trace[maps[0].expansor[1]], self.drop_trace[maps[1].expansor[1]] = self._site - 1, self._site
@@ -586,10 +613,13 @@ class CISTGCN(nn.Module):
                 oo = [y for y, _ in ops.contract_many([("bvt,bxv->bvtx" if dom == 0 else "bvt,btw->btvw", s, q, None, None, None)
                                                        for dom, s, q in seeds])]
             # 7. gate output Linear + expansor first map
-            items = [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
+            items = [] if gate_fused else [_lin_item(g[0], m.map_s[4], False), _lin_item(g[1], m.map_t[4], False)]
             items += [_pw_item(oo[i], a.expansor[0], tr) for i, a in enumerate(maps)]
             o = _run_items(items)
-            m.w1, m.w2 = o[0][0], o[1][0]
+            if gate_fused:
+                o = [None, None] + o
+            else:
+                m.w1, m.w2 = o[0][0], o[1][0]
             e = self._na_many([dict(x=o[2 + i], bn=a.expansor[1], drop=True, prelu=a.expansor[3]) for i, a in enumerate(maps)])
             adj = _run_items([_pw_item(e[i], a.expansor[4], False) for i, a in enumerate(maps)])
         # 8. graph product + channel mix, then BN + residual + PReLU

@@ -1790,6 +1790,110 @@ def block_input(x, bn, train, n, stats=None):
     return list(out[:n]), (out[n], out[n + 1])
 
 
+def gate_head_ok(B, C, S, prelus):
+    return bool(_lib.lib().cg_gate_head_supported(B, C, S)) and all(p.weight.numel() == 1 for p in prelus)
+
+
+class _GateHead(torch.autograd.Function):
+    """Tail of the gate paths of a DSTD_GC block, CISTGCN.py:337-352 / :378-384 (csrc/gate_head.hip): per path
+    z (B,C) -> BatchNorm -> Dropout -> PReLU -> cat(block statistics) -> Linear -> BatchNorm1d -> Dropout -> PReLU -> Linear = w (B,C).
+    Tensor inputs: per path z, stats, gamma2, beta2, alpha2, Wl, gamma3, beta3, alpha3, W2 (10 each)."""
+
+    @staticmethod
+    def _block(cfg, ts, n, train, saves, ys, dev):
+        B, C = ts[0].shape
+        S = ts[1].shape[1]
+        t = _lib.GateHead()
+        t.B, t.C, t.S, t.train, t.n = B, C, S, 1 if train else 0, n
+        p = float(cfg.get("drop_p", 0.0)) if train else 0.0
+        t.drop_p = p
+        if p > 0.0:
+            t.seed = seed_state(dev).data_ptr()
+        for i in range(n):
+            z, stats, g2, b2, a2, wl, g3, b3, a3, w2 = ts[10 * i:10 * i + 10]
+            q = t.p[i]
+            q.z, q.stats, q.stats_ld = z.data_ptr(), stats.data_ptr(), stats.stride(0)
+            _tail_bn(q.bn2, cfg["bn2"][i], None, saves[i][0], train)
+            _tail_bn(q.bn3, cfg["bn3"][i], None, saves[i][1], train)
+            q.alpha2, q.Wl, q.alpha3, q.W2 = a2.data_ptr(), wl.data_ptr(), a3.data_ptr(), w2.data_ptr()
+            q.salt2, q.salt3 = cfg["salts"][i]
+            q.y = ys[i].data_ptr()
+        return t, p
+
+    @staticmethod
+    def forward(ctx, cfg, n, *ts):
+        ctx.set_materialize_grads(False)
+        dev, f32, train = ts[0].device, torch.float32, bool(cfg["train"])
+        B, C = ts[0].shape
+        for i in range(n):
+            z, stats = ts[10 * i], ts[10 * i + 1]
+            _chk(z), _chk(stats)
+            if not z.is_contiguous() or stats.stride(1) != 1 or not ts[10 * i + 5].is_contiguous() or not ts[10 * i + 9].is_contiguous():
+                raise ValueError("gate_head expects contiguous z / weights and unit-stride statistics rows")
+            if train and B < 2:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(z.shape),))
+        saves = [torch.empty(2, 2, C, dtype=f32, device=dev) for _ in range(n)]
+        ys = [torch.empty(B, C, dtype=f32, device=dev) for _ in range(n)]
+        ws = [torch.empty(B, C, dtype=f32, device=dev) for _ in range(n)]
+        t, p = _GateHead._block(cfg, ts, n, train, saves, ys, dev)
+        taps = cfg.get("taps")
+        for i in range(n):
+            t.p[i].w = ws[i].data_ptr()
+            if taps is not None:
+                taps += [torch.empty(B, C, dtype=f32, device=dev), torch.empty(B, C, dtype=f32, device=dev)]
+                t.p[i].tap2, t.p[i].tap3 = taps[-2].data_ptr(), taps[-1].data_ptr()
+        _lib.call("cg_gate_head_fwd", ctypes.byref(t), _stream(ts[0]))
+        ctx.cfg, ctx.n, ctx.p = cfg, n, p
+        ctx.seed_epoch = seed_epoch(dev) if p > 0.0 else None
+        ctx.save_for_backward(*ts, *ys, *saves)
+        return tuple(ws)
+
+    @staticmethod
+    def backward(ctx, *dws):
+        n, cfg = ctx.n, ctx.cfg
+        sv = ctx.saved_tensors
+        ts, ys, saves = sv[:10 * n], sv[10 * n:11 * n], sv[11 * n:12 * n]
+        dev, f32, train = ts[0].device, torch.float32, bool(cfg["train"])
+        _check_seed_epoch(ctx, dev, "gate_head")
+        B, C = ts[0].shape
+        S = ts[1].shape[1]
+        t, _ = _GateHead._block(cfg, ts, n, train, saves, ys, dev)
+        keep, grads = [], []
+        nscr = int(_lib.lib().cg_gate_head_scratch_floats(B, C, S))
+        for i in range(n):
+            d = dws[i]
+            if d is None:
+                d = _zeros(B * C, dev)[0].view(B, C)
+            d = d if d.is_contiguous() else _copy(d)
+            dz = torch.empty(B, C, dtype=f32, device=dev)
+            dst = torch.empty(B, S, dtype=f32, device=dev)
+            dwl, dw2 = torch.empty(C, C + S, dtype=f32, device=dev), torch.empty(C, C, dtype=f32, device=dev)
+            small = torch.empty(6, C, dtype=f32, device=dev)
+            scr = torch.empty(nscr, dtype=f32, device=dev)
+            q = t.p[i]
+            q.dw, q.dz, q.dstats, q.dWl, q.dW2, q.scratch = d.data_ptr(), dz.data_ptr(), dst.data_ptr(), dwl.data_ptr(), dw2.data_ptr(), scr.data_ptr()
+            q.dgamma2, q.dbeta2, q.dalpha2, q.dgamma3, q.dbeta3, q.dalpha3 = (small[k].data_ptr() for k in range(6))
+            keep += [d, scr]
+            grads += [dz.view(ts[10 * i].shape), dst, small[0], small[1], small[2, :1].reshape(1), dwl.view(ts[10 * i + 5].shape),
+                      small[3], small[4], small[5, :1].reshape(1), dw2.view(ts[10 * i + 9].shape)]
+        _lib.call("cg_gate_head_bwd", ctypes.byref(t), _stream(ts[0]))
+        del keep
+        return (None, None) + tuple(g if ctx.needs_input_grad[2 + k] else None for k, g in enumerate(grads))
+
+
+def gate_head(zs, stats, convs, maps, train, drop_p=0.0, salts=((0, 0), (0, 0)), taps=None):
+    """Gates w_i (B,C) of a block's gate paths from z_i (B,C) = output of conv_i[4] and stats_i (B,S): `convs[i]` / `maps[i]` are the
+    reference's conv_s|t (slots 5: BatchNorm2d, 7: PReLU used) and map_s|t (0: Linear, 1: BatchNorm1d, 3: PReLU, 4: Linear) holders;
+    salts[i] = the site ids of the two Dropout layers of path i.  One launch for all paths, forward and backward."""
+    n = len(zs)
+    cfg = {"train": bool(train), "drop_p": float(drop_p), "salts": tuple((int(a), int(b)) for a, b in salts),
+           "bn2": tuple(c[5] for c in convs), "bn3": tuple(m[1] for m in maps), "taps": taps}
+    ts = []
+    for z, st, c, m in zip(zs, stats, convs, maps):
+        ts += [z, st, c[5].weight, c[5].bias, c[7].weight, m[0].weight, m[1].weight, m[1].bias, m[3].weight, m[4].weight]
+    return list(_GateHead.apply(cfg, n, *ts))
+
+
 def context_heads_ok(x, hidden):
     """True when `context_heads` takes the two one-channel heads of x (B,1,H,W)."""
     return x.dim() == 4 and x.shape[1] == 1 and x.is_contiguous() and hidden <= 64 and x.shape[2] * x.shape[3] <= 16384

@@ -355,6 +355,40 @@ int cg_block_input_fwd(const CgBlockInput* t, void* stream);
 int cg_block_input_bwd(const CgBlockInput* t, void* stream);
 int cg_block_input_supported(int B, int C, int T, int V);
 
+/* ---- tail of the gate paths of a DSTD_GC block, conv_s / conv_t slots 5-7 and map_s / map_t, CISTGCN.py:337-352 / :378-384 ------
+ * per path: z (B,C) -> BatchNorm2d -> Dropout -> PReLU -> cat with the block statistics (B,S) -> Linear (C, C+S) -> BatchNorm1d -> Dropout ->
+ * PReLU -> Linear (C,C) = the gate (B,C).  One workgroup per path holds the whole batch (the batch statistics are workgroup reductions):
+ * one launch forward, one backward, for both paths.  C <= 64, S <= 192 (cg_gate_head_supported; else CG_ESHAPE: cg_norm_act_* +
+ * cg_copy_many + cg_contract_many).  Forward writes y (B,C: the first Linear's output, kept for the backward), w, both bn.save;
+ * backward needs `scratch` = cg_gate_head_scratch_floats(B, C, S) floats per path and writes dz, dstats (B,S), every parameter gradient. */
+typedef struct CgGatePath {
+  const float* z;
+  const float* stats; long long stats_ld;
+  CgTailBN bn2; const float* alpha2;
+  const float* Wl;
+  CgTailBN bn3; const float* alpha3;
+  const float* W2;
+  unsigned int salt2, salt3;
+  float* y;
+  float* w;
+  float* tap2; float* tap3;
+  const float* dw;
+  float* dz;
+  float* dstats;
+  float* dWl; float* dW2;
+  float* dgamma2; float* dbeta2; float* dalpha2; float* dgamma3; float* dbeta3; float* dalpha3;
+  float* scratch;
+} CgGatePath;
+typedef struct CgGateHead {
+  int B, C, S, train, n, pad;
+  float drop_p; int pad2; const unsigned long long* seed;
+  CgGatePath p[2];
+} CgGateHead;
+int cg_gate_head_fwd(const CgGateHead* t, void* stream);
+int cg_gate_head_bwd(const CgGateHead* t, void* stream);
+int cg_gate_head_supported(int B, int C, int S);
+long long cg_gate_head_scratch_floats(int B, int C, int S);
+
 /* ---- ContextLayer heads 1 and 3, CISTGCN.py:408-418 with :465 / :467 ---------------------------------
  * Conv2d(1, C, 1, bias=False) -> BatchNorm2d(C) -> PReLU of the one-channel tensor x (B,1,T_out,3V), reduced over the positions:
  *   head 0 (context_conv1): y[0][b,c] = max_p z (first arg-max in `arg`), head 1 (context_conv3): y[1][b,c] = mean_p z.

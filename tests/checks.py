@@ -994,6 +994,76 @@ def check_map2adj_tail(device, shapes=((3, 7, 9), (2, 10, 22), (4, 25, 6), (2, 4
                 assert_close(a.float(), b.float(), "%s buffer[%d]" % (what, k), rel=1e-6)
 
 
+def check_gate_head(device, shapes=((5, 8, 10, 2), (37, 64, 102, 2), (4, 3, 46, 2), (20, 10, 22, 1))):
+    """ops.gate_head (csrc/gate_head.hip) against stock PyTorch in fp64: BatchNorm2d -> Dropout(0) -> PReLU -> cat(statistics) -> Linear ->
+    BatchNorm1d -> PReLU -> Linear per gate path (CISTGCN.py:337-352): gates, both PReLU taps, dz, the statistics' gradient, every
+    parameter gradient, running statistics; train and eval mode; the statistics handed over as column slices of a wider tensor.
+    Dropout: keep factors of helpers.hip_keep_scale applied in the reference.  shapes: (B, C, S, paths)."""
+    from cistgcn_amd.models.CISTGCN.CISTGCN import Stage
+    from helpers import hip_keep_scale
+    g = _gen(91)
+    for (B, C, S, n) in shapes:
+        for train, pdrop in ((True, 0.0), (True, 0.25), (False, 0.0)):
+            def make(dt):
+                gg = _gen(600 + C)
+                convs, maps = [], []
+                for k in range(n):
+                    conv = Stage(s5=nn.BatchNorm2d(C), s7=nn.PReLU())
+                    mp = Stage(s0=nn.Linear(C + S, C, bias=False), s1=nn.BatchNorm1d(C), s3=nn.PReLU(), s4=nn.Linear(C, C, bias=False))
+                    with torch.no_grad():
+                        for bn in (conv[5], mp[1]):
+                            bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=gg)); bn.bias.copy_(0.3 * torch.randn(C, generator=gg))
+                            bn.running_mean.copy_(0.2 * torch.randn(C, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(C, generator=gg))
+                        mp[0].weight.copy_(torch.randn(mp[0].weight.shape, generator=gg) * 0.3); mp[4].weight.copy_(torch.randn(C, C, generator=gg) * 0.3)
+                        conv[7].weight.fill_(0.1 + 0.1 * k); mp[3].weight.fill_(0.3 - 0.1 * k)
+                    convs.append(conv); maps.append(mp)
+                return nn.ModuleList(convs).to(dt), nn.ModuleList(maps).to(dt)
+            z0 = [0.5 + 1.5 * _rand(g, B, C) for _ in range(n)]
+            wide = _rand(g, B, S + 5)
+            gw = [_rand(g, B, C) for _ in range(n)]
+            salts = [(3 + k, 11 + k) for k in range(n)]
+            seed = 987654321
+            what = "gate_head B%d C%d S%d x%d %s p=%.2f" % (B, C, S, n, "train" if train else "eval", pdrop)
+            # fp64 reference (the keep factors of the kernels' hash)
+            rc, rm = make(torch.float64)
+            rc.train(train); rm.train(train)
+            zr = [_leaf(t.double(), "cpu") for t in z0]
+            sr = _leaf(wide.double(), "cpu")
+            outs, taps_r = [], []
+            for k in range(n):
+                keep2 = torch.from_numpy(hip_keep_scale(seed, salts[k][0], pdrop, B * C)).view(B, C).double() if pdrop > 0 else 1.0
+                keep3 = torch.from_numpy(hip_keep_scale(seed, salts[k][1], pdrop, B * C)).view(B, C).double() if pdrop > 0 else 1.0
+                h2 = rc[k][7](rc[k][5](zr[k].view(B, C, 1, 1)).view(B, C) * keep2)
+                y = rm[k][0](torch.cat((h2, sr[:, 2:2 + S]), 1))
+                h3 = rm[k][3](rm[k][1](y) * keep3)
+                outs.append(rm[k][4](h3)); taps_r += [h2, h3]
+            torch.autograd.backward(outs, [t.double() for t in gw])
+            # HIP
+            dc, dm = make(torch.float32)
+            dc, dm = dc.to(device).train(train), dm.to(device).train(train)
+            zd = [_leaf(t, device) for t in z0]
+            sd = _leaf(wide, device)
+            ops.manual_seed(seed, device)
+            ops.begin_step(device)
+            taps = []
+            ws = ops.gate_head(zd, [sd[:, 2:2 + S]] * n, list(dc), list(dm), train, drop_p=pdrop, salts=salts, taps=taps)
+            torch.autograd.backward(ws, [t.to(device) for t in gw])
+            for k in range(n):
+                assert_close(ws[k], outs[k], "%s gate %d" % (what, k), rel=3e-5)
+                assert_close(taps[2 * k], taps_r[2 * k], "%s tap2 %d" % (what, k), rel=3e-5)
+                assert_close(taps[2 * k + 1], taps_r[2 * k + 1], "%s tap3 %d" % (what, k), rel=3e-5)
+                assert_close(zd[k].grad, zr[k].grad, "%s dz %d" % (what, k), rel=5e-5, floor=max(1e-3, float(zr[k].grad.abs().max())))
+            assert_close(sd.grad, sr.grad, what + " dstats", rel=5e-5, floor=max(1e-3, float(sr.grad.abs().max())))
+            for mods_d, mods_r in ((dc, rc), (dm, rm)):
+                for (kname, pa), (_, pb) in zip(mods_d.named_parameters(), mods_r.named_parameters()):
+                    floor = max(1e-3, float(pb.grad.abs().max()))
+                    if train and kname.endswith("0.weight"):      # Linear in front of a train-mode BatchNorm1d: remainder of cancelling sums
+                        floor = max(floor, float(mods_r[int(kname.split(".")[0])][1].weight.grad.abs().max()))
+                    assert_close(pa.grad, pb.grad, "%s grad %s" % (what, kname), rel=5e-5, floor=floor)
+                for (kname, ba), (_, bb) in zip(mods_d.named_buffers(), mods_r.named_buffers()):
+                    assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, kname), rel=1e-5)
+
+
 def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14), (3, 64, (32, 32, 32, 32), 5, 12))):
     """ops.tower_maps (pointwise maps + BatchNorm2d + PReLU as one operator; backward: cg_norm_act_bwd_reduce_many + cg_pointwise_maps_bwd
     undoing BatchNorm / PReLU on load) against stock PyTorch in fp64: outputs, dx, every dW / dgamma / dbeta / dalpha, running statistics,
