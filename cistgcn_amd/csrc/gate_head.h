@@ -28,7 +28,7 @@ struct CgGatePath {
   float* dstats;                // (B,S) contiguous
   float* dWl; float* dW2;
   float* dgamma2; float* dbeta2; float* dalpha2; float* dgamma3; float* dbeta3; float* dalpha3;
-  float* scratch;               // backward: B * (2C + S) floats
+  float* scratch;               // unused (cg_gate_head_scratch_floats() == 0): the backward keeps its intermediates in registers
 };
 struct CgGateHead {
   int B, C, S, train, n, pad;   // n paths (1 or 2)

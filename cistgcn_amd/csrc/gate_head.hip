@@ -17,6 +17,7 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 #define CG_GATE_THREADS 1024
 #define CG_GATE_WAVES (CG_GATE_THREADS / CG_WAVE)
 #define CG_GATE_CP 64                      // padded column count = lanes of a wave
+#define CG_GATE_NS 16                      // samples per thread: B <= WAVES * NS = 256
 
 struct CgGateAff { float mean, rstd, scale, beta; };
 
@@ -68,20 +69,33 @@ __device__ __forceinline__ double cg_gate_colsum(double v, double* sRed, int wav
 __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_fwd_kernel(CgGateHead t) {
   const CgGatePath& p = t.p[blockIdx.x];
   const int B = t.B, C = t.C, S = t.S, K = C + S, KP = (K + 3) & ~3;
-  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [K][CP]   Wl transposed
-  float* sW2 = sWl + K * CG_GATE_CP;                                  // [C][CP]   W2 transposed
+  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [KP][CP]  Wl transposed, rows K .. KP-1 zero
+  float* sW2 = sWl + KP * CG_GATE_CP;                                 // [C][CP]   W2 transposed
   float* sU = sW2 + C * CG_GATE_CP;                                   // [WAVES][KP] input rows of the current chunk
   float* sAff = sU + CG_GATE_WAVES * KP;                              // [2][CP][4] mean, rstd, scale, beta of bn2 / bn3
-  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4 + ((K * CG_GATE_CP + C * CG_GATE_CP + CG_GATE_WAVES * KP) & 1));
+  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4);      // an even number of floats in front of it
   const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
   const bool drop = t.train && t.drop_p > 0.f;
   const unsigned long long seed = drop ? *t.seed : 0ull;
+  for (int e = tid; e < (KP - K) * CG_GATE_CP; e += CG_GATE_THREADS) sWl[K * CG_GATE_CP + e] = 0.f;
   for (int e = tid; e < C * K; e += CG_GATE_THREADS) { const int o = e / K, i = e - o * K; sWl[i * CG_GATE_CP + o] = p.Wl[e]; }
   for (int e = tid; e < C * C; e += CG_GATE_THREADS) { const int o = e / C, j = e - o * C; sW2[j * CG_GATE_CP + o] = p.W2[e]; }
+  // this thread's share of the batch: samples b = wave + 16 k, column `lane`.  z is loaded once, y stays in registers between the two Linear
+  // layers: inside the rounds below nothing waits for HBM but the statistics rows, and those are requested one round ahead (with the loads
+  // inside the rounds a 256-sample batch took 140 us: sixteen dependent round trips per pass)
+  float zreg[CG_GATE_NS], yreg[CG_GATE_NS];
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b = wave + CG_GATE_WAVES * k;
+    zreg[k] = (b < B && lane < C) ? p.z[(long long)b * C + lane] : 0.f;
+    yreg[k] = 0.f;
+  }
   // ---- BatchNorm of z over the batch
   double s1 = 0.0, s2 = 0.0;
-  if (t.train && lane < C)
-    for (int b = wave; b < B; b += CG_GATE_WAVES) { const double v = (double)p.z[(long long)b * C + lane]; s1 += v; s2 += v * v; }
+  if (t.train) {
+#pragma unroll
+    for (int k = 0; k < CG_GATE_NS; ++k) if (wave + CG_GATE_WAVES * k < B) { const double v = (double)zreg[k]; s1 += v; s2 += v * v; }
+  }
   s1 = cg_gate_colsum(s1, sRed, wave, lane);
   s2 = cg_gate_colsum(s2, sRed, wave, lane);
   if (wave == 0 && lane < C) {
@@ -93,25 +107,46 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_fwd_kernel(CgGat
   const float alpha2 = p.alpha2[0], alpha3 = p.alpha3[0];
   // ---- y = Wl [PReLU(Dropout(BN(z))) | stats], sixteen samples per round (a wave = a sample)
   s1 = 0.0; s2 = 0.0;
-  for (int b0 = 0; b0 < B; b0 += CG_GATE_WAVES) {
-    const int b = b0 + wave;
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f;                 // statistics columns C + lane (+ 64, + 128) of the next round's sample
+  auto load_stats = [&](int b) {
+    const float* row = p.stats + (long long)b * p.stats_ld;
+    st0 = (b < B && lane < S) ? row[lane] : 0.f;
+    st1 = (b < B && lane + 64 < S) ? row[lane + 64] : 0.f;
+    st2 = (b < B && lane + 128 < S) ? row[lane + 128] : 0.f;
+  };
+  load_stats(wave);
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b = wave + CG_GATE_WAVES * k;
+    if (CG_GATE_WAVES * k >= B) break;                                 // uniform
     __syncthreads();
-    if (b < B)
-      for (int i = lane; i < K; i += CG_WAVE) {
-        float v;
-        if (i < C) {
-          const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + i) : 1.f;
-          const float u = cg_gate_u(sAff + 4 * i, p.z[(long long)b * C + i], keep);
-          v = u > 0.f ? u : alpha2 * u;
-          if (p.tap2) p.tap2[(long long)b * C + i] = v;
-        } else v = p.stats[(long long)b * p.stats_ld + (i - C)];
-        sU[wave * KP + i] = v;
+    if (b < B) {
+      float* u = sU + wave * KP;
+      if (lane < C) {
+        const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
+        const float uu = cg_gate_u(sAff + 4 * lane, zreg[k], keep);
+        const float v = uu > 0.f ? uu : alpha2 * uu;
+        if (p.tap2) p.tap2[(long long)b * C + lane] = v;
+        u[lane] = v;
       }
+      if (lane < S) u[C + lane] = st0;
+      if (lane + 64 < S) u[C + lane + 64] = st1;
+      if (lane + 128 < S) u[C + lane + 128] = st2;
+      for (int i = K + lane; i < KP; i += CG_WAVE) u[i] = 0.f;
+    }
+    load_stats(b + CG_GATE_WAVES);
     __syncthreads();
     if (b < B && lane < C) {
       const float* u = sU + wave * KP;
       float acc = 0.f;
-      for (int i = 0; i < K; ++i) acc += sWl[i * CG_GATE_CP + lane] * u[i];
+      for (int i = 0; i < KP; i += 4) {
+        const float4 uv = *reinterpret_cast<const float4*>(u + i);      // the same address in every lane: a broadcast
+        acc += sWl[i * CG_GATE_CP + lane] * uv.x;
+        acc += sWl[(i + 1) * CG_GATE_CP + lane] * uv.y;
+        acc += sWl[(i + 2) * CG_GATE_CP + lane] * uv.z;
+        acc += sWl[(i + 3) * CG_GATE_CP + lane] * uv.w;
+      }
+      yreg[k] = acc;
       p.y[(long long)b * C + lane] = acc;
       s1 += (double)acc; s2 += (double)acc * (double)acc;
     }
@@ -126,13 +161,15 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_fwd_kernel(CgGat
   }
   __syncthreads();
   // ---- w = W2 PReLU(Dropout(BN(y)))
-  for (int b0 = 0; b0 < B; b0 += CG_GATE_WAVES) {
-    const int b = b0 + wave;
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b = wave + CG_GATE_WAVES * k;
+    if (CG_GATE_WAVES * k >= B) break;
     __syncthreads();
     if (b < B && lane < C) {
       const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
-      const float u = cg_gate_u(sAff + 4 * (CG_GATE_CP + lane), p.y[(long long)b * C + lane], keep);   // written by this thread above
-      const float v = u > 0.f ? u : alpha3 * u;
+      const float uu = cg_gate_u(sAff + 4 * (CG_GATE_CP + lane), yreg[k], keep);
+      const float v = uu > 0.f ? uu : alpha3 * uu;
       if (p.tap3) p.tap3[(long long)b * C + lane] = v;
       sU[wave * KP + lane] = v;
     }
@@ -148,7 +185,7 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_fwd_kernel(CgGat
 
 // ======================================================================================================================
 #define CG_GATE_ACC2 4          // C * C <= THREADS * ACC2
-#define CG_GATE_ACCL 16         // C * (C + S) <= THREADS * ACCL
+#define CG_GATE_ACCL 11         // C * (C + S) <= THREADS * ACCL (64 x 166 = 10624 <= 11264)
 
 __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGateHead t) {
   const CgGatePath& p = t.p[blockIdx.x];
@@ -158,12 +195,23 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
   float* sA = sW2 + C * C;                                            // [WAVES][CP] dw rows, then dy rows
   float* sH = sA + CG_GATE_WAVES * CG_GATE_CP;                        // [WAVES][KP] h3 rows, then u rows
   float* sAff = sH + CG_GATE_WAVES * KP;                              // [2][CP][4]
-  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4 + ((C * K + C * C + CG_GATE_WAVES * KP) & 1));
-  float* G3 = p.scratch;                                              // (B,C) gradient in front of bn3
-  float* G2 = p.scratch + (long long)B * C;                           // (B,C) gradient in front of bn2
+  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4 + ((C * K + C * C) & 1));
+  __shared__ float sM[2][CG_GATE_CP][2];
+  __shared__ double sAlpha[CG_GATE_CP];
   const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
   const bool drop = t.train && t.drop_p > 0.f;
   const unsigned long long seed = drop ? *t.seed : 0ull;
+  // this thread's share of the batch (samples wave + 16 k, column lane) lives in registers through all three phases: dw / y / z are loaded
+  // once, the gradients in front of the two BatchNorms (g3, g2) never leave the registers
+  float ra[CG_GATE_NS], ry[CG_GATE_NS], rg[CG_GATE_NS];               // ra: dw, later z; ry: y; rg: g3, later g2
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b = wave + CG_GATE_WAVES * k;
+    const bool ok = b < B && lane < C;
+    ra[k] = ok ? p.dw[(long long)b * C + lane] : 0.f;
+    ry[k] = ok ? p.y[(long long)b * C + lane] : 0.f;
+    rg[k] = 0.f;
+  }
   for (int e = tid; e < C * K; e += CG_GATE_THREADS) sWl[e] = p.Wl[e];
   for (int e = tid; e < C * C; e += CG_GATE_THREADS) sW2[e] = p.W2[e];
   if (wave == 0 && lane < C) {
@@ -184,15 +232,16 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
   // ---- phase 1: through the last Linear and the PReLU / Dropout behind bn3; dW2
   double S1 = 0.0, S2 = 0.0, SA = 0.0;
   const float* k3 = sAff + 4 * (CG_GATE_CP + lane);
-  for (int b0 = 0; b0 < B; b0 += CG_GATE_WAVES) {
-    const int b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b0 = CG_GATE_WAVES * k, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
+    if (b0 >= B) break;                                                // uniform
     __syncthreads();
-    float u3 = 0.f, keep3 = 1.f, yv = 0.f;
+    float u3 = 0.f, keep3 = 1.f;
     if (b < B && lane < C) {
-      sA[wave * CG_GATE_CP + lane] = p.dw[(long long)b * C + lane];
+      sA[wave * CG_GATE_CP + lane] = ra[k];
       keep3 = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
-      yv = p.y[(long long)b * C + lane];
-      u3 = cg_gate_u(k3, yv, keep3);
+      u3 = cg_gate_u(k3, ry[k], keep3);
       sH[wave * KP + lane] = u3 > 0.f ? u3 : alpha3 * u3;
     }
     __syncthreads();
@@ -203,8 +252,8 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
       const float gu = u3 > 0.f ? dh : alpha3 * dh;
       if (!(u3 > 0.f)) SA += (double)dh * (double)u3;
       const float g = gu * keep3;
-      S1 += (double)g; S2 += (double)g * (double)((yv - k3[0]) * k3[1]);
-      G3[(long long)b * C + lane] = g;
+      S1 += (double)g; S2 += (double)g * (double)((ry[k] - k3[0]) * k3[1]);
+      rg[k] = g;
     }
 #pragma unroll
     for (int q = 0; q < CG_GATE_ACC2; ++q) {
@@ -217,11 +266,23 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
       }
     }
   }
+  // z of this thread's samples replaces dw; the statistics rows of the first round are requested
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b = wave + CG_GATE_WAVES * k;
+    ra[k] = (b < B && lane < C) ? p.z[(long long)b * C + lane] : 0.f;
+  }
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f;
+  auto load_stats = [&](int b) {
+    const float* row = p.stats + (long long)b * p.stats_ld;
+    st0 = (b < B && lane < S) ? row[lane] : 0.f;
+    st1 = (b < B && lane + 64 < S) ? row[lane + 64] : 0.f;
+    st2 = (b < B && lane + 128 < S) ? row[lane + 128] : 0.f;
+  };
+  load_stats(wave);
   S1 = cg_gate_colsum(S1, sRed, wave, lane);
   S2 = cg_gate_colsum(S2, sRed, wave, lane);
   SA = cg_gate_colsum(SA, sRed, wave, lane);
-  __shared__ float sM[2][CG_GATE_CP][2];
-  __shared__ double sAlpha[CG_GATE_CP];
   if (wave == 0) {
     if (lane < C) {
       sM[1][lane][0] = t.train ? (float)(S1 / (double)B) : 0.f; sM[1][lane][1] = t.train ? (float)(S2 / (double)B) : 0.f;
@@ -235,22 +296,26 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
   // ---- phase 2: through bn3 and the first Linear; the statistics' gradient; PReLU / Dropout behind bn2; dWl
   S1 = 0.0; S2 = 0.0; SA = 0.0;
   const float* k2 = sAff + 4 * lane;
-  for (int b0 = 0; b0 < B; b0 += CG_GATE_WAVES) {
-    const int b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
+#pragma unroll
+  for (int k = 0; k < CG_GATE_NS; ++k) {
+    const int b0 = CG_GATE_WAVES * k, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
+    if (b0 >= B) break;
     __syncthreads();
-    float u2 = 0.f, keep2 = 1.f, zv = 0.f;
+    float u2 = 0.f, keep2 = 1.f;
     if (b < B) {
+      float* u = sH + wave * KP;
       if (lane < C) {
-        const float g = G3[(long long)b * C + lane];                        // written by this thread in phase 1
-        const float xh = (p.y[(long long)b * C + lane] - k3[0]) * k3[1];
-        sA[wave * CG_GATE_CP + lane] = k3[2] * (g - sM[1][lane][0] - xh * sM[1][lane][1]);
+        const float xh = (ry[k] - k3[0]) * k3[1];
+        sA[wave * CG_GATE_CP + lane] = k3[2] * (rg[k] - sM[1][lane][0] - xh * sM[1][lane][1]);
         keep2 = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
-        zv = p.z[(long long)b * C + lane];
-        u2 = cg_gate_u(k2, zv, keep2);
-        sH[wave * KP + lane] = u2 > 0.f ? u2 : alpha2 * u2;
+        u2 = cg_gate_u(k2, ra[k], keep2);
+        u[lane] = u2 > 0.f ? u2 : alpha2 * u2;
       }
-      for (int i = C + lane; i < K; i += CG_WAVE) sH[wave * KP + i] = p.stats[(long long)b * p.stats_ld + (i - C)];
+      if (lane < S) u[C + lane] = st0;
+      if (lane + 64 < S) u[C + lane + 64] = st1;
+      if (lane + 128 < S) u[C + lane + 128] = st2;
     }
+    load_stats(b + CG_GATE_WAVES);
     __syncthreads();
     if (b < B) {
       const float* dyr = sA + wave * CG_GATE_CP;
@@ -262,8 +327,8 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
           const float gu = u2 > 0.f ? du : alpha2 * du;
           if (!(u2 > 0.f)) SA += (double)du * (double)u2;
           const float g = gu * keep2;
-          S1 += (double)g; S2 += (double)g * (double)((zv - k2[0]) * k2[1]);
-          G2[(long long)b * C + lane] = g;
+          S1 += (double)g; S2 += (double)g * (double)((ra[k] - k2[0]) * k2[1]);
+          rg[k] = g;
         }
       }
     }
@@ -292,11 +357,16 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
   if (tid == 0) { double s = 0.0; for (int c = 0; c < C; ++c) s += sAlpha[c]; p.dalpha2[0] = (float)s; }
 
   // ---- phase 3: through bn2
-  if (lane < C)
-    for (int b = wave; b < B; b += CG_GATE_WAVES) {
-      const float xh = (p.z[(long long)b * C + lane] - k2[0]) * k2[1];
-      p.dz[(long long)b * C + lane] = k2[2] * (G2[(long long)b * C + lane] - sM[0][lane][0] - xh * sM[0][lane][1]);     // G2: this thread's own
+  if (lane < C) {
+#pragma unroll
+    for (int k = 0; k < CG_GATE_NS; ++k) {
+      const int b = wave + CG_GATE_WAVES * k;
+      if (b < B) {
+        const float xh = (ra[k] - k2[0]) * k2[1];
+        p.dz[(long long)b * C + lane] = k2[2] * (rg[k] - sM[0][lane][0] - xh * sM[0][lane][1]);
+      }
     }
+  }
 #pragma unroll
   for (int q = 0; q < CG_GATE_ACC2; ++q) { const int e = tid + CG_GATE_THREADS * q; if (e < C * C) p.dW2[e] = acc2[q]; }
 #pragma unroll
@@ -306,7 +376,7 @@ __global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGat
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int cg_gate_check(const CgGateHead* t, bool bwd) {
   if (!t || t->n < 1 || t->n > 2) return CG_EARG;
-  if (t->B <= 0 || t->C <= 0 || t->C > CG_GATE_MAXC || t->S < 0 || t->S > CG_GATE_MAXS) return CG_ESHAPE;
+  if (t->B <= 0 || t->B > CG_GATE_WAVES * CG_GATE_NS || t->C <= 0 || t->C > CG_GATE_MAXC || t->S < 0 || t->S > CG_GATE_MAXS) return CG_ESHAPE;
   if (t->train && t->B < 2) return CG_ESHAPE;
   if (t->train && t->drop_p > 0.f && !t->seed) return CG_EARG;
   if (t->drop_p < 0.f || t->drop_p >= 1.f) return CG_EARG;
@@ -316,20 +386,22 @@ static int cg_gate_check(const CgGateHead* t, bool bwd) {
     if (!p.bn2.gamma || !p.bn2.beta || !p.bn2.save || !p.bn3.gamma || !p.bn3.beta || !p.bn3.save) return CG_EARG;
     if (!bwd && (!p.w || (!t->train && (!p.bn2.running_mean || !p.bn2.running_var || !p.bn3.running_mean || !p.bn3.running_var)))) return CG_EARG;
     if (bwd && (!p.dw || !p.dz || (t->S > 0 && !p.dstats) || !p.dWl || !p.dW2 || !p.dgamma2 || !p.dbeta2 || !p.dalpha2 || !p.dgamma3 || !p.dbeta3 ||
-                !p.dalpha3 || !p.scratch)) return CG_EARG;
+                !p.dalpha3)) return CG_EARG;
   }
   return CG_OK;
 }
 
-extern "C" int cg_gate_head_supported(int B, int C, int S) { return (B > 0 && C > 0 && C <= CG_GATE_MAXC && S >= 0 && S <= CG_GATE_MAXS) ? 1 : 0; }
-extern "C" long long cg_gate_head_scratch_floats(int B, int C, int S) { return (long long)B * (2 * C + S); }
+extern "C" int cg_gate_head_supported(int B, int C, int S) {
+  return (B > 0 && B <= CG_GATE_WAVES * CG_GATE_NS && C > 0 && C <= CG_GATE_MAXC && S >= 0 && S <= CG_GATE_MAXS) ? 1 : 0;
+}
+extern "C" long long cg_gate_head_scratch_floats(int B, int C, int S) { (void)B; (void)C; (void)S; return 0; }      // the backward keeps its intermediates in registers
 
 // include/cistgcn_hip.h : cg_gate_head_fwd / cg_gate_head_bwd
 extern "C" int cg_gate_head_fwd(const CgGateHead* t, void* stream_) {
   int st = cg_gate_check(t, false);
   if (st != CG_OK) return st;
   const int K = t->C + t->S, KP = (K + 3) & ~3;
-  const size_t lds = ((size_t)K * CG_GATE_CP + (size_t)t->C * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + 2 * CG_GATE_CP * 4 + 1) * sizeof(float) +
+  const size_t lds = ((size_t)KP * CG_GATE_CP + (size_t)t->C * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + 2 * CG_GATE_CP * 4 + 1) * sizeof(float) +
                      (size_t)CG_GATE_WAVES * CG_GATE_CP * sizeof(double);
   if (lds > 64 * 1024 && cg_lds_limit((const void*)cg_gate_head_fwd_kernel, lds) != hipSuccess) return CG_ESHAPE;
   hipLaunchKernelGGL(cg_gate_head_fwd_kernel, dim3((unsigned)t->n), dim3(CG_GATE_THREADS), lds, (hipStream_t)stream_, *t);

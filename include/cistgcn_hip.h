@@ -358,9 +358,9 @@ int cg_block_input_supported(int B, int C, int T, int V);
 /* ---- tail of the gate paths of a DSTD_GC block, conv_s / conv_t slots 5-7 and map_s / map_t, CISTGCN.py:337-352 / :378-384 ------
  * per path: z (B,C) -> BatchNorm2d -> Dropout -> PReLU -> cat with the block statistics (B,S) -> Linear (C, C+S) -> BatchNorm1d -> Dropout ->
  * PReLU -> Linear (C,C) = the gate (B,C).  One workgroup per path holds the whole batch (the batch statistics are workgroup reductions):
- * one launch forward, one backward, for both paths.  C <= 64, S <= 192 (cg_gate_head_supported; else CG_ESHAPE: cg_norm_act_* +
+ * one launch forward, one backward, for both paths.  B <= 256, C <= 64, S <= 192 (cg_gate_head_supported; else CG_ESHAPE: cg_norm_act_* +
  * cg_copy_many + cg_contract_many).  Forward writes y (B,C: the first Linear's output, kept for the backward), w, both bn.save;
- * backward needs `scratch` = cg_gate_head_scratch_floats(B, C, S) floats per path and writes dz, dstats (B,S), every parameter gradient. */
+ * backward writes dz, dstats (B,S) and every parameter gradient (`scratch` is unused: cg_gate_head_scratch_floats() == 0). */
 typedef struct CgGatePath {
   const float* z;
   const float* stats; long long stats_ld;
