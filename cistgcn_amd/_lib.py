@@ -138,7 +138,7 @@ class GatePath(ctypes.Structure):
                 ("salt2", c_uint), ("salt3", c_uint), ("y", c_void_p), ("w", c_void_p), ("tap2", c_void_p), ("tap3", c_void_p),
                 ("dw", c_void_p), ("dz", c_void_p), ("dstats", c_void_p), ("dWl", c_void_p), ("dW2", c_void_p),
                 ("dgamma2", c_void_p), ("dbeta2", c_void_p), ("dalpha2", c_void_p), ("dgamma3", c_void_p), ("dbeta3", c_void_p), ("dalpha3", c_void_p),
-                ("scratch", c_void_p)]
+                ("scratch", c_void_p), ("red", c_void_p)]
 
 
 class GateHead(ctypes.Structure):

@@ -28,7 +28,8 @@ struct CgGatePath {
   float* dstats;                // (B,S) contiguous
   float* dWl; float* dW2;
   float* dgamma2; float* dbeta2; float* dalpha2; float* dgamma3; float* dbeta3; float* dalpha3;
-  float* scratch;               // unused (cg_gate_head_scratch_floats() == 0): the backward keeps its intermediates in registers
+  float* scratch;               // backward: cg_gate_head_scratch_floats(B, C, S) floats (the gradients in front of the two BatchNorms)
+  double* red;                  // backward: two f64 words, zero on entry (slope sums)
 };
 struct CgGateHead {
   int B, C, S, train, n, pad;   // n paths (1 or 2)

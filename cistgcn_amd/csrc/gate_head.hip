@@ -5,9 +5,12 @@
 // Every tensor here is (B, <= C + S) - a few hundred KB at B = 256 - but as separate operators the chain was seven launches forward
 // (channel sums, row kernel, two concatenation copies, contraction, row kernel, contraction) and as many backward, each 10-45 us of
 // launch latency and split-K bookkeeping: ~110 us forward and ~90 us backward per block, 1.1 ms of the 22 ms step at B = 256 and a
-// quarter of the launches of the B = 16 step.  Here ONE workgroup per gate path holds the whole batch: the three batch statistics
-// are workgroup reductions, the two Linear layers walk the batch in chunks of sixteen samples (a wave = a sample, a lane = an
-// output column, weights transposed in LDS), the concatenation is an index.  Forward and backward are one launch each.
+// quarter of the launches of the B = 16 step.  Here the chain is cut only at its batch statistics: two launches forward, three backward,
+// for both paths.  A workgroup owns sixteen samples (a wave = a sample, a lane = a column; the weights sit transposed in LDS, the
+// concatenation is an index) and computes the BatchNorm statistics of the WHOLE batch itself - the tensors are (B, 64): reading 64 KB
+// again per workgroup costs less than a launch, and no workgroup waits for another.  (First version, measured: ONE workgroup per path
+// holding the whole batch, one launch per direction - 112 / 278 us at B = 256, the two Linear layers bound by the LDS bandwidth of a
+// single CU.)
 #include "cg_common.h"
 #include "cg_phase.h"
 #include "gate_head.h"
@@ -17,13 +20,12 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 #define CG_GATE_THREADS 1024
 #define CG_GATE_WAVES (CG_GATE_THREADS / CG_WAVE)
 #define CG_GATE_CP 64                      // padded column count = lanes of a wave
-#define CG_GATE_NS 16                      // samples per thread: B <= WAVES * NS = 256
 
 struct CgGateAff { float mean, rstd, scale, beta; };
 
 // BatchNorm constants of column c from the workgroup's own batch sums (train) or the running statistics (eval); thread c of wave 0
-// calls this (forward): it records save / running statistics exactly like nn.BatchNorm
-__device__ __forceinline__ CgGateAff cg_gate_aff_fwd(const CgTailBN& bn, int c, int C, int B, int train, double s1, double s2) {
+// calls this (forward); the workgroup of the first chunk (`owner`) records save / running statistics exactly like nn.BatchNorm
+__device__ __forceinline__ CgGateAff cg_gate_aff_fwd(const CgTailBN& bn, int c, int C, int B, int train, double s1, double s2, bool owner) {
   CgGateAff a;
   const float gamma = bn.gamma[c];
   a.beta = bn.beta[c];
@@ -33,7 +35,7 @@ __device__ __forceinline__ CgGateAff cg_gate_aff_fwd(const CgTailBN& bn, int c, 
     if (var < 0.0) var = 0.0;
     a.mean = (float)mean;
     a.rstd = (float)(1.0 / sqrt(var + (double)bn.eps));
-    if (bn.running_mean) {
+    if (owner && bn.running_mean) {
       const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
       bn.running_mean[c] = (1.f - bn.momentum) * bn.running_mean[c] + bn.momentum * (float)mean;
       bn.running_var[c] = (1.f - bn.momentum) * bn.running_var[c] + bn.momentum * (float)unb;
@@ -43,7 +45,7 @@ __device__ __forceinline__ CgGateAff cg_gate_aff_fwd(const CgTailBN& bn, int c, 
     a.mean = bn.running_mean[c];
     a.rstd = 1.0f / sqrtf(bn.running_var[c] + bn.eps);
   }
-  bn.save[c] = a.mean; bn.save[C + c] = a.rstd;
+  if (owner) { bn.save[c] = a.mean; bn.save[C + c] = a.rstd; }
   a.scale = gamma * a.rstd;
   return a;
 }
@@ -65,318 +67,263 @@ __device__ __forceinline__ double cg_gate_colsum(double v, double* sRed, int wav
   return s;
 }
 
-// ======================================================================================================================
-__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_fwd_kernel(CgGateHead t) {
-  const CgGatePath& p = t.p[blockIdx.x];
-  const int B = t.B, C = t.C, S = t.S, K = C + S, KP = (K + 3) & ~3;
-  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [KP][CP]  Wl transposed, rows K .. KP-1 zero
-  float* sW2 = sWl + KP * CG_GATE_CP;                                 // [C][CP]   W2 transposed
-  float* sU = sW2 + C * CG_GATE_CP;                                   // [WAVES][KP] input rows of the current chunk
-  float* sAff = sU + CG_GATE_WAVES * KP;                              // [2][CP][4] mean, rstd, scale, beta of bn2 / bn3
-  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4);      // an even number of floats in front of it
-  const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
-  const bool drop = t.train && t.drop_p > 0.f;
-  const unsigned long long seed = drop ? *t.seed : 0ull;
-  for (int e = tid; e < (KP - K) * CG_GATE_CP; e += CG_GATE_THREADS) sWl[K * CG_GATE_CP + e] = 0.f;
-  for (int e = tid; e < C * K; e += CG_GATE_THREADS) { const int o = e / K, i = e - o * K; sWl[i * CG_GATE_CP + o] = p.Wl[e]; }
-  for (int e = tid; e < C * C; e += CG_GATE_THREADS) { const int o = e / C, j = e - o * C; sW2[j * CG_GATE_CP + o] = p.W2[e]; }
-  // this thread's share of the batch: samples b = wave + 16 k, column `lane`.  z is loaded once, y stays in registers between the two Linear
-  // layers: inside the rounds below nothing waits for HBM but the statistics rows, and those are requested one round ahead (with the loads
-  // inside the rounds a 256-sample batch took 140 us: sixteen dependent round trips per pass)
-  float zreg[CG_GATE_NS], yreg[CG_GATE_NS];
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b = wave + CG_GATE_WAVES * k;
-    zreg[k] = (b < B && lane < C) ? p.z[(long long)b * C + lane] : 0.f;
-    yreg[k] = 0.f;
-  }
-  // ---- BatchNorm of z over the batch
-  double s1 = 0.0, s2 = 0.0;
-  if (t.train) {
-#pragma unroll
-    for (int k = 0; k < CG_GATE_NS; ++k) if (wave + CG_GATE_WAVES * k < B) { const double v = (double)zreg[k]; s1 += v; s2 += v * v; }
-  }
+// sums over the whole batch of a (B,C) tensor per column, optionally of g and g * xhat with xhat = (x - mean) * rstd: every workgroup
+// computes them for itself.  Thread (lane, wave) walks the samples wave, wave + 16, ...; result valid in wave 0
+__device__ __forceinline__ void cg_gate_batch_sums(const float* __restrict__ a, const float* __restrict__ x, float mean, float rstd, int B, int C,
+                                                   double* sRed, int wave, int lane, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+  if (lane < C)
+    for (int b = wave; b < B; b += CG_GATE_WAVES) {
+      const double v = (double)a[(long long)b * C + lane];
+      s1 += v;
+      s2 += x ? v * (double)((x[(long long)b * C + lane] - mean) * rstd) : v * v;
+    }
   s1 = cg_gate_colsum(s1, sRed, wave, lane);
   s2 = cg_gate_colsum(s2, sRed, wave, lane);
+}
+
+// ======================================================================================================================
+// forward, launch 1:  y = Wl [PReLU(Dropout(BN(z))) | stats]      grid (chunks of 16 samples, paths)
+__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_fwd1_kernel(CgGateHead t) {
+  const CgGatePath& p = t.p[blockIdx.y];
+  const int B = t.B, C = t.C, S = t.S, K = C + S, KP = (K + 3) & ~3;
+  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [KP][CP]  Wl transposed, rows K .. KP-1 zero
+  float* sU = sWl + KP * CG_GATE_CP;                                  // [WAVES][KP] input rows of this workgroup's samples
+  float* sAff = sU + CG_GATE_WAVES * KP;                              // [CP][4] mean, rstd, scale, beta
+  double* sRed = reinterpret_cast<double*>(sAff + CG_GATE_CP * 4);    // an even number of floats in front of it
+  const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
+  const int b = (int)blockIdx.x * CG_GATE_WAVES + wave;
+  const bool drop = t.train && t.drop_p > 0.f;
+  const unsigned long long seed = drop ? *t.seed : 0ull;
+  // this sample's row of z and of the statistics travel while the weights are staged and the batch is summed
+  const float zv = (b < B && lane < C) ? p.z[(long long)b * C + lane] : 0.f;
+  float st[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) st[q] = (b < B && lane + 64 * q < S) ? p.stats[(long long)b * p.stats_ld + lane + 64 * q] : 0.f;
+  for (int e = tid; e < (KP - K) * CG_GATE_CP; e += CG_GATE_THREADS) sWl[K * CG_GATE_CP + e] = 0.f;
+  for (int e = tid; e < C * K; e += CG_GATE_THREADS) { const int o = e / K, i = e - o * K; sWl[i * CG_GATE_CP + o] = p.Wl[e]; }
+  double s1 = 0.0, s2 = 0.0;
+  if (t.train) cg_gate_batch_sums(p.z, nullptr, 0.f, 0.f, B, C, sRed, wave, lane, s1, s2);
   if (wave == 0 && lane < C) {
-    const CgGateAff a = cg_gate_aff_fwd(p.bn2, lane, C, B, t.train, s1, s2);
+    const CgGateAff a = cg_gate_aff_fwd(p.bn2, lane, C, B, t.train, s1, s2, blockIdx.x == 0);
     float* k = sAff + 4 * lane;
     k[0] = a.mean; k[1] = a.rstd; k[2] = a.scale; k[3] = a.beta;
   }
   __syncthreads();
-  const float alpha2 = p.alpha2[0], alpha3 = p.alpha3[0];
-  // ---- y = Wl [PReLU(Dropout(BN(z))) | stats], sixteen samples per round (a wave = a sample)
-  s1 = 0.0; s2 = 0.0;
-  float st0 = 0.f, st1 = 0.f, st2 = 0.f;                 // statistics columns C + lane (+ 64, + 128) of the next round's sample
-  auto load_stats = [&](int b) {
-    const float* row = p.stats + (long long)b * p.stats_ld;
-    st0 = (b < B && lane < S) ? row[lane] : 0.f;
-    st1 = (b < B && lane + 64 < S) ? row[lane + 64] : 0.f;
-    st2 = (b < B && lane + 128 < S) ? row[lane + 128] : 0.f;
-  };
-  load_stats(wave);
+  if (b < B) {
+    float* u = sU + wave * KP;
+    if (lane < C) {
+      const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
+      const float uu = cg_gate_u(sAff + 4 * lane, zv, keep);
+      const float v = uu > 0.f ? uu : p.alpha2[0] * uu;
+      if (p.tap2) p.tap2[(long long)b * C + lane] = v;
+      u[lane] = v;
+    }
 #pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b = wave + CG_GATE_WAVES * k;
-    if (CG_GATE_WAVES * k >= B) break;                                 // uniform
-    __syncthreads();
-    if (b < B) {
-      float* u = sU + wave * KP;
-      if (lane < C) {
-        const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
-        const float uu = cg_gate_u(sAff + 4 * lane, zreg[k], keep);
-        const float v = uu > 0.f ? uu : alpha2 * uu;
-        if (p.tap2) p.tap2[(long long)b * C + lane] = v;
-        u[lane] = v;
-      }
-      if (lane < S) u[C + lane] = st0;
-      if (lane + 64 < S) u[C + lane + 64] = st1;
-      if (lane + 128 < S) u[C + lane + 128] = st2;
-      for (int i = K + lane; i < KP; i += CG_WAVE) u[i] = 0.f;
-    }
-    load_stats(b + CG_GATE_WAVES);
-    __syncthreads();
-    if (b < B && lane < C) {
-      const float* u = sU + wave * KP;
-      float acc = 0.f;
-      for (int i = 0; i < KP; i += 4) {
-        const float4 uv = *reinterpret_cast<const float4*>(u + i);      // the same address in every lane: a broadcast
-        acc += sWl[i * CG_GATE_CP + lane] * uv.x;
-        acc += sWl[(i + 1) * CG_GATE_CP + lane] * uv.y;
-        acc += sWl[(i + 2) * CG_GATE_CP + lane] * uv.z;
-        acc += sWl[(i + 3) * CG_GATE_CP + lane] * uv.w;
-      }
-      yreg[k] = acc;
-      p.y[(long long)b * C + lane] = acc;
-      s1 += (double)acc; s2 += (double)acc * (double)acc;
-    }
+    for (int q = 0; q < 3; ++q) if (lane + 64 * q < S) u[C + lane + 64 * q] = st[q];
+    for (int i = K + lane; i < KP; i += CG_WAVE) u[i] = 0.f;
   }
-  // ---- BatchNorm1d of y over the batch
-  s1 = cg_gate_colsum(s1, sRed, wave, lane);
-  s2 = cg_gate_colsum(s2, sRed, wave, lane);
+  __syncthreads();
+  if (b < B && lane < C) {
+    const float* u = sU + wave * KP;
+    float acc = 0.f;
+    for (int i = 0; i < KP; i += 4) {
+      const float4 uv = *reinterpret_cast<const float4*>(u + i);        // the same address in every lane: a broadcast
+      acc += sWl[i * CG_GATE_CP + lane] * uv.x;
+      acc += sWl[(i + 1) * CG_GATE_CP + lane] * uv.y;
+      acc += sWl[(i + 2) * CG_GATE_CP + lane] * uv.z;
+      acc += sWl[(i + 3) * CG_GATE_CP + lane] * uv.w;
+    }
+    p.y[(long long)b * C + lane] = acc;
+  }
+}
+
+// forward, launch 2:  w = W2 PReLU(Dropout(BN1d(y)))
+__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_fwd2_kernel(CgGateHead t) {
+  const CgGatePath& p = t.p[blockIdx.y];
+  const int B = t.B, C = t.C;
+  float* sW2 = reinterpret_cast<float*>(cg_dyn_lds);                 // [C][CP]   W2 transposed
+  float* sU = sW2 + C * CG_GATE_CP;                                   // [WAVES][CP]
+  float* sAff = sU + CG_GATE_WAVES * CG_GATE_CP;
+  double* sRed = reinterpret_cast<double*>(sAff + CG_GATE_CP * 4);
+  const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
+  const int b = (int)blockIdx.x * CG_GATE_WAVES + wave;
+  const bool drop = t.train && t.drop_p > 0.f;
+  const unsigned long long seed = drop ? *t.seed : 0ull;
+  const float yv = (b < B && lane < C) ? p.y[(long long)b * C + lane] : 0.f;
+  for (int e = tid; e < C * C; e += CG_GATE_THREADS) { const int o = e / C, j = e - o * C; sW2[j * CG_GATE_CP + o] = p.W2[e]; }
+  double s1 = 0.0, s2 = 0.0;
+  if (t.train) cg_gate_batch_sums(p.y, nullptr, 0.f, 0.f, B, C, sRed, wave, lane, s1, s2);
   if (wave == 0 && lane < C) {
-    const CgGateAff a = cg_gate_aff_fwd(p.bn3, lane, C, B, t.train, s1, s2);
-    float* k = sAff + 4 * (CG_GATE_CP + lane);
+    const CgGateAff a = cg_gate_aff_fwd(p.bn3, lane, C, B, t.train, s1, s2, blockIdx.x == 0);
+    float* k = sAff + 4 * lane;
     k[0] = a.mean; k[1] = a.rstd; k[2] = a.scale; k[3] = a.beta;
   }
   __syncthreads();
-  // ---- w = W2 PReLU(Dropout(BN(y)))
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b = wave + CG_GATE_WAVES * k;
-    if (CG_GATE_WAVES * k >= B) break;
-    __syncthreads();
-    if (b < B && lane < C) {
-      const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
-      const float uu = cg_gate_u(sAff + 4 * (CG_GATE_CP + lane), yreg[k], keep);
-      const float v = uu > 0.f ? uu : alpha3 * uu;
-      if (p.tap3) p.tap3[(long long)b * C + lane] = v;
-      sU[wave * KP + lane] = v;
-    }
-    __syncthreads();
-    if (b < B && lane < C) {
-      const float* h = sU + wave * KP;
-      float acc = 0.f;
-      for (int j = 0; j < C; ++j) acc += sW2[j * CG_GATE_CP + lane] * h[j];
-      p.w[(long long)b * C + lane] = acc;
-    }
+  if (b < B && lane < C) {
+    const float keep = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
+    const float uu = cg_gate_u(sAff + 4 * lane, yv, keep);
+    const float v = uu > 0.f ? uu : p.alpha3[0] * uu;
+    if (p.tap3) p.tap3[(long long)b * C + lane] = v;
+    sU[wave * CG_GATE_CP + lane] = v;
+  }
+  __syncthreads();
+  if (b < B && lane < C) {
+    const float* h = sU + wave * CG_GATE_CP;
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc += sW2[j * CG_GATE_CP + lane] * h[j];
+    p.w[(long long)b * C + lane] = acc;
   }
 }
 
 // ======================================================================================================================
-#define CG_GATE_ACC2 4          // C * C <= THREADS * ACC2
-#define CG_GATE_ACCL 11         // C * (C + S) <= THREADS * ACCL (64 x 166 = 10624 <= 11264)
-
-__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_head_bwd_kernel(CgGateHead t) {
-  const CgGatePath& p = t.p[blockIdx.x];
-  const int B = t.B, C = t.C, S = t.S, K = C + S, KP = (K + 3) & ~3;
-  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [C][K]   Wl as it lies in memory
-  float* sW2 = sWl + C * K;                                           // [C][C]
-  float* sA = sW2 + C * C;                                            // [WAVES][CP] dw rows, then dy rows
-  float* sH = sA + CG_GATE_WAVES * CG_GATE_CP;                        // [WAVES][KP] h3 rows, then u rows
-  float* sAff = sH + CG_GATE_WAVES * KP;                              // [2][CP][4]
-  double* sRed = reinterpret_cast<double*>(sAff + 2 * CG_GATE_CP * 4 + ((C * K + C * C) & 1));
-  __shared__ float sM[2][CG_GATE_CP][2];
-  __shared__ double sAlpha[CG_GATE_CP];
+// backward, launch 1: through the last Linear and the PReLU / Dropout behind bn3 -> G3 (gradient in front of bn3); dW2, slope sum
+__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_bwd1_kernel(CgGateHead t) {
+  const CgGatePath& p = t.p[blockIdx.y];
+  const int B = t.B, C = t.C;
+  float* sW2 = reinterpret_cast<float*>(cg_dyn_lds);                 // [C][C] as it lies in memory
+  float* sA = sW2 + C * C;                                            // [WAVES][CP] dw rows
+  float* sH = sA + CG_GATE_WAVES * CG_GATE_CP;                        // [WAVES][CP] h3 rows
+  double* sRed = reinterpret_cast<double*>(sH + CG_GATE_WAVES * CG_GATE_CP + ((C * C) & 1));
   const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
+  const int b0 = (int)blockIdx.x * CG_GATE_WAVES, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
   const bool drop = t.train && t.drop_p > 0.f;
   const unsigned long long seed = drop ? *t.seed : 0ull;
-  // this thread's share of the batch (samples wave + 16 k, column lane) lives in registers through all three phases: dw / y / z are loaded
-  // once, the gradients in front of the two BatchNorms (g3, g2) never leave the registers
-  float ra[CG_GATE_NS], ry[CG_GATE_NS], rg[CG_GATE_NS];               // ra: dw, later z; ry: y; rg: g3, later g2
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b = wave + CG_GATE_WAVES * k;
-    const bool ok = b < B && lane < C;
-    ra[k] = ok ? p.dw[(long long)b * C + lane] : 0.f;
-    ry[k] = ok ? p.y[(long long)b * C + lane] : 0.f;
-    rg[k] = 0.f;
-  }
-  for (int e = tid; e < C * K; e += CG_GATE_THREADS) sWl[e] = p.Wl[e];
+  const bool ok = b < B && lane < C;
+  const float dwv = ok ? p.dw[(long long)b * C + lane] : 0.f, yv = ok ? p.y[(long long)b * C + lane] : 0.f;
   for (int e = tid; e < C * C; e += CG_GATE_THREADS) sW2[e] = p.W2[e];
+  float u3 = 0.f, keep3 = 1.f;
+  const float alpha3 = p.alpha3[0];
+  if (ok) {
+    const CgGateAff a3 = cg_gate_aff_bwd(p.bn3, lane, C);
+    const float k3[4] = {a3.mean, a3.rstd, a3.scale, a3.beta};
+    keep3 = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
+    u3 = cg_gate_u(k3, yv, keep3);
+    sA[wave * CG_GATE_CP + lane] = dwv;
+    sH[wave * CG_GATE_CP + lane] = u3 > 0.f ? u3 : alpha3 * u3;
+  }
+  __syncthreads();
+  double SA = 0.0;
+  if (ok) {
+    const float* dwr = sA + wave * CG_GATE_CP;
+    float dh = 0.f;
+    for (int o = 0; o < C; ++o) dh += dwr[o] * sW2[o * C + lane];
+    const float gu = u3 > 0.f ? dh : alpha3 * dh;
+    if (!(u3 > 0.f)) SA = (double)dh * (double)u3;
+    p.scratch[(long long)b * C + lane] = gu * keep3;
+  }
+  for (int e = tid; e < C * C; e += CG_GATE_THREADS) {
+    const int o = e / C, j = e - o * C;
+    float a = 0.f;
+    for (int w = 0; w < nb; ++w) a += sA[w * CG_GATE_CP + o] * sH[w * CG_GATE_CP + j];
+    atomicAdd(&p.dW2[e], a);
+  }
+  SA = cg_gate_colsum(SA, sRed, wave, lane);
+  if (wave == 0) {
+    SA = cg_wave_sum(lane < C ? SA : 0.0);
+    if (lane == 0) atomicAdd(&p.red[1], SA);
+  }
+}
+
+// backward, launch 2: through bn3 and the first Linear -> the statistics' gradient, G2 (gradient in front of bn2); dWl, slope sum
+__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_bwd2_kernel(CgGateHead t) {
+  const CgGatePath& p = t.p[blockIdx.y];
+  const int B = t.B, C = t.C, S = t.S, K = C + S, KP = (K + 3) & ~3;
+  float* sWl = reinterpret_cast<float*>(cg_dyn_lds);                 // [C][K] as it lies in memory
+  float* sA = sWl + C * K;                                            // [WAVES][CP] dy rows
+  float* sH = sA + CG_GATE_WAVES * CG_GATE_CP;                        // [WAVES][KP] u rows
+  double* sRed = reinterpret_cast<double*>(sH + CG_GATE_WAVES * KP + ((C * K) & 1));
+  __shared__ float sM[CG_GATE_CP][2];
+  const float* G3 = p.scratch;
+  float* G2 = p.scratch + (long long)B * C;
+  const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
+  const int b0 = (int)blockIdx.x * CG_GATE_WAVES, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
+  const bool drop = t.train && t.drop_p > 0.f;
+  const unsigned long long seed = drop ? *t.seed : 0ull;
+  const bool ok = b < B && lane < C;
+  const float gv = ok ? G3[(long long)b * C + lane] : 0.f, yv = ok ? p.y[(long long)b * C + lane] : 0.f, zv = ok ? p.z[(long long)b * C + lane] : 0.f;
+  float st[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) st[q] = (b < B && lane + 64 * q < S) ? p.stats[(long long)b * p.stats_ld + lane + 64 * q] : 0.f;
+  for (int e = tid; e < C * K; e += CG_GATE_THREADS) sWl[e] = p.Wl[e];
+  CgGateAff a3 = {0.f, 0.f, 0.f, 0.f}, a2 = a3;
+  if (lane < C) { a3 = cg_gate_aff_bwd(p.bn3, lane, C); a2 = cg_gate_aff_bwd(p.bn2, lane, C); }
+  double S1, S2;
+  cg_gate_batch_sums(G3, p.y, a3.mean, a3.rstd, B, C, sRed, wave, lane, S1, S2);
   if (wave == 0 && lane < C) {
-    const CgGateAff a2 = cg_gate_aff_bwd(p.bn2, lane, C), a3 = cg_gate_aff_bwd(p.bn3, lane, C);
-    float* k = sAff + 4 * lane;
-    k[0] = a2.mean; k[1] = a2.rstd; k[2] = a2.scale; k[3] = a2.beta;
-    k = sAff + 4 * (CG_GATE_CP + lane);
-    k[0] = a3.mean; k[1] = a3.rstd; k[2] = a3.scale; k[3] = a3.beta;
+    sM[lane][0] = t.train ? (float)(S1 / (double)B) : 0.f; sM[lane][1] = t.train ? (float)(S2 / (double)B) : 0.f;
+    if (blockIdx.x == 0) { p.dgamma3[lane] = (float)S2; p.dbeta3[lane] = (float)S1; if (lane == 0) p.dalpha3[0] = (float)p.red[1]; }
   }
   __syncthreads();
-  const float alpha2 = p.alpha2[0], alpha3 = p.alpha3[0];
-  float acc2[CG_GATE_ACC2], accl[CG_GATE_ACCL];
-#pragma unroll
-  for (int q = 0; q < CG_GATE_ACC2; ++q) acc2[q] = 0.f;
-#pragma unroll
-  for (int q = 0; q < CG_GATE_ACCL; ++q) accl[q] = 0.f;
-
-  // ---- phase 1: through the last Linear and the PReLU / Dropout behind bn3; dW2
-  double S1 = 0.0, S2 = 0.0, SA = 0.0;
-  const float* k3 = sAff + 4 * (CG_GATE_CP + lane);
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b0 = CG_GATE_WAVES * k, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
-    if (b0 >= B) break;                                                // uniform
-    __syncthreads();
-    float u3 = 0.f, keep3 = 1.f;
-    if (b < B && lane < C) {
-      sA[wave * CG_GATE_CP + lane] = ra[k];
-      keep3 = drop ? cg_drop_scale(t.drop_p, seed, p.salt3, (unsigned long long)b * C + lane) : 1.f;
-      u3 = cg_gate_u(k3, ry[k], keep3);
-      sH[wave * KP + lane] = u3 > 0.f ? u3 : alpha3 * u3;
-    }
-    __syncthreads();
-    if (b < B && lane < C) {
-      const float* dwr = sA + wave * CG_GATE_CP;
-      float dh = 0.f;
-      for (int o = 0; o < C; ++o) dh += dwr[o] * sW2[o * C + lane];
-      const float gu = u3 > 0.f ? dh : alpha3 * dh;
-      if (!(u3 > 0.f)) SA += (double)dh * (double)u3;
-      const float g = gu * keep3;
-      S1 += (double)g; S2 += (double)g * (double)((ry[k] - k3[0]) * k3[1]);
-      rg[k] = g;
+  float u2 = 0.f, keep2 = 1.f;
+  const float alpha2 = p.alpha2[0];
+  if (b < B) {
+    float* u = sH + wave * KP;
+    if (lane < C) {
+      sA[wave * CG_GATE_CP + lane] = a3.scale * (gv - sM[lane][0] - (yv - a3.mean) * a3.rstd * sM[lane][1]);
+      const float k2[4] = {a2.mean, a2.rstd, a2.scale, a2.beta};
+      keep2 = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
+      u2 = cg_gate_u(k2, zv, keep2);
+      u[lane] = u2 > 0.f ? u2 : alpha2 * u2;
     }
 #pragma unroll
-    for (int q = 0; q < CG_GATE_ACC2; ++q) {
-      const int e = tid + CG_GATE_THREADS * q;
-      if (e < C * C) {
-        const int o = e / C, j = e - o * C;
-        float a = 0.f;
-        for (int w = 0; w < nb; ++w) a += sA[w * CG_GATE_CP + o] * sH[w * KP + j];
-        acc2[q] += a;
+    for (int q = 0; q < 3; ++q) if (lane + 64 * q < S) u[C + lane + 64 * q] = st[q];
+  }
+  __syncthreads();
+  double SA = 0.0;
+  if (b < B) {
+    const float* dyr = sA + wave * CG_GATE_CP;
+    for (int i = lane; i < K; i += CG_WAVE) {
+      float du = 0.f;
+      for (int o = 0; o < C; ++o) du += dyr[o] * sWl[o * K + i];
+      if (i >= C) p.dstats[(long long)b * S + (i - C)] = du;
+      else {                                                              // i == lane
+        const float gu = u2 > 0.f ? du : alpha2 * du;
+        if (!(u2 > 0.f)) SA = (double)du * (double)u2;
+        G2[(long long)b * C + lane] = gu * keep2;
       }
     }
   }
-  // z of this thread's samples replaces dw; the statistics rows of the first round are requested
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b = wave + CG_GATE_WAVES * k;
-    ra[k] = (b < B && lane < C) ? p.z[(long long)b * C + lane] : 0.f;
+  for (int e = tid; e < C * K; e += CG_GATE_THREADS) {
+    const int o = e / K, i = e - o * K;
+    float a = 0.f;
+    for (int w = 0; w < nb; ++w) a += sA[w * CG_GATE_CP + o] * sH[w * KP + i];
+    atomicAdd(&p.dWl[e], a);
   }
-  float st0 = 0.f, st1 = 0.f, st2 = 0.f;
-  auto load_stats = [&](int b) {
-    const float* row = p.stats + (long long)b * p.stats_ld;
-    st0 = (b < B && lane < S) ? row[lane] : 0.f;
-    st1 = (b < B && lane + 64 < S) ? row[lane + 64] : 0.f;
-    st2 = (b < B && lane + 128 < S) ? row[lane + 128] : 0.f;
-  };
-  load_stats(wave);
-  S1 = cg_gate_colsum(S1, sRed, wave, lane);
-  S2 = cg_gate_colsum(S2, sRed, wave, lane);
   SA = cg_gate_colsum(SA, sRed, wave, lane);
   if (wave == 0) {
-    if (lane < C) {
-      sM[1][lane][0] = t.train ? (float)(S1 / (double)B) : 0.f; sM[1][lane][1] = t.train ? (float)(S2 / (double)B) : 0.f;
-      p.dgamma3[lane] = (float)S2; p.dbeta3[lane] = (float)S1;
-    }
-    sAlpha[lane] = lane < C ? SA : 0.0;
+    SA = cg_wave_sum(lane < C ? SA : 0.0);
+    if (lane == 0) atomicAdd(&p.red[0], SA);
+  }
+}
+
+// backward, launch 3: through bn2 -> dz
+__global__ __launch_bounds__(CG_GATE_THREADS) void cg_gate_bwd3_kernel(CgGateHead t) {
+  const CgGatePath& p = t.p[blockIdx.y];
+  const int B = t.B, C = t.C;
+  double* sRed = reinterpret_cast<double*>(cg_dyn_lds);
+  const float* G2 = p.scratch + (long long)B * C;
+  const int tid = threadIdx.x, lane = tid & (CG_WAVE - 1), wave = tid / CG_WAVE;
+  const int b = (int)blockIdx.x * CG_GATE_WAVES + wave;
+  const bool ok = b < B && lane < C;
+  const float gv = ok ? G2[(long long)b * C + lane] : 0.f, zv = ok ? p.z[(long long)b * C + lane] : 0.f;
+  CgGateAff a2 = {0.f, 0.f, 0.f, 0.f};
+  if (lane < C) a2 = cg_gate_aff_bwd(p.bn2, lane, C);
+  double S1, S2;
+  cg_gate_batch_sums(G2, p.z, a2.mean, a2.rstd, B, C, sRed, wave, lane, S1, S2);
+  __shared__ float sM[CG_GATE_CP][2];
+  if (wave == 0 && lane < C) {
+    sM[lane][0] = t.train ? (float)(S1 / (double)B) : 0.f; sM[lane][1] = t.train ? (float)(S2 / (double)B) : 0.f;
+    if (blockIdx.x == 0) { p.dgamma2[lane] = (float)S2; p.dbeta2[lane] = (float)S1; if (lane == 0) p.dalpha2[0] = (float)p.red[0]; }
   }
   __syncthreads();
-  if (tid == 0) { double s = 0.0; for (int c = 0; c < C; ++c) s += sAlpha[c]; p.dalpha3[0] = (float)s; }
-
-  // ---- phase 2: through bn3 and the first Linear; the statistics' gradient; PReLU / Dropout behind bn2; dWl
-  S1 = 0.0; S2 = 0.0; SA = 0.0;
-  const float* k2 = sAff + 4 * lane;
-#pragma unroll
-  for (int k = 0; k < CG_GATE_NS; ++k) {
-    const int b0 = CG_GATE_WAVES * k, b = b0 + wave, nb = min(CG_GATE_WAVES, B - b0);
-    if (b0 >= B) break;
-    __syncthreads();
-    float u2 = 0.f, keep2 = 1.f;
-    if (b < B) {
-      float* u = sH + wave * KP;
-      if (lane < C) {
-        const float xh = (ry[k] - k3[0]) * k3[1];
-        sA[wave * CG_GATE_CP + lane] = k3[2] * (rg[k] - sM[1][lane][0] - xh * sM[1][lane][1]);
-        keep2 = drop ? cg_drop_scale(t.drop_p, seed, p.salt2, (unsigned long long)b * C + lane) : 1.f;
-        u2 = cg_gate_u(k2, ra[k], keep2);
-        u[lane] = u2 > 0.f ? u2 : alpha2 * u2;
-      }
-      if (lane < S) u[C + lane] = st0;
-      if (lane + 64 < S) u[C + lane + 64] = st1;
-      if (lane + 128 < S) u[C + lane + 128] = st2;
-    }
-    load_stats(b + CG_GATE_WAVES);
-    __syncthreads();
-    if (b < B) {
-      const float* dyr = sA + wave * CG_GATE_CP;
-      for (int i = lane; i < K; i += CG_WAVE) {
-        float du = 0.f;
-        for (int o = 0; o < C; ++o) du += dyr[o] * sWl[o * K + i];
-        if (i >= C) p.dstats[(long long)b * S + (i - C)] = du;
-        else {                                                            // i == lane
-          const float gu = u2 > 0.f ? du : alpha2 * du;
-          if (!(u2 > 0.f)) SA += (double)du * (double)u2;
-          const float g = gu * keep2;
-          S1 += (double)g; S2 += (double)g * (double)((ra[k] - k2[0]) * k2[1]);
-          rg[k] = g;
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < CG_GATE_ACCL; ++q) {
-      const int e = tid + CG_GATE_THREADS * q;
-      if (e < C * K) {
-        const int o = e / K, i = e - o * K;
-        float a = 0.f;
-        for (int w = 0; w < nb; ++w) a += sA[w * CG_GATE_CP + o] * sH[w * KP + i];
-        accl[q] += a;
-      }
-    }
-  }
-  S1 = cg_gate_colsum(S1, sRed, wave, lane);
-  S2 = cg_gate_colsum(S2, sRed, wave, lane);
-  SA = cg_gate_colsum(SA, sRed, wave, lane);
-  if (wave == 0) {
-    if (lane < C) {
-      sM[0][lane][0] = t.train ? (float)(S1 / (double)B) : 0.f; sM[0][lane][1] = t.train ? (float)(S2 / (double)B) : 0.f;
-      p.dgamma2[lane] = (float)S2; p.dbeta2[lane] = (float)S1;
-    }
-    sAlpha[lane] = lane < C ? SA : 0.0;
-  }
-  __syncthreads();
-  if (tid == 0) { double s = 0.0; for (int c = 0; c < C; ++c) s += sAlpha[c]; p.dalpha2[0] = (float)s; }
-
-  // ---- phase 3: through bn2
-  if (lane < C) {
-#pragma unroll
-    for (int k = 0; k < CG_GATE_NS; ++k) {
-      const int b = wave + CG_GATE_WAVES * k;
-      if (b < B) {
-        const float xh = (ra[k] - k2[0]) * k2[1];
-        p.dz[(long long)b * C + lane] = k2[2] * (rg[k] - sM[0][lane][0] - xh * sM[0][lane][1]);
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < CG_GATE_ACC2; ++q) { const int e = tid + CG_GATE_THREADS * q; if (e < C * C) p.dW2[e] = acc2[q]; }
-#pragma unroll
-  for (int q = 0; q < CG_GATE_ACCL; ++q) { const int e = tid + CG_GATE_THREADS * q; if (e < C * K) p.dWl[e] = accl[q]; }
+  if (ok) p.dz[(long long)b * C + lane] = a2.scale * (gv - sM[lane][0] - (zv - a2.mean) * a2.rstd * sM[lane][1]);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int cg_gate_check(const CgGateHead* t, bool bwd) {
   if (!t || t->n < 1 || t->n > 2) return CG_EARG;
-  if (t->B <= 0 || t->B > CG_GATE_WAVES * CG_GATE_NS || t->C <= 0 || t->C > CG_GATE_MAXC || t->S < 0 || t->S > CG_GATE_MAXS) return CG_ESHAPE;
+  if (t->B <= 0 || t->B > 65535 * CG_GATE_WAVES || t->C <= 0 || t->C > CG_GATE_MAXC || t->S < 0 || t->S > CG_GATE_MAXS) return CG_ESHAPE;
   if (t->train && t->B < 2) return CG_ESHAPE;
   if (t->train && t->drop_p > 0.f && !t->seed) return CG_EARG;
   if (t->drop_p < 0.f || t->drop_p >= 1.f) return CG_EARG;
@@ -386,36 +333,50 @@ static int cg_gate_check(const CgGateHead* t, bool bwd) {
     if (!p.bn2.gamma || !p.bn2.beta || !p.bn2.save || !p.bn3.gamma || !p.bn3.beta || !p.bn3.save) return CG_EARG;
     if (!bwd && (!p.w || (!t->train && (!p.bn2.running_mean || !p.bn2.running_var || !p.bn3.running_mean || !p.bn3.running_var)))) return CG_EARG;
     if (bwd && (!p.dw || !p.dz || (t->S > 0 && !p.dstats) || !p.dWl || !p.dW2 || !p.dgamma2 || !p.dbeta2 || !p.dalpha2 || !p.dgamma3 || !p.dbeta3 ||
-                !p.dalpha3)) return CG_EARG;
+                !p.dalpha3 || !p.scratch || !p.red)) return CG_EARG;
   }
   return CG_OK;
 }
 
-extern "C" int cg_gate_head_supported(int B, int C, int S) {
-  return (B > 0 && B <= CG_GATE_WAVES * CG_GATE_NS && C > 0 && C <= CG_GATE_MAXC && S >= 0 && S <= CG_GATE_MAXS) ? 1 : 0;
-}
-extern "C" long long cg_gate_head_scratch_floats(int B, int C, int S) { (void)B; (void)C; (void)S; return 0; }      // the backward keeps its intermediates in registers
+extern "C" int cg_gate_head_supported(int B, int C, int S) { return (B > 0 && C > 0 && C <= CG_GATE_MAXC && S >= 0 && S <= CG_GATE_MAXS) ? 1 : 0; }
+// backward scratch per path: the gradients in front of the two BatchNorms
+extern "C" long long cg_gate_head_scratch_floats(int B, int C, int S) { (void)S; return (long long)2 * B * C; }
 
-// include/cistgcn_hip.h : cg_gate_head_fwd / cg_gate_head_bwd
+// include/cistgcn_hip.h : cg_gate_head_fwd (two launches) / cg_gate_head_bwd (three)
 extern "C" int cg_gate_head_fwd(const CgGateHead* t, void* stream_) {
   int st = cg_gate_check(t, false);
   if (st != CG_OK) return st;
+  hipStream_t stream = (hipStream_t)stream_;
   const int K = t->C + t->S, KP = (K + 3) & ~3;
-  const size_t lds = ((size_t)KP * CG_GATE_CP + (size_t)t->C * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + 2 * CG_GATE_CP * 4 + 1) * sizeof(float) +
-                     (size_t)CG_GATE_WAVES * CG_GATE_CP * sizeof(double);
-  if (lds > 64 * 1024 && cg_lds_limit((const void*)cg_gate_head_fwd_kernel, lds) != hipSuccess) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_gate_head_fwd_kernel, dim3((unsigned)t->n), dim3(CG_GATE_THREADS), lds, (hipStream_t)stream_, *t);
+  const dim3 grid((unsigned)((t->B + CG_GATE_WAVES - 1) / CG_GATE_WAVES), (unsigned)t->n), block(CG_GATE_THREADS);
+  const size_t red = (size_t)CG_GATE_WAVES * CG_GATE_CP * sizeof(double);
+  const size_t lds1 = ((size_t)KP * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + CG_GATE_CP * 4) * sizeof(float) + red;
+  if (lds1 > 64 * 1024 && cg_lds_limit((const void*)cg_gate_fwd1_kernel, lds1) != hipSuccess) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_gate_fwd1_kernel, grid, block, lds1, stream, *t);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  const size_t lds2 = ((size_t)t->C * CG_GATE_CP + (size_t)CG_GATE_WAVES * CG_GATE_CP + CG_GATE_CP * 4) * sizeof(float) + red;
+  hipLaunchKernelGGL(cg_gate_fwd2_kernel, grid, block, lds2, stream, *t);
   return cg_launch_status();
 }
 
+// dW2 / dWl (accumulated with float atomics over the chunks) and red[0..1] must be zero on entry
 extern "C" int cg_gate_head_bwd(const CgGateHead* t, void* stream_) {
   int st = cg_gate_check(t, true);
   if (st != CG_OK) return st;
+  hipStream_t stream = (hipStream_t)stream_;
   const int K = t->C + t->S, KP = (K + 3) & ~3;
-  if ((long long)t->C * t->C > (long long)CG_GATE_THREADS * CG_GATE_ACC2 || (long long)t->C * K > (long long)CG_GATE_THREADS * CG_GATE_ACCL) return CG_ESHAPE;
-  const size_t lds = ((size_t)t->C * K + (size_t)t->C * t->C + (size_t)CG_GATE_WAVES * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + 2 * CG_GATE_CP * 4 + 1) * sizeof(float) +
-                     (size_t)CG_GATE_WAVES * CG_GATE_CP * sizeof(double);
-  if (lds > 64 * 1024 && cg_lds_limit((const void*)cg_gate_head_bwd_kernel, lds) != hipSuccess) return CG_ESHAPE;
-  hipLaunchKernelGGL(cg_gate_head_bwd_kernel, dim3((unsigned)t->n), dim3(CG_GATE_THREADS), lds, (hipStream_t)stream_, *t);
+  const dim3 grid((unsigned)((t->B + CG_GATE_WAVES - 1) / CG_GATE_WAVES), (unsigned)t->n), block(CG_GATE_THREADS);
+  const size_t red = (size_t)CG_GATE_WAVES * CG_GATE_CP * sizeof(double);
+  const size_t lds1 = ((size_t)t->C * t->C + (size_t)2 * CG_GATE_WAVES * CG_GATE_CP + 1) * sizeof(float) + red;
+  hipLaunchKernelGGL(cg_gate_bwd1_kernel, grid, block, lds1, stream, *t);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  const size_t lds2 = ((size_t)t->C * K + (size_t)CG_GATE_WAVES * CG_GATE_CP + (size_t)CG_GATE_WAVES * KP + 1) * sizeof(float) + red;
+  if (lds2 > 64 * 1024 && cg_lds_limit((const void*)cg_gate_bwd2_kernel, lds2) != hipSuccess) return CG_ESHAPE;
+  hipLaunchKernelGGL(cg_gate_bwd2_kernel, grid, block, lds2, stream, *t);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  hipLaunchKernelGGL(cg_gate_bwd3_kernel, grid, block, red, stream, *t);
   return cg_launch_status();
 }

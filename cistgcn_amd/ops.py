@@ -1867,10 +1867,12 @@ class _GateHead(torch.autograd.Function):
             d = d if d.is_contiguous() else _copy(d)
             dz = torch.empty(B, C, dtype=f32, device=dev)
             dst = torch.empty(B, S, dtype=f32, device=dev)
-            dwl, dw2 = torch.empty(C, C + S, dtype=f32, device=dev), torch.empty(C, C, dtype=f32, device=dev)
+            zw, _ = _zeros(C * (C + S) + C * C, dev)                         # accumulated with float atomics over the chunks of the batch
+            dwl, dw2 = zw[:C * (C + S)].view(C, C + S), zw[C * (C + S):].view(C, C)
             small = torch.empty(6, C, dtype=f32, device=dev)
             scr = torch.empty(max(nscr, 1), dtype=f32, device=dev)
             q = t.p[i]
+            q.red = _arena(dev).take(2).data_ptr()
             q.dw, q.dz, q.dstats, q.dWl, q.dW2, q.scratch = d.data_ptr(), dz.data_ptr(), dst.data_ptr(), dwl.data_ptr(), dw2.data_ptr(), scr.data_ptr()
             q.dgamma2, q.dbeta2, q.dalpha2, q.dgamma3, q.dbeta3, q.dalpha3 = (small[k].data_ptr() for k in range(6))
             keep += [d, scr]
