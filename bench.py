@@ -97,6 +97,7 @@ FAM_ROWSCONV = "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)"
 FAM_FPN = "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)"
 FAM_STATS = "block input: global_norm + statistics (cg_block_input_fwd/bwd, cg_dstd_stats_fwd/bwd)"
 FAM_CTX = "ContextLayer heads (cg_context_heads_fwd/bwd)"
+FAM_GATE = "gate paths behind their (1,V) convolutions (cg_gate_head_fwd/bwd)"
 FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as rocprofv3 --kernel-trace reports them
     FAM_STGCN: ("cg_stgcn_", "cg_dom_fold"),
     FAM_TAIL: ("cg_tail_",),
@@ -108,6 +109,7 @@ FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as roc
     FAM_FPN: ("cg_fpn_",),
     FAM_STATS: ("cg_bin_", "cg_dstd_stats"),
     FAM_CTX: ("cg_ctx_",),
+    FAM_GATE: ("cg_gate_",),
 }
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")      # HBM bytes per family / per block from rocprofv3 PMC passes (tools/collect_profiles_r04.py)
 
@@ -183,6 +185,11 @@ def _call_bytes(name, args):
         n = 4 * t.B * t.C * t.T * t.V
         # forward: x -> xn; backward: the consumers' gradients and x -> dx (the stored sum G travels twice more: not algorithmic)
         return FAM_STATS, 2 * n if name.endswith("fwd") else (sum(1 for i in range(t.ng) if t.g[i]) + 2) * n
+    if name in ("cg_gate_head_fwd", "cg_gate_head_bwd"):
+        import ctypes
+        t = ctypes.cast(args[0], ctypes.POINTER(_lib.GateHead)).contents
+        per = 4 * t.B * (2 * t.C + t.S) + 4 * t.C * (2 * t.C + t.S)          # z, statistics, gate; both weight matrices
+        return FAM_GATE, t.n * per * (1 if name.endswith("fwd") else 2)
     if name in ("cg_context_heads_fwd", "cg_context_heads_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.CtxHeads)).contents
