@@ -163,10 +163,11 @@ def _host_can_run_the_fp64_oracle_at_full_size():
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("dropout", [0.0, 0.1], ids=["dropout0", "dropout0.1"])
+@pytest.mark.parametrize("dropout", [0.1] + ([0.0] if os.environ.get("CISTGCN_GPU_FULL", "0") == "1" else []), ids=lambda p: "dropout%s" % p)
 def test_full_size_train_matches_oracle(dropout):
-    """BASELINE configs[2] (CISTGCN-64, B=256, 50->25, V=22) in TRAIN mode against the CPU oracle directly - once with dropout 0 and
-    once as the benchmark runs it (dropout 0.1, the oracle applying the masks of the HIP run): prediction, loss, dL/dx, all 698
+    """BASELINE configs[2] (CISTGCN-64, B=256, 50->25, V=22) in TRAIN mode against the CPU oracle directly, as the benchmark runs it
+    (dropout 0.1, the oracle applying the masks of the HIP run; with CISTGCN_GPU_FULL=1 also with dropout 0 - 80 s more of fp64 CPU
+    work, passed in round 4 with the worst gradient at 0.10 of the bound): prediction, loss, dL/dx, all 698
     parameter gradients, Adj / w1 / w2 of every block, the ContextLayer maps and the updated running statistics.  This is the only
     size at which the persistent tile loops (several tiles per workgroup with prefetch), the statistics epilogues over thousands of
     workgroups, the plane kernels of the fused stage and many-rows-per-workgroup row kernels run.  The oracle runs in fp64 (its
