@@ -1,6 +1,6 @@
 // TEST-ONLY shim: lets the CPU-only build container execute the *same* .hip kernel sources that
-// ship for gfx950, by mapping every HIP thread of a workgroup to an OS thread (real barriers, real
-// shared memory semantics, wave-level shuffles through a per-wave exchange slot).  It exists so
+// ship for gfx950, by mapping every HIP thread of a workgroup to a fiber of its own (real barriers, real
+// shared memory semantics, wave-level shuffles through a per-wave exchange slot; see emu_runtime.cpp).  It exists so
 // that indexing / synchronisation bugs surface in `pytest -m "not gpu"`; it is never shipped,
 // never loaded by the product package, and has nothing to do with performance.
 #pragma once
@@ -14,7 +14,7 @@
 
 struct dim3 {
   unsigned x, y, z;
-  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+  constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float4 { float x, y, z, w; } __attribute__((aligned(16)));
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
@@ -22,8 +22,8 @@ struct uint4 { unsigned x, y, z, w; } __attribute__((aligned(16)));
 struct int4 { int x, y, z, w; } __attribute__((aligned(16)));
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
-extern thread_local dim3 threadIdx;
-extern dim3 blockIdx, blockDim, gridDim;
+extern thread_local dim3 threadIdx, blockIdx;      // per OS thread: one workgroup at a time runs on each (its HIP threads are fibers)
+extern dim3 blockDim, gridDim;
 
 #define CG_OPAQUE_V(x) ((void)(x))
 static inline void __builtin_amdgcn_sched_barrier(int) {}
@@ -35,8 +35,12 @@ static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y;
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__ static
-#define HIP_DYNAMIC_SHARED(type, var) extern type var[];
+#if defined(__SANITIZE_ADDRESS__)
+#define __shared__ static                   // sanitizer build: ONE workgroup in flight (emu_runtime.cpp), plain statics have redzones (thread_local ones do not)
+#else
+#define __shared__ static thread_local      // one copy per OS thread = per workgroup in flight
+#endif
+#define HIP_DYNAMIC_SHARED(type, var) extern thread_local type var[];
 
 typedef int hipError_t;
 enum { hipSuccess = 0 };
