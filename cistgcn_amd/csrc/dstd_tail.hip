@@ -104,6 +104,34 @@ __device__ __forceinline__ void cg_tail_consts(const CgDstdTail& t, float* sK, b
   }
 }
 
+// What the staging code of the matrix phases reads of the argument block for every quad, fetched ONCE per workgroup: the block lives in
+// kernel-argument memory, and the slopes behind pointers; read inside the staging loops they cost a scalar (or global) load and a full
+// wait per quad - found in the ISA in round 4.
+struct CgTailHot {
+  int C, P, train;
+  float drop_p;
+  unsigned int salt[2];
+  float alpha_p[2];
+  float* tap_a[2]; float* tap_x[2];
+};
+__device__ __forceinline__ CgTailHot cg_tail_hot(const CgDstdTail& t) {
+  CgTailHot h;
+  h.C = t.C; h.P = t.T * t.V; h.train = t.train; h.drop_p = t.drop_p;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    h.salt[i] = t.salt[i];
+    h.alpha_p[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t.alpha_p[i][0])));
+    h.tap_a[i] = t.tap_a[i]; h.tap_x[i] = t.tap_x[i];
+  }
+  return h;
+}
+__device__ __forceinline__ void cg_tail_keep4(const CgTailHot& h, int i, unsigned long long seed, unsigned long long idx0, float keep[4]) {
+  if (!(h.train && h.drop_p > 0.f)) { keep[0] = keep[1] = keep[2] = keep[3] = 1.f; return; }
+  const unsigned long long bits = cg_drop_bits(seed, h.salt[i], idx0 >> 2);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) keep[j] = cg_drop_pick(bits, j, h.drop_p);
+}
+
 // keep factors of the four consecutive elements idx0 .. idx0 + 3 (idx0 % 4 == 0): one hash, as cg_norm_act's float4 path
 __device__ __forceinline__ void cg_tail_keep4(const CgDstdTail& t, int i, unsigned long long seed, unsigned long long idx0, float keep[4]) {
   if (!(t.train && t.drop_p > 0.f)) { keep[0] = keep[1] = keep[2] = keep[3] = 1.f; return; }
@@ -138,10 +166,10 @@ __device__ __forceinline__ void cg_tail_act_load(const CgDstdTail& t, int b, int
 }
 
 template <int PT>
-__device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const float* sK, unsigned long long seed, int b, int p0, int np,
+__device__ __forceinline__ void cg_tail_act_finish(const CgTailHot& t, const float* sK, unsigned long long seed, int b, int p0, int np,
                                                    const float4 yq[PT / 8], const float4 rq[PT / 8], const float wq[PT / 8], float* img, int what) {
   constexpr int PS = PT + 4;
-  const int C = t.C, P = t.T * t.V;
+  const int C = t.C, P = t.P;
 #pragma unroll
   for (int q = 0; q < PT / 8; ++q) {
     const int i = q / (PT / 16), e = threadIdx.x + (q - i * (PT / 16)) * CG_TAIL_THREADS;       // same slots as cg_tail_act_load
@@ -154,7 +182,7 @@ __device__ __forceinline__ void cg_tail_act_finish(const CgDstdTail& t, const fl
       const float yv[4] = {yq[q].x, yq[q].y, yq[q].z, yq[q].w}, rv[4] = {rq[q].x, rq[q].y, rq[q].z, rq[q].w};
       float keep[4];
       cg_tail_keep4(t, i, seed, (unsigned long long)off, keep);
-      const float wv = wq[q], ap = t.alpha_p[i][0], scale_p = k1.z * k1.y;
+      const float wv = wq[q], ap = t.alpha_p[i], scale_p = k1.z * k1.y;
       float xv[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -235,8 +263,13 @@ __device__ __forceinline__ void cg_tail_stage_act(const CgDstdTail& t, const flo
 // ======================================================================================================================
 // F2: h0[b][co][p] = sum_c2 Wc[co][c2] a[c2][p]  + channel sums of h0.   Persistent workgroups over (sample, 64 positions)
 // ======================================================================================================================
+// MT_ / NT2_: 16-row tiles of the C output channels / of the 2C stacked input channels as compile-time constants (0: taken from t.C at
+// run time - any width).  With the widths of the shipped configurations known to the compiler every matrix-core loop below unrolls with
+// constant LDS offsets and independent accumulator chains; the run-time form left them rolled: LDS read, full wait, four dependent
+// MFMAs per iteration (round 4, found in the ISA).
+template <int MT_, int NT2_>
 __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTail t, int tiles_per_sample, int total, int per) {
-  const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
+  const int C = t.C, C2 = 2 * C, CM = MT_ ? 16 * MT_ : (C + 15) & ~15, C2M = NT2_ ? 16 * NT2_ : (C2 + 15) & ~15, P = t.T * t.V;
   const int WS = C2M + 4;
   float* sAct = reinterpret_cast<float*>(cg_dyn_lds);            // [C2M][PS]
   float* sW = sAct + C2M * CG_TAIL_PS;                            // [CM][WS]
@@ -251,7 +284,9 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
   for (int e = tid; e < C * C2; e += CG_TAIL_THREADS) { const int co = e / C2, c2 = e - co * C2; sW[co * WS + c2] = t.Wc[e]; }
   cg_tail_consts(t, sK, false, wg == 0);
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const CgTailHot hot = cg_tail_hot(t);
   const int MT = CM / 16;
+  constexpr int nw = CG_TAIL_THREADS / 64;
   const bool vec = (P & 3) == 0;
   float4 yq[CG_TAIL_PT / 8], rq[CG_TAIL_PT / 8];
   float wq[CG_TAIL_PT / 8];
@@ -264,7 +299,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
     if (lid >= total) break;
     const int b = lid / tiles_per_sample, tile = lid - b * tiles_per_sample, p0 = tile * CG_TAIL_PT, np = min(CG_TAIL_PT, P - p0);
     __syncthreads();
-    if (vec) cg_tail_act_finish<CG_TAIL_PT>(t, sK, seed, b, p0, np, yq, rq, wq, sAct, 0);
+    if (vec) cg_tail_act_finish<CG_TAIL_PT>(hot, sK, seed, b, p0, np, yq, rq, wq, sAct, 0);
     else cg_tail_stage_act<CG_TAIL_PT>(t, sK, seed, b, p0, np, sAct, 0);
     __syncthreads();
     if (vec && it + 1 < per && lid + 1 < total) {          // the next tile's reads travel while the matrix cores work
@@ -272,19 +307,52 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
       cg_tail_act_load<CG_TAIL_PT>(t, b2, q0, min(CG_TAIL_PT, P - q0), yq, rq, wq);
     }
     float* hb = t.h0 + (long long)b * C * P + p0;
-    for (int w = wave; w < MT * 2; w += CG_TAIL_THREADS / 64) {          // (co tile, pair of position tiles)
+    // (co tile, pair of position tiles): MT * 2 tasks.  Known widths: the (up to two) tasks of a wave - co tiles w >> 1 and (w >> 1) + 2 on
+    // the SAME position pair - advance through k together: the activation fragments are read once, four independent MFMA chains
+    constexpr int NTASK = MT_ ? (2 * MT_ + nw - 1) / nw : 1;
+    cg_f32x4 facc[NTASK][2];
+    if (MT_) {
+#pragma unroll
+      for (int ti = 0; ti < NTASK; ++ti) facc[ti][0] = facc[ti][1] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (2 * MT_ >= nw || wave < 2 * MT_) {
+        const int n0 = 32 * (wave & 1);
+#pragma unroll
+        for (int k0 = 0; k0 < 16 * NT2_; k0 += 16) {                        // rows >= 2C of sAct and columns >= 2C of sW are zero
+          float b0v[4], b1v[4];
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sAct + n0, CG_TAIL_PS, l15, slot), CG_TAIL_PS, k0, b0v);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sAct + n0 + 16, CG_TAIL_PS, l15, slot), CG_TAIL_PS, k0, b1v);
+#pragma unroll
+          for (int ti = 0; ti < NTASK; ++ti) {
+            float av[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sW + 16 * ((wave >> 1) + (nw / 2) * ti) * WS, WS, l15, slot), WS, k0, av);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                                   // C[position 4 * slot + q][output channel l15]
+              facc[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], facc[ti][0], 0, 0, 0);
+              facc[ti][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], facc[ti][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ti = 0; ti < (MT_ ? NTASK : 2); ++ti) {                      // C <= 64: at most eight tasks
+      const int w = wave + nw * ti;
+      if (w >= MT * 2) break;
       const int mt = w >> 1, n0 = 32 * (w & 1), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * WS, WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sAct + n0, CG_TAIL_PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sAct + n1, CG_TAIL_PS, l15, slot);
-      for (int k0 = 0; k0 < C2M; k0 += 16) {                              // rows >= 2C of sAct and columns >= 2C of sW are zero
-        float av[4], b0v[4], b1v[4];
-        cg_tfrag<0>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
+      if (MT_) { c0 = facc[MT_ ? ti : 0][0]; c1 = facc[MT_ ? ti : 0][1]; }
+      else {
+        const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * WS, WS, l15, slot);
+        const float* bp0 = cg_tfrag_ptr<1>(sAct + n0, CG_TAIL_PS, l15, slot);
+        const float* bp1 = cg_tfrag_ptr<1>(sAct + n1, CG_TAIL_PS, l15, slot);
+        for (int k0 = 0; k0 < C2M; k0 += 16) {                              // rows >= 2C of sAct and columns >= 2C of sW are zero
+          float av[4], b0v[4], b1v[4];
+          cg_tfrag<0>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                                     // C[position 4 * slot + q][output channel l15]
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) {                                     // C[position 4 * slot + q][output channel l15]
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+          }
         }
       }
       // position-major tiles: a lane holds four consecutive positions of ONE output channel -> 16-byte stores of h0, channel sums
@@ -428,8 +496,9 @@ extern "C" int cg_tail_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 #endif
 
 // K3: per tile: dh0 (BatchNorm backward of g_c), d a = Wc^T dh0, dWc += dh0 a^T, g_p = d a * PReLU_p' -> HBM + its sums
+template <int MT_, int NT2_>
 __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTail t, int tiles_per_sample, int total, int per, int replicas) {
-  const int C = t.C, C2 = 2 * C, CM = (C + 15) & ~15, C2M = (C2 + 15) & ~15, P = t.T * t.V;
+  const int C = t.C, C2 = 2 * C, CM = MT_ ? 16 * MT_ : (C + 15) & ~15, C2M = NT2_ ? 16 * NT2_ : (C2 + 15) & ~15, P = t.T * t.V;
   const int WS = C2M + 4;
   float* sZ = reinterpret_cast<float*>(cg_dyn_lds);              // [C2M][PS]  zhat of both branches
   float* sDH = sZ + C2M * CG_TAIL_PS3;                             // [CM][PS]   dh0
@@ -455,6 +524,9 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     kc[4] = t.train ? (float)(t.red_c[2 * c] / cnt) : 0.f; kc[5] = t.train ? (float)(t.red_c[2 * c + 1] / cnt) : 0.f;
   }
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const CgTailHot hot = cg_tail_hot(t);
+  const bool train = t.train != 0;
+  float* const gp0 = t.gp[0]; float* const gp1 = t.gp[1];
   const int MT = CM / 16, NT2 = C2M / 16;
   const float invP = 1.f / (float)P;
   // dWc accumulators: tile (mt, n2) for id = u * nw + wave, kept in registers across all tiles of this workgroup
@@ -483,7 +555,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
       if (c < C && pp < np) {
         const long long off = ((long long)b * C + c) * P + p0 + pp;
         h4[q] = *reinterpret_cast<const float4*>(t.h0 + off); d4[q] = *reinterpret_cast<const float4*>(t.dout + off);
-        gt[q] = t.gate[(long long)b * C + c]; dp[q] = t.dpooled[(long long)b * C + c] * invP;
+        gt[q] = t.gate[(long long)b * C + c]; dp[q] = t.dpooled[(long long)b * C + c];     // raw: arithmetic on a loaded value would wait for it here
       }
     }
   };
@@ -499,7 +571,7 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     __syncthreads();
     CG_TSTAMP();
     if (vec) {
-      cg_tail_act_finish<CG_TAIL_PT3>(t, sK, seed, b, p0, np, yq, rq, wq, sZ, 1);
+      cg_tail_act_finish<CG_TAIL_PT3>(hot, sK, seed, b, p0, np, yq, rq, wq, sZ, 1);
       CG_TSTAMP();
       // dh0 = gamma_c * rstd * (g_c - mean(g_c) - h0hat * mean(g_c h0hat)); per-channel constants from sKc
 #pragma unroll
@@ -508,14 +580,15 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         if (c >= C) continue;
         float val[4] = {0.f, 0.f, 0.f, 0.f};
         if (pp < np) {
-          const float* kc = sKc + 8 * c;                  // mean, rstd, scale = gamma * rstd, beta, m1, m2
+          const float4 kcA = *reinterpret_cast<const float4*>(sKc + 8 * c);       // mean, rstd, scale = gamma * rstd, beta
+          const float2 kcB = *reinterpret_cast<const float2*>(sKc + 8 * c + 4);   // m1, m2
           const float hv[4] = {h4[q].x, h4[q].y, h4[q].z, h4[q].w}, dv[4] = {d4[q].x, d4[q].y, d4[q].z, d4[q].w};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float u = (hv[j] - kc[0]) * kc[2] + kc[3];
-            const float dh = dv[j] * gt[q] + dp[q];
+            const float u = (hv[j] - kcA.x) * kcA.z + kcA.w;
+            const float dh = dv[j] * gt[q] + dp[q] * invP;
             const float g = u > 0.f ? dh : alpha_c * dh;
-            val[j] = t.train ? kc[2] * (g - kc[4] - (hv[j] - kc[0]) * kc[1] * kc[5]) : g * kc[2];
+            val[j] = train ? kcA.z * (g - kcB.x - (hv[j] - kcA.x) * kcA.y * kcB.y) : g * kcA.z;
           }
         }
         *reinterpret_cast<float4*>(sDH + c * CG_TAIL_PS3 + pp) = make_float4(val[0], val[1], val[2], val[3]);
@@ -546,9 +619,41 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
     }
     CG_TSTAMP();
     // dWc[co][c2] += sum_p dh0[co][p] a[c2][p],  a = PReLU_p(gamma zhat + beta) rebuilt from zhat in the B fragments
+    if (MT_) {
+      // known widths: tile id = u * nw + wave = mt * NT2 + n2 with n2 = g * nw + wave (g < G), u = mt * G + g: the G activation fragments of a
+      // wave are read and activated ONCE per step and meet every dh0 fragment: G + MT reads for 4 G MT independent MFMAs
+      constexpr int G = NT2_ >= nw ? NT2_ / nw : 1;
+      static_assert(NT2_ == 0 || NT2_ % nw == 0 || (NT2_ < nw && MT_ == 1), "tile split of the four waves");
+      if (NT2_ >= nw || wave < NT2_) {
 #pragma unroll
-    for (int u = 0; u < CG_TAIL_MAXW; ++u) {
-      const int id = u * nw + wave;
+        for (int k0 = 0; k0 < CG_TAIL_PT3; k0 += 16) {
+          float afr[G][4];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int n2 = g * nw + wave, c2 = 16 * n2 + l15;
+            const bool cok = c2 < C2;
+            const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (c2 >= C ? alpha_p1 : alpha_p0) : 0.f;
+            float bv[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sZ + 16 * n2 * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot), CG_TAIL_PS3, k0, bv);
+            // positions >= np hold zhat = 0 but a = PReLU(beta) != 0 there; dh0 is zero at those positions, so the product vanishes
+#pragma unroll
+            for (int s = 0; s < 4; ++s) afr[g][s] = cg_prelu(gam * bv[s] + bet, alp);
+          }
+#pragma unroll
+          for (int mt = 0; mt < (MT_ ? MT_ : 1); ++mt) {
+            float av[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sDH + 16 * mt * CG_TAIL_PS3, CG_TAIL_PS3, l15, slot), CG_TAIL_PS3, k0, av);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+                wacc[mt * G + g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], afr[g][s], wacc[mt * G + g], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+    for (int u = 0; u < CG_TAIL_MAXW; ++u) {      const int id = u * nw + wave;
       if (id < MT * NT2) {
         const int mt = id / NT2, n2 = id - mt * NT2, c2 = 16 * n2 + l15;
         const int i = c2 >= C ? 1 : 0, c = c2 - i * C;
@@ -569,34 +674,65 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_k3_kernel(CgDstdTa
         }
       }
     }
+    }
     CG_TSTAMP();
     // d a[c2][p] = sum_co Wc[co][c2] dh0[co][p];  g_p = d a * PReLU_p'(gamma zhat + beta) -> HBM, sums of g_p and g_p * zhat.
     // Result tiles are position-major (dh0 fragments as the A operand): a lane holds four consecutive positions of ONE channel -
     // zhat comes as one 16-byte LDS read, g_p leaves as one 16-byte store, the channel constants are per lane, and the sums of a
     // channel are three registers per task over all tiles of the workgroup (a wave owns the same c2 tiles in every tile)
+    static_assert(CG_TAIL_PT3 == 32, "one pair of position tiles per task: task w = channel tile w");
+    cg_f32x4 dacc[CG_TAIL_K3_TASKS][2];
+    if (MT_) {
+      // known widths: the tasks of a wave (channel tiles wave, wave + 4) share the dh0 fragments and advance through k together
+#pragma unroll
+      for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) dacc[ti][0] = dacc[ti][1] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (NT2_ >= nw || wave < NT2_) {
+#pragma unroll
+        for (int k0 = 0; k0 < 16 * (MT_ ? MT_ : 1); k0 += 16) {
+          float b0v[4], b1v[4];
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sDH, CG_TAIL_PS3, l15, slot), CG_TAIL_PS3, k0, b0v);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sDH + 16, CG_TAIL_PS3, l15, slot), CG_TAIL_PS3, k0, b1v);
+#pragma unroll
+          for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
+            if (nw * ti >= NT2_ && ti > 0) break;              // constant per instantiation
+            float av[4];
+            cg_tfrag<1>(cg_tfrag_ptr<1>(sW + 16 * (wave + nw * ti), WS, l15, slot), WS, k0, av);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                       // C[position 4 * slot + q][channel l15]
+              dacc[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], dacc[ti][0], 0, 0, 0);
+              dacc[ti][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], dacc[ti][1], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int ti = 0; ti < CG_TAIL_K3_TASKS; ++ti) {
       const int w = wave + nw * ti;
       if (w >= NT2 * (CG_TAIL_PT3 / 32)) break;
       const int mt = w / (CG_TAIL_PT3 / 32), n0 = 32 * (w % (CG_TAIL_PT3 / 32)), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sDH + n0, CG_TAIL_PS3, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sDH + n1, CG_TAIL_PS3, l15, slot);
-      for (int k0 = 0; k0 < CM; k0 += 16) {
-        float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS3, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS3, k0, b1v);
+      if (MT_) { c0 = dacc[ti][0]; c1 = dacc[ti][1]; }
+      else {
+        const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, WS, l15, slot);
+        const float* bp0 = cg_tfrag_ptr<1>(sDH + n0, CG_TAIL_PS3, l15, slot);
+        const float* bp1 = cg_tfrag_ptr<1>(sDH + n1, CG_TAIL_PS3, l15, slot);
+        for (int k0 = 0; k0 < CM; k0 += 16) {
+          float av[4], b0v[4], b1v[4];
+          cg_tfrag<1>(ap, WS, k0, av); cg_tfrag<1>(bp0, CG_TAIL_PS3, k0, b0v); cg_tfrag<1>(bp1, CG_TAIL_PS3, k0, b1v);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                       // C[position 4 * slot + q][channel l15]
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) {                       // C[position 4 * slot + q][channel l15]
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+          }
         }
       }
       const int c2 = 16 * mt + l15;
       const bool cok = c2 < C2;
       const int i = c2 >= C ? 1 : 0, c = cok ? c2 - i * C : 0;
       const float gam = cok ? sK[8 * c2 + 6] : 0.f, bet = cok ? sK[8 * c2 + 7] : 0.f, alp = cok ? (i ? alpha_p1 : alpha_p0) : 0.f;
-      float* gpr = t.gp[i] + ((long long)b * C + c) * P + p0;
+      float* gpr = (i ? gp1 : gp0) + ((long long)b * C + c) * P + p0;       // a select of two hoisted pointers: t.gp[i] with a per-lane i is a
+                                                                                 // vector load from the argument block, and waiting for it waits for the whole prefetch
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int pq = (h ? n1 : n0) + 4 * slot;
@@ -809,9 +945,19 @@ extern "C" int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream_) {
     const int tps = (P + CG_TAIL_PT - 1) / CG_TAIL_PT, total = t->B * tps;
     const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
     const size_t lds = cg_tail_gemm_lds(t->C, false);
-    hipError_t e = cg_lds_limit((const void*)cg_tail_f2_kernel, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cg_tail_f2_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per);
+    const int mt = (t->C + 15) / 16, nt2 = (2 * t->C + 15) / 16;
+#define CG_TAIL_F2_LAUNCH(M, N)                                                                                               \
+    {                                                                                                                        \
+      hipError_t e = cg_lds_limit((const void*)cg_tail_f2_kernel<M, N>, lds);                                                \
+      if (e != hipSuccess) return (int)e;                                                                                    \
+      hipLaunchKernelGGL((cg_tail_f2_kernel<M, N>), dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per); \
+    }
+    if (mt == 4 && nt2 == 8) CG_TAIL_F2_LAUNCH(4, 8)           // C = 57 .. 64
+    else if (mt == 2 && nt2 == 4) CG_TAIL_F2_LAUNCH(2, 4)      // C = 25 .. 32
+    else if (mt == 1 && nt2 == 2) CG_TAIL_F2_LAUNCH(1, 2)      // C = 9 .. 16
+    else if (mt == 1 && nt2 == 1) CG_TAIL_F2_LAUNCH(1, 1)      // C <= 8
+    else CG_TAIL_F2_LAUNCH(0, 0)
+#undef CG_TAIL_F2_LAUNCH
   } else if (phase == 3) {
     if (!t->pooled || (t->train && !t->bn_c.stats)) return CG_EARG;
     hipLaunchKernelGGL(cg_tail_f3_kernel, dim3((unsigned)t->C, (unsigned)t->B), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
@@ -841,9 +987,19 @@ extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
     const int tps = (P + CG_TAIL_PT3 - 1) / CG_TAIL_PT3, total = t->B * tps;
     const int per = (total + 511) / 512, nwg = (total + per - 1) / per;
     const size_t lds = cg_tail_gemm_lds(C, true);
-    hipError_t e = cg_lds_limit((const void*)cg_tail_k3_kernel, lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cg_tail_k3_kernel, dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per, CG_TAIL_REPLICAS);
+    const int mt = (C + 15) / 16, nt2 = (2 * C + 15) / 16;
+#define CG_TAIL_K3_LAUNCH(M, N)                                                                                               \
+    {                                                                                                                        \
+      hipError_t e = cg_lds_limit((const void*)cg_tail_k3_kernel<M, N>, lds);                                                \
+      if (e != hipSuccess) return (int)e;                                                                                    \
+      hipLaunchKernelGGL((cg_tail_k3_kernel<M, N>), dim3((unsigned)nwg), dim3(CG_TAIL_THREADS), lds, stream, *t, tps, total, per, CG_TAIL_REPLICAS); \
+    }
+    if (mt == 4 && nt2 == 8) CG_TAIL_K3_LAUNCH(4, 8)
+    else if (mt == 2 && nt2 == 4) CG_TAIL_K3_LAUNCH(2, 4)
+    else if (mt == 1 && nt2 == 2) CG_TAIL_K3_LAUNCH(1, 2)
+    else if (mt == 1 && nt2 == 1) CG_TAIL_K3_LAUNCH(1, 1)
+    else CG_TAIL_K3_LAUNCH(0, 0)
+#undef CG_TAIL_K3_LAUNCH
     st = cg_launch_status();
     if (st != CG_OK) return st;
     const int n = C * 2 * C;

@@ -24,13 +24,23 @@ HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
 #define CG_ADJ_TPW_MAX 8                    // 64-position tiles per workgroup
 
+// Tile geometry of a padded slab count KcM (16 / 32 / 64): compile-time in the kernels (one instantiation each), so that every matrix-core
+// loop has a constant trip count and constant LDS strides - with run-time geometry the compiler left the k loops rolled: two LDS reads,
+// a full wait, four dependent MFMAs per iteration (round 4).  The host's CgAdjGeom carries the same numbers for the launch arithmetic.
+template <int KCM> struct CgAdjK {
+  static constexpr int KcM = KCM, WS = KCM + 4, PT = 4096 / KCM, PS = PT + 4, NP = PT / 32, MT = KCM / 16;
+  static constexpr int lgq = KCM > 32 ? 4 : KCM > 16 ? 5 : 6;          // log2(PT / 4)
+};
+
 // geometry of a tower (host side, cg_adj_geometry): handed to the kernels next to the argument block
 __device__ __forceinline__ const CgAdjGeom& cg_adj_geom(const CgAdjTailPair& pr, int i) { return pr.g[i]; }
 __device__ __forceinline__ unsigned cg_adj_div(unsigned n, unsigned magic) { return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n; }
 
 // Staging loops: the global loads of four strides are issued together, then their LDS stores.
 // S[k][a], Q[k][b'] of sample b: [KcM][JS] tables, rows >= Kc zero
+template <int KCM>
 __device__ __forceinline__ void cg_adj_tables(const CgAdjTail& t, const CgAdjGeom& g, int b, float* sS, float* sQ) {
+  using K = CgAdjK<KCM>;
   const int V = t.domain == 0 ? t.Kc : t.J, T = t.domain == 0 ? t.J : t.Kc, KJ = t.Kc * t.J;
   const float* sb = t.s + (long long)b * V * T;      // (V, T)
   const float* qb = t.q + (long long)b * T * V;      // (T, V)
@@ -51,12 +61,15 @@ __device__ __forceinline__ void cg_adj_tables(const CgAdjTail& t, const CgAdjGeo
       if (i < KJ) { sS[k * g.JS + a] = sv[j]; sQ[k * g.JS + a] = qv[j]; }
     }
   }
-  for (int e = t.Kc * g.JS + threadIdx.x; e < g.KcM * g.JS; e += CG_ADJ_THREADS) { sS[e] = 0.f; sQ[e] = 0.f; }
+  for (int e = t.Kc * g.JS + threadIdx.x; e < K::KcM * g.JS; e += CG_ADJ_THREADS) { sS[e] = 0.f; sQ[e] = 0.f; }
+  for (int k = threadIdx.x; k < t.Kc; k += CG_ADJ_THREADS) { sS[k * g.JS + t.J] = 0.f; sQ[k * g.JS + t.J] = 0.f; }     // the pad column: read (and discarded) by clamped indices
 }
 
 // W (Kc x Kc) -> sW [KcM][WS], padding zero
+template <int KCM>
 __device__ __forceinline__ void cg_adj_weight(const float* __restrict__ W, const CgAdjTail& t, const CgAdjGeom& g, float* sW) {
-  const int n = t.Kc * t.Kc, padw = g.WS - t.Kc;
+  using K = CgAdjK<KCM>;
+  const int n = t.Kc * t.Kc, padw = K::WS - t.Kc;
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * CG_ADJ_THREADS) {
     float v[4];
 #pragma unroll
@@ -64,21 +77,23 @@ __device__ __forceinline__ void cg_adj_weight(const float* __restrict__ W, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = i0 + CG_ADJ_THREADS * j, r = (int)cg_adj_div((unsigned)i, g.magicKc);
-      if (i < n) sW[r * g.WS + i - r * t.Kc] = v[j];
+      if (i < n) sW[r * K::WS + i - r * t.Kc] = v[j];
     }
   }
   for (int i = threadIdx.x; i < t.Kc * padw; i += CG_ADJ_THREADS) {            // columns Kc .. WS - 1 of the rows < Kc
     const int r = (int)cg_adj_div((unsigned)i, g.magicPad);
-    sW[r * g.WS + t.Kc + i - r * padw] = 0.f;
+    sW[r * K::WS + t.Kc + i - r * padw] = 0.f;
   }
-  for (int e = t.Kc * g.WS + threadIdx.x; e < g.KcM * g.WS; e += CG_ADJ_THREADS) sW[e] = 0.f;
+  for (int e = t.Kc * K::WS + threadIdx.x; e < K::KcM * K::WS; e += CG_ADJ_THREADS) sW[e] = 0.f;
 }
 
 // rows Kc .. KcM - 1 of `count` consecutive [KcM][PS] tile images: never written by the staging, read by the fragments
+template <int KCM>
 __device__ __forceinline__ void cg_adj_zero_pad_rows(const CgAdjTail& t, const CgAdjGeom& g, float* img, int count) {
-  const int n = (g.KcM - t.Kc) * g.PS;
+  using K = CgAdjK<KCM>;
+  const int n = (K::KcM - t.Kc) * K::PS;
   for (int c = 0; c < count; ++c)
-    for (int e = threadIdx.x; e < n; e += CG_ADJ_THREADS) img[(c * g.KcM + t.Kc) * g.PS + e] = 0.f;
+    for (int e = threadIdx.x; e < n; e += CG_ADJ_THREADS) img[(c * K::KcM + t.Kc) * K::PS + e] = 0.f;
 }
 
 // generated fragment of the seed for 16-wide k chunk k0: v[s] = S[k][a] Q[k][b'], k = k0 + 4*slot + s
@@ -93,30 +108,27 @@ __device__ __forceinline__ void cg_adj_seed_frag_k(const float* sS, const float*
 // ======================================================================================================================
 // M1: e[u][p] = sum_k W0[u][k] S[k][a] Q[k][b']   + channel sums of e
 // ======================================================================================================================
-__global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair pr) {
-  const CgAdjTail& t = pr.t[blockIdx.y];
-  const CgAdjGeom& g = pr.g[blockIdx.y];
-  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
-  if (ch >= g.nch) return;
-  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
+template <int KCM>
+__device__ __forceinline__ void cg_adj_m1_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int tile0, int tile1) {
+  using K = CgAdjK<KCM>;
   float* sS = reinterpret_cast<float*>(cg_dyn_lds);
-  float* sQ = sS + g.KcM * g.JS;
-  float* sW = sQ + g.KcM * g.JS;
-  double* sStat = reinterpret_cast<double*>(sW + g.KcM * g.WS + ((g.KcM * g.JS * 2 + g.KcM * g.WS) & 1));
+  float* sQ = sS + K::KcM * g.JS;
+  float* sW = sQ + K::KcM * g.JS;
+  double* sStat = reinterpret_cast<double*>(sW + K::KcM * K::WS + ((K::KcM * g.JS * 2 + K::KcM * K::WS) & 1));
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
-  cg_adj_tables(t, g, b, sS, sQ);
-  cg_adj_weight(t.W0, t, g, sW);
-  for (int e = tid; e < 2 * g.KcM; e += CG_ADJ_THREADS) sStat[e] = 0.0;
+  cg_adj_tables<KCM>(t, g, b, sS, sQ);
+  cg_adj_weight<KCM>(t.W0, t, g, sW);
+  for (int e = tid; e < 2 * K::KcM; e += CG_ADJ_THREADS) sStat[e] = 0.0;
   __syncthreads();
-  const int MT = g.KcM / 16;
+  constexpr int MT = K::MT;
   float* eb = t.e + (long long)b * t.Kc * g.Pn;
-  const int P0 = tile0 * g.PT, ngroups = (min(g.Pn, tile1 * g.PT) - P0 + 31) / 32;
+  const int P0 = tile0 * K::PT, ngroups = (min(g.Pn, tile1 * K::PT) - P0 + 31) / 32;
   // C[position][channel] tiles: a lane ends up with four consecutive positions of ONE channel (float4 stores, per-lane channel
   // sums); a wave keeps its channel tile (4 % MT == 0), so the sums stay in registers over all its groups
   const bool vec = (g.Pn & 3) == 0;
   const int mt = wave % MT, u = 16 * mt + l15;
   const bool uok = u < t.Kc;
-  const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * g.WS, g.WS, l15, slot);
+  const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * K::WS, K::WS, l15, slot);
   float s1 = 0.f, s2 = 0.f;
   for (int w = wave; w < ngroups * MT; w += CG_ADJ_THREADS / 64) {       // (group of 32 positions, u tile)
     const int grp = w / MT, p0 = P0 + 32 * grp;
@@ -124,9 +136,9 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
     const int aa = (int)cg_adj_div((unsigned)pa, g.magicJ), ab = (int)cg_adj_div((unsigned)pb, g.magicJ);
     const bool oka = pa < g.Pn, okb = pb < g.Pn;
     cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-    for (int k0 = 0; k0 < g.KcM; k0 += 16) {
+    for (int k0 = 0; k0 < K::KcM; k0 += 16) {
       float av[4], b0v[4], b1v[4];
-      cg_tfrag<0>(ap, g.WS, k0, av);
+      cg_tfrag<0>(ap, K::WS, k0, av);
       cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, oka ? aa : 0, oka ? pa - aa * t.J : 0, oka, b0v);
       cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, okb ? ab : 0, okb ? pb - ab * t.J : 0, okb, b1v);
 #pragma unroll
@@ -162,6 +174,23 @@ __global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair
   }
 }
 
+// the instantiation of a tower's padded slab count (wave-uniform: one tower per blockIdx.y)
+#define CG_ADJ_DISPATCH(KcM_, CALL)                  \
+  switch (KcM_) {                                     \
+    case 16: { constexpr int KCM = 16; CALL; } break; \
+    case 32: { constexpr int KCM = 32; CALL; } break; \
+    default: { constexpr int KCM = 64; CALL; } break; \
+  }
+
+__global__ __launch_bounds__(CG_ADJ_THREADS) void cg_adj_m1_kernel(CgAdjTailPair pr) {
+  const CgAdjTail& t = pr.t[blockIdx.y];
+  const CgAdjGeom& g = pr.g[blockIdx.y];
+  const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
+  if (ch >= g.nch) return;
+  const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
+  CG_ADJ_DISPATCH(g.KcM, cg_adj_m1_body<KCM>(t, g, b, tile0, tile1))
+}
+
 // `red` ([CG_ADJ_REPLICAS][2 Kc + 1] f64: sums of g and g e_hat per channel, d alpha) summed over its replicas
 __device__ __forceinline__ double cg_adj_red(const CgAdjTail& t, int i) {
   double s = 0.0;
@@ -169,7 +198,7 @@ __device__ __forceinline__ double cg_adj_red(const CgAdjTail& t, int i) {
   return s;
 }
 
-// per-channel constants [KcM][8]: mean, rstd, scale = gamma * rstd, beta, m1, m2 (backward), gamma, -
+// per-channel constants [KcM][8]: mean, rstd, scale = gamma * rstd, beta, m1, m2 (backward), gamma, scale * rstd * m2
 __device__ __forceinline__ void cg_adj_consts(const CgAdjTail& t, const CgAdjGeom& g, float* sK, bool backward, bool owner) {
   const double cnt = (double)t.B * g.Pn;
   for (int c = threadIdx.x; c < t.Kc; c += CG_ADJ_THREADS) {
@@ -179,6 +208,7 @@ __device__ __forceinline__ void cg_adj_consts(const CgAdjTail& t, const CgAdjGeo
     k[4] = (backward && t.train) ? (float)(cg_adj_red(t, 2 * c) / cnt) : 0.f;
     k[5] = (backward && t.train) ? (float)(cg_adj_red(t, 2 * c + 1) / cnt) : 0.f;
     k[6] = a.gamma;
+    k[7] = k[2] * k[1] * k[5];                    // N2: de = scale (g - m1) - (e - mean) * [scale rstd m2]
   }
 }
 
@@ -190,101 +220,112 @@ __device__ __forceinline__ float cg_adj_keep(const CgAdjTail& t, unsigned long l
 // ---- pipelined staging: a thread's share of one [Kc][64-position] tile travels global -> registers (issued a tile ahead, in flight
 // during the matrix work) -> transform -> LDS.  VEC (J*J % 4 == 0): float4 number r of the thread is element 4 * (tid + 256 r) of the
 // tile image; otherwise scalar number j is element tid + 256 j.
-template <bool VEC>
-__device__ __forceinline__ void cg_adj_fetch(const CgAdjGeom& g, const float* __restrict__ src, int Kc, int Pn, int p0, int np, float buf[16]) {
+template <int KCM, bool VEC>
+__device__ __forceinline__ void cg_adj_fetch(const float* __restrict__ src, int Kc, int Pn, int p0, int np, float buf[16]) {
+  using K = CgAdjK<KCM>;
   if (VEC) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < Kc && pp < np) v = *reinterpret_cast<const float4*>(src + (long long)c * Pn + p0 + pp);
-      buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> K::lgq, pp = 4 * (e & ((1 << K::lgq) - 1));
+      // no branch around the load (element 0 of the sample stands in for what lies outside): the loads of a thread issue back to back
+      const bool in = c < Kc && pp < np;
+      const float4 v = *reinterpret_cast<const float4*>(src + (in ? (long long)c * Pn + p0 + pp : 0ll));
+      buf[4 * r] = in ? v.x : 0.f; buf[4 * r + 1] = in ? v.y : 0.f; buf[4 * r + 2] = in ? v.z : 0.f; buf[4 * r + 3] = in ? v.w : 0.f;
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (g.lgq + 2), pp = e & (g.PT - 1);
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (K::lgq + 2), pp = e & (K::PT - 1);
       buf[j] = (c < Kc && pp < np) ? src[(long long)c * Pn + p0 + pp] : 0.f;
     }
   }
 }
 // fn(c, pp, ok, off): channel c < Kc, tile position pp of staging register number `off` (4 consecutive positions with VEC, else 1);
 // ok: inside the tensor
-template <bool VEC, typename F>
-__device__ __forceinline__ void cg_adj_commit(const CgAdjGeom& g, int Kc, int np, F fn) {
+template <int KCM, bool VEC, typename F>
+__device__ __forceinline__ void cg_adj_commit(int Kc, int np, F fn) {
+  using K = CgAdjK<KCM>;
   if (VEC) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * r, c = e >> K::lgq, pp = 4 * (e & ((1 << K::lgq) - 1));
       if (c < Kc) fn(c, pp, pp < np, 4 * r);
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (g.lgq + 2), pp = e & (g.PT - 1);
+      const int e = (int)threadIdx.x + CG_ADJ_THREADS * j, c = e >> (K::lgq + 2), pp = e & (K::PT - 1);
       if (c < Kc) fn(c, pp, pp < np, j);
     }
   }
 }
 template <bool VEC>
-__device__ __forceinline__ void cg_adj_keeps(const CgAdjTail& t, bool drop, unsigned long long seed, long long idx, float keep[4]) {
-  if (VEC) cg_keep4(drop, t.drop_p, seed, t.salt, (unsigned long long)idx, keep);
-  else keep[0] = drop ? cg_drop_scale(t.drop_p, seed, t.salt, (unsigned long long)idx) : 1.f;
+__device__ __forceinline__ void cg_adj_keeps(float drop_p, unsigned int salt, bool drop, unsigned long long seed, long long idx, float keep[4]) {
+  if (VEC) cg_keep4(drop, drop_p, seed, salt, (unsigned long long)idx, keep);
+  else keep[0] = drop ? cg_drop_scale(drop_p, seed, salt, (unsigned long long)idx) : 1.f;
 }
-template <bool VEC>
-__device__ __forceinline__ void cg_adj_put(const CgAdjGeom& g, float* img, int c, int pp, const float v[4]) {
-  if (VEC) *reinterpret_cast<float4*>(img + c * g.PS + pp) = make_float4(v[0], v[1], v[2], v[3]);
-  else img[c * g.PS + pp] = v[0];
+template <int KCM, bool VEC>
+__device__ __forceinline__ void cg_adj_put(float* img, int c, int pp, const float v[4]) {
+  using K = CgAdjK<KCM>;
+  if (VEC) *reinterpret_cast<float4*>(img + c * K::PS + pp) = make_float4(v[0], v[1], v[2], v[3]);
+  else img[c * K::PS + pp] = v[0];
 }
 
 // ======================================================================================================================
 // M2: Adj[u'][p] = sum_u W4[u'][u] h[u][p],  h = PReLU(Dropout(BN(e)))
 // ======================================================================================================================
-template <bool VEC>
+template <int KCM, bool VEC>
 __device__ __forceinline__ void cg_adj_m2_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int tile0, int tile1, bool owner) {
+  using K = CgAdjK<KCM>;
   float* sH = reinterpret_cast<float*>(cg_dyn_lds);              // [KcM][PS]
-  float* sW = sH + g.KcM * g.PS;                             // [KcM][WS]
-  float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
+  float* sW = sH + K::KcM * K::PS;                             // [KcM][WS]
+  float* sK = sW + K::KcM * K::WS;                                  // [KcM][8]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   constexpr int N = VEC ? 4 : 1;
-  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
+  // read once what the tile loop needs of the argument blocks (kernel-argument memory behind a run-time index)
+  const int Kc = t.Kc, Pn = g.Pn;
+  const bool train = t.train != 0;
+  (void)train;
+  const float* eb = t.e + (long long)b * Kc * Pn;
   float ebuf[16];
-  cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, tile0 * g.PT, min(g.PT, g.Pn - tile0 * g.PT), ebuf);
-  cg_adj_zero_pad_rows(t, g, sH, 1);
-  cg_adj_weight(t.W4, t, g, sW);
+  cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, tile0 * K::PT, min(K::PT, Pn - tile0 * K::PT), ebuf);
+  cg_adj_zero_pad_rows<KCM>(t, g, sH, 1);
+  cg_adj_weight<KCM>(t.W4, t, g, sW);
   cg_adj_consts(t, g, sK, false, owner);
-  const bool drop = t.train && t.drop_p > 0.f;
+  const float drop_p = t.drop_p; const unsigned int salt = t.salt;
+  const bool drop = train && drop_p > 0.f;
   const unsigned long long seed = drop ? *t.seed : 0ull;
   const float alpha = t.alpha[0];
-  const int MT = g.KcM / 16;
-  float* ab = t.adj + (long long)b * t.Kc * g.Pn;
+  constexpr int MT = K::MT;
+  float* ab = t.adj + (long long)b * Kc * Pn;
+  float* const tap = t.tap;
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
+    const int p0 = tile * K::PT, np = min(K::PT, Pn - p0);
     __syncthreads();
-    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
-      const float* k = sK + 8 * c;
-      const long long idx = ((long long)b * t.Kc + c) * g.Pn + p0 + pp;
+    cg_adj_commit<KCM, VEC>(Kc, np, [&](int c, int pp, bool ok, int off) {
+      const float4 k4 = *reinterpret_cast<const float4*>(sK + 8 * c);           // mean, rstd, scale, beta
+      const long long idx = ((long long)b * Kc + c) * Pn + p0 + pp;
       float keep[4], v[4];
-      cg_adj_keeps<VEC>(t, drop && ok, seed, idx, keep);
+      cg_adj_keeps<VEC>(drop_p, salt, drop && ok, seed, idx, keep);
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = ok ? cg_prelu(((ebuf[off + j] - k[0]) * k[2] + k[3]) * keep[j], alpha) : 0.f;
-      cg_adj_put<VEC>(g, sH, c, pp, v);
-      if (t.tap && ok) {
-        if (VEC) *reinterpret_cast<float4*>(t.tap + idx) = make_float4(v[0], v[1], v[2], v[3]);
-        else t.tap[idx] = v[0];
+      for (int j = 0; j < N; ++j) v[j] = ok ? cg_prelu(((ebuf[off + j] - k4.x) * k4.z + k4.w) * keep[j], alpha) : 0.f;
+      cg_adj_put<KCM, VEC>(sH, c, pp, v);
+      if (tap && ok) {
+        if (VEC) *reinterpret_cast<float4*>(tap + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        else tap[idx] = v[0];
       }
     });
     __syncthreads();
-    if (tile + 1 < tile1) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0 + g.PT, min(g.PT, g.Pn - p0 - g.PT), ebuf);
-    for (int w = wave; w < MT * g.NP; w += CG_ADJ_THREADS / 64) {
-      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
+    if (tile + 1 < tile1) cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, p0 + K::PT, min(K::PT, Pn - p0 - K::PT), ebuf);
+    for (int w = wave; w < MT * K::NP; w += CG_ADJ_THREADS / 64) {
+      const int mt = w / K::NP, n0 = 32 * (w - mt * K::NP), n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * g.WS, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sH + n0, g.PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sH + n1, g.PS, l15, slot);
-      for (int k0 = 0; k0 < g.KcM; k0 += 16) {
+      const float* ap = cg_tfrag_ptr<0>(sW + 16 * mt * K::WS, K::WS, l15, slot);
+      const float* bp0 = cg_tfrag_ptr<1>(sH + n0, K::PS, l15, slot);
+      const float* bp1 = cg_tfrag_ptr<1>(sH + n1, K::PS, l15, slot);
+      for (int k0 = 0; k0 < K::KcM; k0 += 16) {
         float av[4], b0v[4], b1v[4];
-        cg_tfrag<0>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
+        cg_tfrag<0>(ap, K::WS, k0, av); cg_tfrag<1>(bp0, K::PS, k0, b0v); cg_tfrag<1>(bp1, K::PS, k0, b1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                     // C[position][channel]: four consecutive positions per lane
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
@@ -292,12 +333,12 @@ __device__ __forceinline__ void cg_adj_m2_body(const CgAdjTail& t, const CgAdjGe
         }
       }
       const int u = 16 * mt + l15;
-      if (u < t.Kc) {
+      if (u < Kc) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pq = (h ? n1 : n0) + 4 * slot;
           const cg_f32x4 c = h ? c1 : c0;
-          float* dst = ab + (long long)u * g.Pn + p0 + pq;
+          float* dst = ab + (long long)u * Pn + p0 + pq;
           if (VEC) { if (pq < np) *reinterpret_cast<float4*>(dst) = make_float4(c[0], c[1], c[2], c[3]); }
           else {
 #pragma unroll
@@ -315,116 +356,136 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_m2_kernel(CgAdjTailP
   const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
   if (ch >= g.nch) return;
   const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
-  if ((g.Pn & 3) == 0) cg_adj_m2_body<true>(t, g, b, tile0, tile1, blockIdx.x == 0);
-  else cg_adj_m2_body<false>(t, g, b, tile0, tile1, blockIdx.x == 0);
+  if ((g.Pn & 3) == 0) { CG_ADJ_DISPATCH(g.KcM, (cg_adj_m2_body<KCM, true>(t, g, b, tile0, tile1, blockIdx.x == 0))) }
+  else { CG_ADJ_DISPATCH(g.KcM, (cg_adj_m2_body<KCM, false>(t, g, b, tile0, tile1, blockIdx.x == 0))) }
 }
 
 // ======================================================================================================================
 // N1: dh = W4^T dAdj;  g = dh PReLU'(u) keep -> HBM;  red = { sum g, sum g e_hat }, d alpha;  dW4 += dAdj h^T
 // ======================================================================================================================
-template <bool VEC>
+template <int KCM, bool VEC>
 __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int tile0, int tile1, int dbg) {
+  using K = CgAdjK<KCM>;
   float* sE = reinterpret_cast<float*>(cg_dyn_lds);              // [KcM][PS] e_hat
-  float* sP = sE + g.KcM * g.PS;                             // [KcM][PS] dropout keep factors
-  float* sD = sP + g.KcM * g.PS;                             // [KcM][PS] dAdj
-  float* sW = sD + g.KcM * g.PS;                             // [KcM][WS] W4
-  float* sK = sW + g.KcM * g.WS;                                  // [KcM][8]
-  double* sRed = reinterpret_cast<double*>(sK + 8 * g.KcM);       // [KcM][2] + [1]
+  float* sP = sE + K::KcM * K::PS;                             // [KcM][PS] dropout keep factors
+  float* sD = sP + K::KcM * K::PS;                             // [KcM][PS] dAdj
+  float* sW = sD + K::KcM * K::PS;                             // [KcM][WS] W4
+  float* sK = sW + K::KcM * K::WS;                                  // [KcM][8]
+  double* sRed = reinterpret_cast<double*>(sK + 8 * K::KcM);       // [KcM][2] + [1]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
   constexpr int N = VEC ? 4 : 1;
-  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
-  const float* db = t.dadj + (long long)b * t.Kc * g.Pn;
+  // read once what the tile loop needs of the argument blocks (kernel-argument memory behind a run-time index)
+  const int Kc = t.Kc, Pn = g.Pn;
+  const bool train = t.train != 0;
+  (void)train;
+  const float* eb = t.e + (long long)b * Kc * Pn;
+  const float* db = t.dadj + (long long)b * Kc * Pn;
   float ebuf[16], dbuf[16];
   {
-    const int p0 = tile0 * g.PT, np = min(g.PT, g.Pn - p0);
-    cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0, np, ebuf);
-    cg_adj_fetch<VEC>(g, db, t.Kc, g.Pn, p0, np, dbuf);
+    const int p0 = tile0 * K::PT, np = min(K::PT, Pn - p0);
+    cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, p0, np, ebuf);
+    cg_adj_fetch<KCM, VEC>(db, Kc, Pn, p0, np, dbuf);
   }
-  cg_adj_zero_pad_rows(t, g, sE, 3);
-  for (int e = tid; e < 2 * g.KcM + 1; e += CG_ADJ_THREADS) sRed[e] = 0.0;
-  cg_adj_weight(t.W4, t, g, sW);
+  cg_adj_zero_pad_rows<KCM>(t, g, sE, 3);
+  for (int e = tid; e < 2 * K::KcM + 1; e += CG_ADJ_THREADS) sRed[e] = 0.0;
+  cg_adj_weight<KCM>(t.W4, t, g, sW);
   cg_adj_consts(t, g, sK, true, false);
-  const bool drop = t.train && t.drop_p > 0.f;
+  const float drop_p = t.drop_p; const unsigned int salt = t.salt;
+  const bool drop = train && drop_p > 0.f;
   const unsigned long long seed = drop ? *t.seed : 0ull;
   const float alpha = t.alpha[0];
-  const int MT = g.KcM / 16;
-  cg_f32x4 wacc[CG_ADJ_MAXW];
+  constexpr int MT = K::MT;
+  constexpr int NU = (MT * MT + 3) / 4;                  // weight-gradient tiles of a wave
+  static_assert(MT * K::NP == 8 && NU <= CG_ADJ_MAXW, "task split of the four waves");
+  constexpr int NS = NU == 1 ? 2 : 1;                    // a wave with one tile splits its sum over even / odd steps: two MFMA chains
+  cg_f32x4 wacc[NU][NS];
 #pragma unroll
-  for (int u = 0; u < CG_ADJ_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-  float* gb = t.g + (long long)b * t.Kc * g.Pn;
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int h = 0; h < NS; ++h) wacc[u][h] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  float* gb = t.g + (long long)b * Kc * Pn;
   float racc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, sa = 0.f;   // per lane: sums of g and g e_hat (one channel per dh task), d alpha
   if (dbg & 64) tile1 = tile0;
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
+    const int p0 = tile * K::PT, np = min(K::PT, Pn - p0);
     __syncthreads();
-    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
-      const float* k = sK + 8 * c;
+    cg_adj_commit<KCM, VEC>(Kc, np, [&](int c, int pp, bool ok, int off) {
+      const float2 k01 = *reinterpret_cast<const float2*>(sK + 8 * c);          // mean, rstd
       float keep[4], v[4], d[4];
-      cg_adj_keeps<VEC>(t, drop && ok, seed, ((long long)b * t.Kc + c) * g.Pn + p0 + pp, keep);
+      cg_adj_keeps<VEC>(drop_p, salt, drop && ok, seed, ((long long)b * Kc + c) * Pn + p0 + pp, keep);
 #pragma unroll
-      for (int j = 0; j < N; ++j) { v[j] = ok ? (ebuf[off + j] - k[0]) * k[1] : 0.f; keep[j] = ok ? keep[j] : 0.f; d[j] = dbuf[off + j]; }
-      cg_adj_put<VEC>(g, sE, c, pp, v);
-      cg_adj_put<VEC>(g, sP, c, pp, keep);
-      cg_adj_put<VEC>(g, sD, c, pp, d);
+      for (int j = 0; j < N; ++j) { v[j] = ok ? (ebuf[off + j] - k01.x) * k01.y : 0.f; keep[j] = ok ? keep[j] : 0.f; d[j] = dbuf[off + j]; }
+      cg_adj_put<KCM, VEC>(sE, c, pp, v);
+      cg_adj_put<KCM, VEC>(sP, c, pp, keep);
+      cg_adj_put<KCM, VEC>(sD, c, pp, d);
     });
     __syncthreads();
     if (tile + 1 < tile1 && !(dbg & 8)) {
-      const int q0 = p0 + g.PT, nq = min(g.PT, g.Pn - q0);
-      cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, q0, nq, ebuf);
-      cg_adj_fetch<VEC>(g, db, t.Kc, g.Pn, q0, nq, dbuf);
+      const int q0 = p0 + K::PT, nq = min(K::PT, Pn - q0);
+      cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, q0, nq, ebuf);
+      cg_adj_fetch<KCM, VEC>(db, Kc, Pn, q0, nq, dbuf);
     }
     // dW4[u'][u] += sum_p dAdj[u'][p] h[u][p],  h rebuilt from e_hat and the keep factors in the B fragments (lane = channel u)
+    if (!(dbg & 1) && (MT * MT >= nw || wave < MT * MT)) {       // 1 tile (wave 0), 4 tiles (one per wave) or 16 (four per wave)
 #pragma unroll
-    for (int u = 0; u < CG_ADJ_MAXW; ++u) {
-      const int id = u * nw + wave;
-      if (id < MT * MT && !(dbg & 1)) {
-        const int mt = id / MT, n2 = id - mt * MT, cu = 16 * n2 + l15;
-        const bool cok = cu < t.Kc;
-        const float gam = cok ? sK[8 * cu + 6] : 0.f, bet = cok ? sK[8 * cu + 3] : 0.f;
-        const float* ap = cg_tfrag_ptr<0>(sD + 16 * mt * g.PS, g.PS, l15, slot);
-        const float* bp = cg_tfrag_ptr<0>(sE + 16 * n2 * g.PS, g.PS, l15, slot);
-        const float* kp = cg_tfrag_ptr<0>(sP + 16 * n2 * g.PS, g.PS, l15, slot);
-#pragma unroll 4
-        for (int k0 = 0; k0 < g.PT; k0 += 16) {
-          float av[4], bv[4], keep[4];
-          cg_tfrag<0>(ap, g.PS, k0, av); cg_tfrag<0>(bp, g.PS, k0, bv); cg_tfrag<0>(kp, g.PS, k0, keep);
+      for (int k0 = 0; k0 < K::PT; k0 += 16) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            // rows of channels >= Kc and positions beyond the tensor hold keep = 0: h = 0
-            const float h = cg_prelu((gam * bv[s] + bet) * keep[s], alpha);
-            wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], h, wacc[u], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) {
+          const int id = u * nw + wave;
+          {
+            const int mt = id / MT, n2 = id - mt * MT, cu = 16 * n2 + l15;
+            const bool cok = cu < Kc;
+            const float gam = cok ? sK[8 * cu + 6] : 0.f, bet = cok ? sK[8 * cu + 3] : 0.f;
+            float av[4], bv[4], keep[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sD + 16 * mt * K::PS, K::PS, l15, slot), K::PS, k0, av);
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sE + 16 * n2 * K::PS, K::PS, l15, slot), K::PS, k0, bv);
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sP + 16 * n2 * K::PS, K::PS, l15, slot), K::PS, k0, keep);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              // rows of channels >= Kc and positions beyond the tensor hold keep = 0: h = 0
+              const float h = cg_prelu((gam * bv[s] + bet) * keep[s], alpha);
+              wacc[u][(k0 / 16) % NS] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], h, wacc[u][(k0 / 16) % NS], 0, 0, 0);
+            }
           }
         }
       }
     }
     // dh[u][p] = sum_u' W4[u'][u] dAdj[u'][p]
+    cg_f32x4 dacc[2][2];
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
-      const int w = wave + nw * ti;
-      if (w >= MT * g.NP || (dbg & 2)) break;
-      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
-      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sD + n0, g.PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sD + n1, g.PS, l15, slot);
-      for (int k0 = 0; k0 < g.KcM; k0 += 16) {
-        float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
+    for (int ti = 0; ti < 2; ++ti) dacc[ti][0] = dacc[ti][1] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(dbg & 2)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {                     // C[position][channel]: four consecutive positions per lane
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+      for (int k0 = 0; k0 < K::KcM; k0 += 16) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const int w = wave + nw * ti, mt = w / K::NP, n0 = 32 * (w - mt * K::NP), n1 = n0 + 16;
+          float av[4], b0v[4], b1v[4];
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sW + 16 * mt, K::WS, l15, slot), K::WS, k0, av);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sD + n0, K::PS, l15, slot), K::PS, k0, b0v);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sD + n1, K::PS, l15, slot), K::PS, k0, b1v);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {                     // C[position][channel]: four consecutive positions per lane
+            dacc[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], dacc[ti][0], 0, 0, 0);
+            dacc[ti][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], dacc[ti][1], 0, 0, 0);
+          }
         }
       }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+      if (dbg & 2) break;
+      const int w = wave + nw * ti, mt = w / K::NP, n0 = 32 * (w - mt * K::NP), n1 = n0 + 16;
+      const cg_f32x4 c0 = dacc[ti][0], c1 = dacc[ti][1];
       const int u = 16 * mt + l15;
-      if (u < t.Kc) {
+      if (u < Kc) {
         const float gam = sK[8 * u + 6], bet = sK[8 * u + 3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int pq = (h ? n1 : n0) + 4 * slot;
           if (pq >= np) continue;
           const cg_f32x4 c = h ? c1 : c0;
-          const float4 e4 = *reinterpret_cast<const float4*>(sE + u * g.PS + pq), k4 = *reinterpret_cast<const float4*>(sP + u * g.PS + pq);
+          const float4 e4 = *reinterpret_cast<const float4*>(sE + u * K::PS + pq), k4 = *reinterpret_cast<const float4*>(sP + u * K::PS + pq);
           const float ev[4] = {e4.x, e4.y, e4.z, e4.w}, kv[4] = {k4.x, k4.y, k4.z, k4.w};
           float gv[4];
 #pragma unroll
@@ -435,7 +496,7 @@ __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGe
             racc[ti][0] += gv[q]; racc[ti][1] += gv[q] * ev[q];
             if (in && !(upre > 0.f)) sa += c[q] * upre;
           }
-          float* dst = gb + (long long)u * g.Pn + p0 + pq;
+          float* dst = gb + (long long)u * Pn + p0 + pq;
           if (VEC) *reinterpret_cast<float4*>(dst) = make_float4(gv[0], gv[1], gv[2], gv[3]);
           else {
 #pragma unroll
@@ -450,26 +511,25 @@ __device__ __forceinline__ void cg_adj_n1_body(const CgAdjTail& t, const CgAdjGe
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
     const int w = wave + nw * ti;
-    if (w >= MT * g.NP) break;
-    const int u = 16 * (w / g.NP) + l15;
-    if (u < t.Kc) { atomicAdd(&sRed[2 * u], (double)racc[ti][0]); atomicAdd(&sRed[2 * u + 1], (double)racc[ti][1]); }
+    const int u = 16 * (w / K::NP) + l15;
+    if (u < Kc) { atomicAdd(&sRed[2 * u], (double)racc[ti][0]); atomicAdd(&sRed[2 * u + 1], (double)racc[ti][1]); }
   }
-  if (l15 == 0) atomicAdd(&sRed[2 * g.KcM], (double)sa);
+  if (l15 == 0) atomicAdd(&sRed[2 * K::KcM], (double)sa);
   __syncthreads();
   if (dbg & 32) return;
-  double* red = t.red + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * (2 * t.Kc + 1);
-  for (int e = tid; e < 2 * t.Kc; e += CG_ADJ_THREADS) atomicAdd(&red[e], sRed[e]);
-  if (tid == 0) atomicAdd(&red[2 * t.Kc], sRed[2 * g.KcM]);
-  float* dW = t.dW4_ws + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * t.Kc * t.Kc;
+  double* red = t.red + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * (2 * Kc + 1);
+  for (int e = tid; e < 2 * Kc; e += CG_ADJ_THREADS) atomicAdd(&red[e], sRed[e]);
+  if (tid == 0) atomicAdd(&red[2 * Kc], sRed[2 * K::KcM]);
+  float* dW = t.dW4_ws + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * Kc * Kc;
 #pragma unroll
-  for (int u = 0; u < CG_ADJ_MAXW; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int id = u * nw + wave;
     if (id < MT * MT) {
       const int mt = id / MT, n2 = id - mt * MT;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 16 * mt + 4 * slot + q, c = 16 * n2 + l15;
-        if (r < t.Kc && c < t.Kc) atomicAdd(&dW[r * t.Kc + c], wacc[u][q]);
+        if (r < Kc && c < Kc) atomicAdd(&dW[r * Kc + c], NS == 2 ? wacc[u][0][q] + wacc[u][NS - 1][q] : wacc[u][0][q]);
       }
     }
   }
@@ -481,148 +541,231 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n1_kernel(CgAdjTailP
   const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
   if (ch >= g.nch) return;
   const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
-  if ((g.Pn & 3) == 0) cg_adj_n1_body<true>(t, g, b, tile0, tile1, pr.dbg);
-  else cg_adj_n1_body<false>(t, g, b, tile0, tile1, pr.dbg);
+  if ((g.Pn & 3) == 0) { CG_ADJ_DISPATCH(g.KcM, (cg_adj_n1_body<KCM, true>(t, g, b, tile0, tile1, pr.dbg))) }
+  else { CG_ADJ_DISPATCH(g.KcM, (cg_adj_n1_body<KCM, false>(t, g, b, tile0, tile1, pr.dbg))) }
 }
+
+// Diagnostic build only (tools/stamps_adj.py compiles a private copy of the library with -DCG_ADJ_STAMPS): thread 0 of every workgroup
+// of N2 stores the shader clock at its phase boundaries; nothing depends on it, the shipped library has no stamp.
+#ifdef CG_ADJ_STAMPS
+__device__ unsigned long long* cg_adj_stamp_buf = nullptr;
+extern "C" int cg_adj_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(cg_adj_stamp_buf), &p, sizeof(p)); }
+#define CG_ASTAMP()                                                                                                          \
+  do {                                                                                                                       \
+    if (threadIdx.x == 0 && cg_adj_stamp_buf && nst < 250)                                                                    \
+      cg_adj_stamp_buf[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + (++nst)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#define CG_ASTAMP_END() do { if (threadIdx.x == 0 && cg_adj_stamp_buf) cg_adj_stamp_buf[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256] = nst; } while (0)
+#else
+#define CG_ASTAMP() do { } while (0)
+#define CG_ASTAMP_END() do { } while (0)
+#endif
 
 // ======================================================================================================================
 // N2: de = BN'(g);  do = W0^T de;  dS[k][a] += do Q[k][b'],  dQ[k][b'] += do S[k][a];  dW0 += de (S x Q)^T
 // ======================================================================================================================
-template <bool VEC>
+template <int KCM, bool VEC>
 __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGeom& g, int b, int ch, int tile0, int tile1, int dbg) {
+  using K = CgAdjK<KCM>;
   float* sS = reinterpret_cast<float*>(cg_dyn_lds);
-  float* sQ = sS + g.KcM * g.JS;
-  float* sDS = sQ + g.KcM * g.JS;                                 // dS of this chunk (few LDS atomics: one per run of equal a)
-  float* sDQ = sDS + g.KcM * g.JS;                                // dQ of this chunk: cell (k, b') belongs to one thread, plain updates
-  float* sDE = sDQ + g.KcM * g.JS;                                // [KcM][PS] de
-  float* sDO = sDE + g.KcM * g.PS;                           // [KcM][PS] do
-  float* sW = sDO + g.KcM * g.PS;                            // [KcM][WS] W0
-  float* sK = sW + g.KcM * g.WS;
+  float* sQ = sS + K::KcM * g.JS;
+  float* sDS = sQ + K::KcM * g.JS;                                 // dS of this chunk: cell (k, a) has one owner thread per tile, plain updates
+  float* sDQ = sDS + K::KcM * g.JS;                                // dQ of this chunk: cell (k, b') belongs to one thread, plain updates
+  float* sDE = sDQ + K::KcM * g.JS;                                // [KcM][PS] de
+  float* sDO = sDE + K::KcM * K::PS;                           // [KcM][PS] do
+  float* sW = sDO + K::KcM * K::PS;                            // [KcM][WS] W0
+  float* sK = sW + K::KcM * K::WS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ADJ_THREADS / 64;
   constexpr int N = VEC ? 4 : 1;
-  const float* gsrc = t.g + (long long)b * t.Kc * g.Pn;
-  const float* eb = t.e + (long long)b * t.Kc * g.Pn;
+  // what the tile loop reads of the argument blocks, once (they live in kernel-argument memory behind a run-time index: the compiler
+  // re-read t.train in front of every element of the staging code)
+  const int Kc = t.Kc, J = t.J, Pn = g.Pn, JS = g.JS;
+  const unsigned magicJ = g.magicJ;
+  const bool train = t.train != 0;
+  const float* gsrc = t.g + (long long)b * Kc * Pn;
+  const float* eb = t.e + (long long)b * Kc * Pn;
   float gbuf[16], ebuf[16];
-  {
-    const int p0 = tile0 * g.PT, np = min(g.PT, g.Pn - p0);
-    cg_adj_fetch<VEC>(g, gsrc, t.Kc, g.Pn, p0, np, gbuf);
-    if (t.train) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, p0, np, ebuf);
-  }
-  cg_adj_tables(t, g, b, sS, sQ);
-  for (int e = tid; e < 2 * g.KcM * g.JS; e += CG_ADJ_THREADS) sDS[e] = 0.f;
-  cg_adj_zero_pad_rows(t, g, sDE, 2);
-  cg_adj_weight(t.W0, t, g, sW);
-  cg_adj_consts(t, g, sK, true, false);
-  const int MT = g.KcM / 16, KJ = t.Kc * t.J;
-  cg_f32x4 wacc[CG_ADJ_MAXW];
 #pragma unroll
-  for (int u = 0; u < CG_ADJ_MAXW; ++u) wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 16; ++i) ebuf[i] = 0.f;             // eval: e is not needed (its coefficient is zero)
+  int nst = 0; (void)nst;
+  CG_ASTAMP();
+  {
+    const int p0 = tile0 * K::PT, np = min(K::PT, Pn - p0);
+    cg_adj_fetch<KCM, VEC>(gsrc, Kc, Pn, p0, np, gbuf);
+    if (train) cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, p0, np, ebuf);
+  }
+  cg_adj_tables<KCM>(t, g, b, sS, sQ);
+  for (int e = tid; e < 2 * K::KcM * g.JS; e += CG_ADJ_THREADS) sDS[e] = 0.f;
+  cg_adj_zero_pad_rows<KCM>(t, g, sDE, 2);
+  cg_adj_weight<KCM>(t.W0, t, g, sW);
+  cg_adj_consts(t, g, sK, true, false);
+  constexpr int MT = K::MT; const int KJ = Kc * J;
+  constexpr int NU = (MT * MT + 3) / 4;                  // weight-gradient tiles of a wave
+  static_assert(MT * K::NP == 8 && NU <= CG_ADJ_MAXW, "task split of the four waves");
+  constexpr int NS = NU == 1 ? 2 : 1;                    // a wave with one tile splits its sum over even / odd steps: two MFMA chains
+  cg_f32x4 wacc[NU][NS];
+#pragma unroll
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int h = 0; h < NS; ++h) wacc[u][h] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  CG_ASTAMP();
   for (int tile = tile0; tile < tile1; ++tile) {
-    const int p0 = tile * g.PT, np = min(g.PT, g.Pn - p0);
+    const int p0 = tile * K::PT, np = min(K::PT, Pn - p0);
     __syncthreads();
-    cg_adj_commit<VEC>(g, t.Kc, np, [&](int c, int pp, bool ok, int off) {
-      const float* k = sK + 8 * c;
+    CG_ASTAMP();                                        // A: top barrier passed
+    // de = scale (g - m1) - (e - mean) [scale rstd m2]  (eval: m1 = m2 = 0): the constants of a channel in two 16-byte LDS reads
+    cg_adj_commit<KCM, VEC>(Kc, np, [&](int c, int pp, bool ok, int off) {
+      const float4 ka = *reinterpret_cast<const float4*>(sK + 8 * c), kb = *reinterpret_cast<const float4*>(sK + 8 * c + 4);
       float v[4];
 #pragma unroll
-      for (int j = 0; j < N; ++j)
-        v[j] = !ok ? 0.f : t.train ? k[2] * (gbuf[off + j] - k[4] - (ebuf[off + j] - k[0]) * k[1] * k[5]) : gbuf[off + j] * k[2];
-      cg_adj_put<VEC>(g, sDE, c, pp, v);
+      for (int j = 0; j < N; ++j) {
+        const float x = ka.z * (gbuf[off + j] - kb.x) - (ebuf[off + j] - ka.x) * kb.w;
+        v[j] = ok ? x : 0.f;
+      }
+      cg_adj_put<KCM, VEC>(sDE, c, pp, v);
     });
+    CG_ASTAMP();                                        // A1: de committed
     // The seed tile o[k][p] = S[k][a] Q[k][b'] of this tile, ONCE, into the image that `do` takes later (it is free until then):
-    // KcM * PT = 4096 = 16 consecutive positions of one slab per thread, (a, b') advanced by steps instead of one division and two
-    // table reads per element and per tile of output rows (the B fragments used to regenerate it MT times)
+    // KcM * PT = 4096 = 16 consecutive positions of one slab per thread.  Rows k >= Kc of the tables are zero.
     {
-      const int per_row = g.PT >> 4, k = tid / per_row, pp0 = 16 * (tid - k * per_row), p = p0 + pp0;
-      const bool kok = k < t.Kc;
-      int a = (int)cg_adj_div((unsigned)p, g.magicJ), bp = p - a * t.J;
-      float sv = (kok && a < t.J) ? sS[k * g.JS + a] : 0.f;
-      float* dst = sDO + k * g.PS + pp0;
+      constexpr int per_row = K::PT >> 4;
+      const int k = tid / per_row, pp0 = 16 * (tid - k * per_row), p = p0 + pp0;
+      const int a = (int)cg_adj_div((unsigned)p, magicJ), bp = p - a * J;
+      const float* srow = sS + k * JS; const float* qrow = sQ + k * JS;
+      float* dst = sDO + k * K::PS + pp0;
+      if (J >= 16) {
+        // at most one step of a inside the 16 positions: no branch, no division per element, and no condition in front of an LDS read
+        // (positions >= Pn get finite values: de is zero there, and `do` overwrites the image)
+        const float s0 = srow[min(a, J)], s1 = srow[min(a + 1, J)];
 #pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        float v[4];
+        for (int j4 = 0; j4 < 4; ++j4) {
+          float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          v[j] = (kok && p + 4 * j4 + j < g.Pn) ? sv * sQ[k * g.JS + bp] : 0.f;
-          if (++bp == t.J) { bp = 0; ++a; sv = (kok && a < t.J) ? sS[k * g.JS + a] : 0.f; }
+          for (int j = 0; j < 4; ++j) {
+            const int bj = bp + 4 * j4 + j;
+            const bool wrap = bj >= J;
+            v[j] = (wrap ? s1 : s0) * qrow[wrap ? bj - J : bj];
+          }
+          *reinterpret_cast<float4*>(dst + 4 * j4) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *reinterpret_cast<float4*>(dst + 4 * j4) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        int aa = a, bb = bp;
+        float sv = aa < J ? srow[aa] : 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] = p + 4 * j4 + j < Pn ? sv * qrow[bb] : 0.f;
+            if (++bb == J) { bb = 0; ++aa; sv = aa < J ? srow[aa] : 0.f; }
+          }
+          *reinterpret_cast<float4*>(dst + 4 * j4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
     }
+    CG_ASTAMP();                                        // A2: seed image written
     __syncthreads();
+    CG_ASTAMP();                                        // A3: barrier
     if (tile + 1 < tile1 && !(dbg & 8)) {
-      const int q0 = p0 + g.PT, nq = min(g.PT, g.Pn - q0);
-      cg_adj_fetch<VEC>(g, gsrc, t.Kc, g.Pn, q0, nq, gbuf);
-      if (t.train) cg_adj_fetch<VEC>(g, eb, t.Kc, g.Pn, q0, nq, ebuf);
+      const int q0 = p0 + K::PT, nq = min(K::PT, Pn - q0);
+      cg_adj_fetch<KCM, VEC>(gsrc, Kc, Pn, q0, nq, gbuf);
+      if (train) cg_adj_fetch<KCM, VEC>(eb, Kc, Pn, q0, nq, ebuf);
     }
-    // dW0[u][k] += sum_p de[u][p] o[k][p]
+    CG_ASTAMP();                                        // B: images committed, prefetch issued
+    // dW0[u][k] += sum_p de[u][p] o[k][p]: the (up to four) output tiles of a wave advance together through the tile's positions, so
+    // their MFMA chains are independent and the LDS reads of a step are issued in front of all of them
+    if (!(dbg & 1) && (MT * MT >= nw || wave < MT * MT)) {       // 1 tile (wave 0), 4 tiles (one per wave) or 16 (four per wave)
 #pragma unroll
-    for (int u = 0; u < CG_ADJ_MAXW; ++u) {
-      const int id = u * nw + wave;
-      if (id < MT * MT && !(dbg & 1)) {
-        const int mt = id / MT, n2 = id - mt * MT;
-        const float* ap = cg_tfrag_ptr<0>(sDE + 16 * mt * g.PS, g.PS, l15, slot);
-        const float* op = cg_tfrag_ptr<0>(sDO + 16 * n2 * g.PS, g.PS, l15, slot);
-#pragma unroll 4
-        for (int k0 = 0; k0 < g.PT; k0 += 16) {
-          float av[4], ov[4];
-          cg_tfrag<0>(ap, g.PS, k0, av); cg_tfrag<0>(op, g.PS, k0, ov);
+      for (int k0 = 0; k0 < K::PT; k0 += 16) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ov[s], wacc[u], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) {
+          const int id = u * nw + wave;
+          {
+            const int mt = id / MT, n2 = id - mt * MT;
+            float av[4], ov[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sDE + 16 * mt * K::PS, K::PS, l15, slot), K::PS, k0, av);
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sDO + 16 * n2 * K::PS, K::PS, l15, slot), K::PS, k0, ov);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wacc[u][(k0 / 16) % NS] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], ov[s], wacc[u][(k0 / 16) % NS], 0, 0, 0);
+          }
         }
       }
     }
+    CG_ASTAMP();                                        // C: dW0 done (this wave)
     __syncthreads();                                    // the seed image has been read: `do` overwrites it
-    // do[k][p] = sum_u W0[u][k] de[u][p]  ->  dS (runs of equal a inside the 16 lanes of a column group), image for dQ
-    for (int w = wave; w < MT * g.NP && !(dbg & 2); w += nw) {
-      const int mt = w / g.NP, n0 = 32 * (w - mt * g.NP), n1 = n0 + 16;
-      cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* ap = cg_tfrag_ptr<1>(sW + 16 * mt, g.WS, l15, slot);
-      const float* bp0 = cg_tfrag_ptr<1>(sDE + n0, g.PS, l15, slot);
-      const float* bp1 = cg_tfrag_ptr<1>(sDE + n1, g.PS, l15, slot);
-      for (int k0 = 0; k0 < g.KcM; k0 += 16) {
-        float av[4], b0v[4], b1v[4];
-        cg_tfrag<1>(ap, g.WS, k0, av); cg_tfrag<1>(bp0, g.PS, k0, b0v); cg_tfrag<1>(bp1, g.PS, k0, b1v);
+    CG_ASTAMP();                                        // D: barrier
+    // do[k][p] = sum_u W0[u][k] de[u][p]  ->  image for the dS / dQ cells
+    // (always eight tasks = two per wave: MT * NP == 8; both advance through k together: four independent MFMA chains)
+    cg_f32x4 dacc[2][2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);
-          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], c1, 0, 0, 0);
+    for (int ti = 0; ti < 2; ++ti) dacc[ti][0] = dacc[ti][1] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(dbg & 2)) {
+#pragma unroll
+      for (int k0 = 0; k0 < K::KcM; k0 += 16) {
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+          const int w = wave + nw * ti, mt = w / K::NP, n0 = 32 * (w - mt * K::NP), n1 = n0 + 16;
+          float av[4], b0v[4], b1v[4];
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sW + 16 * mt, K::WS, l15, slot), K::WS, k0, av);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sDE + n0, K::PS, l15, slot), K::PS, k0, b0v);
+          cg_tfrag<1>(cg_tfrag_ptr<1>(sDE + n1, K::PS, l15, slot), K::PS, k0, b1v);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            dacc[ti][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], dacc[ti][0], 0, 0, 0);
+            dacc[ti][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1v[s], av[s], dacc[ti][1], 0, 0, 0);
+          }
         }
       }
-      // C[position][slab]: lane = slab k, four consecutive positions: the do image in one float4, dS by runs of equal a
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2 && !(dbg & 2); ++ti) {
+      const int w = wave + nw * ti, mt = w / K::NP, n0 = 32 * (w - mt * K::NP), n1 = n0 + 16;
+      // C[position][slab]: lane = slab k, four consecutive positions: the do image in one float4
       const int k = 16 * mt + l15;
-      const bool kok = k < t.Kc;
+      const bool kok = k < Kc;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int pq = (h ? n1 : n0) + 4 * slot;
-        const cg_f32x4 c = h ? c1 : c0;
+        const cg_f32x4 c = h ? dacc[ti][1] : dacc[ti][0];
         float d[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) d[q] = (kok && pq + q < np) ? c[q] : 0.f;
-        *reinterpret_cast<float4*>(sDO + k * g.PS + pq) = make_float4(d[0], d[1], d[2], d[3]);
-        if (kok && pq < np) {
-          int a = (int)cg_adj_div((unsigned)(p0 + pq), g.magicJ), bp = p0 + pq - a * t.J;
-          float acc = 0.f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if (pq + q < np) acc += d[q] * sQ[k * g.JS + bp];
-            if (++bp == t.J) { if (a < t.J) atomicAdd(&sDS[k * g.JS + a], acc); acc = 0.f; bp = 0; ++a; }
-          }
-          if (bp != 0 && a < t.J) atomicAdd(&sDS[k * g.JS + a], acc);
-        }
+        *reinterpret_cast<float4*>(sDO + k * K::PS + pq) = make_float4(d[0], d[1], d[2], d[3]);
       }
     }
     __syncthreads();
-    // dQ[k][b'] += sum over the tile's positions p = (a, b') of do[k][p] S[k][a]: every cell has one owner thread
-    const int r0 = p0 - (int)cg_adj_div((unsigned)p0, g.magicJ) * t.J;     // b' of the tile's first position
-    for (int cell = tid; cell < KJ && !(dbg & 16); cell += CG_ADJ_THREADS) {
-      const int k = (int)cg_adj_div((unsigned)cell, g.magicJ), bq = cell - k * t.J;
-      float acc = 0.f;
-      for (int pp = bq - r0 + (bq < r0 ? t.J : 0); pp < np; pp += t.J)
-        acc += sDO[k * g.PS + pp] * sS[k * g.JS + (int)cg_adj_div((unsigned)(p0 + pp), g.magicJ)];
-      sDQ[k * g.JS + bq] += acc;
+    CG_ASTAMP();                                        // E: do done, barrier passed
+    // The tile covers the positions p0 .. p0 + np - 1 = (a0, r0) .. in row-major (a, b') order.  Both reductions of the `do` image are
+    // owned cells (no atomics): dQ[k][b'] += sum_m do[k][b' - r0 + J m] S[k][a0 + m]  (one cell per (k, b'), a few terms each) and
+    // dS[k][a0 + m] += sum_b' do[k][J m - r0 + b'] Q[k][b']  (one cell per (k, m): a contiguous run of the image against a row of Q).
+    // Measured alternatives (profiles/r04_stamps.txt): LDS float atomics straight from the result registers (24 ds_add_f32 per wave and
+    // tile: 25 000 cycles, against 6 000 for this pass); four lanes per dS cell with a DPP sum, register-resident dQ cells: no gain -
+    // the pass is bound by the index arithmetic in front of each term, not by its LDS reads.
+    const int a0 = (int)cg_adj_div((unsigned)p0, magicJ), r0 = p0 - a0 * J;
+    if (!(dbg & 16)) {
+      for (int cell = tid; cell < KJ; cell += CG_ADJ_THREADS) {
+        const int k = (int)cg_adj_div((unsigned)cell, magicJ), bq = cell - k * J;
+        const float* img = sDO + k * K::PS; const float* srow = sS + k * JS + a0;
+        float acc = 0.f;
+        int m = bq < r0 ? 1 : 0;
+        for (int pp = bq - r0 + J * m; pp < np; pp += J, ++m) acc += img[pp] * srow[m];
+        sDQ[k * JS + bq] += acc;
+      }
+      const int M = (r0 + np - 1) / J + 1;               // rows a of the position grid that the tile touches
+      for (int cell = tid; cell < Kc * M; cell += CG_ADJ_THREADS) {
+        const int k = cell / M, m = cell - k * M;
+        const int lo = max(0, J * m - r0), hi = min(np, J * (m + 1) - r0);
+        const float* img = sDO + k * K::PS; const float* qrow = sQ + k * JS + (r0 - J * m);
+        float acc0 = 0.f, acc1 = 0.f;
+        int pp = lo;
+        for (; pp + 1 < hi; pp += 2) { acc0 += img[pp] * qrow[pp]; acc1 += img[pp + 1] * qrow[pp + 1]; }
+        if (pp < hi) acc0 += img[pp] * qrow[pp];
+        if (a0 + m < J) sDS[k * JS + a0 + m] += acc0 + acc1;
+      }
     }
   }
   __syncthreads();
+  CG_ASTAMP();
   // this chunk's share of dS / dQ: [b][chunk][2][Kc * J], summed over the chunks by cg_adj_finish_kernel
   if (dbg & 32) return;
   float* part = t.part + ((long long)b * g.nch + ch) * 2 * KJ;
@@ -633,17 +776,19 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
   }
   float* dW = t.dW0_ws + (long long)(blockIdx.x % CG_ADJ_REPLICAS) * t.Kc * t.Kc;
 #pragma unroll
-  for (int u = 0; u < CG_ADJ_MAXW; ++u) {
+  for (int u = 0; u < NU; ++u) {
     const int id = u * nw + wave;
     if (id < MT * MT) {
       const int mt = id / MT, n2 = id - mt * MT;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 16 * mt + 4 * slot + q, c = 16 * n2 + l15;
-        if (r < t.Kc && c < t.Kc) atomicAdd(&dW[r * t.Kc + c], wacc[u][q]);
+        if (r < t.Kc && c < t.Kc) atomicAdd(&dW[r * t.Kc + c], NS == 2 ? wacc[u][0][q] + wacc[u][NS - 1][q] : wacc[u][0][q]);
       }
     }
   }
+  CG_ASTAMP();
+  CG_ASTAMP_END();
 }
 
 __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailPair pr) {
@@ -652,8 +797,8 @@ __global__ __launch_bounds__(CG_ADJ_THREADS, 2) void cg_adj_n2_kernel(CgAdjTailP
   const int b = blockIdx.x / pr.nch_max, ch = blockIdx.x - b * pr.nch_max;
   if (ch >= g.nch) return;
   const int tile0 = ch * g.tpw, tile1 = min(g.ntiles, tile0 + g.tpw);
-  if ((g.Pn & 3) == 0) cg_adj_n2_body<true>(t, g, b, ch, tile0, tile1, pr.dbg);
-  else cg_adj_n2_body<false>(t, g, b, ch, tile0, tile1, pr.dbg);
+  if ((g.Pn & 3) == 0) { CG_ADJ_DISPATCH(g.KcM, (cg_adj_n2_body<KCM, true>(t, g, b, ch, tile0, tile1, pr.dbg))) }
+  else { CG_ADJ_DISPATCH(g.KcM, (cg_adj_n2_body<KCM, false>(t, g, b, ch, tile0, tile1, pr.dbg))) }
 }
 
 // per-channel parameter gradients, fold of the replicated weight gradients and of the per-chunk dS / dQ (both towers)

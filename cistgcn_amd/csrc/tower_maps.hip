@@ -11,6 +11,7 @@
 #include "cg_common.h"
 #include "cg_phase.h"
 #include "tower_maps.h"
+#include <type_traits>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
@@ -25,12 +26,34 @@ struct CgPwGeom {
 };
 struct CgPwArgs { CgPwMaps t; CgPwGeom g; };
 
+// The tile geometry as the kernels see it.  NT_ / CT_ > 0: 16-row tiles of the stacked maps / of the input channels known at compile time
+// (one instantiation per shape of the shipped configurations): every size below is then a constant, the matrix-core loops unroll with
+// constant LDS offsets and independent accumulator chains.  NT_ == 0: the sizes the host computed (any shape the entry point accepts).
+// BWD: the backward kernel sizes its tile by the larger of the two stacks.
+template <int NT_, int CT_, bool BWD>
+struct CgPwK {
+  const CgPwGeom& g;
+  static constexpr int kBig = BWD ? (NT_ > CT_ ? NT_ : CT_) : CT_;
+  static_assert((kBig & (kBig - 1)) == 0, "the host's tile width (cg_pwm_geometry) equals 8192 / rows only for power-of-two stacks");
+  static constexpr int kPT = NT_ ? (16 * CG_PWM_THREADS / (16 * kBig) > 256 ? 256 : 16 * CG_PWM_THREADS / (16 * kBig)) : 0;
+  static constexpr int kLgq = kPT == 256 ? 6 : kPT == 128 ? 5 : kPT == 64 ? 4 : kPT == 32 ? 3 : kPT == 16 ? 2 : 0;
+  __device__ __forceinline__ int CinM() const { return NT_ ? 16 * CT_ : g.CinM; }
+  __device__ __forceinline__ int MM() const { return NT_ ? 16 * NT_ : g.MM; }
+  __device__ __forceinline__ int WS() const { return NT_ ? 16 * CT_ + 4 : g.WS; }
+  __device__ __forceinline__ int NT() const { return NT_ ? NT_ : g.NT; }
+  __device__ __forceinline__ int CT() const { return NT_ ? CT_ : g.CT; }
+  __device__ __forceinline__ int PT() const { return NT_ ? kPT : g.PT; }
+  __device__ __forceinline__ int PS() const { return NT_ ? kPT + 4 : g.PS; }
+  __device__ __forceinline__ int lgq() const { return NT_ ? kLgq : g.lgq; }
+};
+
 // stacked weights -> sW [MM][WS]; rows beyond a map's M_i and columns beyond Cin are zero
 // stacked weights [MM][WS] into LDS, zero in the padding.  Map by map (the map index is a scalar): looking the map of a stacked row up
 // per element - kernel-argument tables indexed by a lane value, three dependent loads - made this prologue 30 k cycles
-__device__ __forceinline__ void cg_pwm_weights(const CgPwArgs& a, float* sW) {
+template <typename KT>
+__device__ __forceinline__ void cg_pwm_weights(const CgPwArgs& a, const KT& G, float* sW) {
   const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
-  for (int e = threadIdx.x; e < g.MM * g.WS; e += CG_PWM_THREADS) sW[e] = 0.f;
+  for (int e = threadIdx.x; e < G.MM() * G.WS(); e += CG_PWM_THREADS) sW[e] = 0.f;
   __syncthreads();
   for (int i = 0; i < t.n; ++i) {
     const float* __restrict__ W = t.W[i];
@@ -38,16 +61,16 @@ __device__ __forceinline__ void cg_pwm_weights(const CgPwArgs& a, float* sW) {
 #pragma unroll 4
     for (int e = threadIdx.x; e < n; e += CG_PWM_THREADS) {
       const int m = e / t.Cin, c = e - m * t.Cin;
-      sW[(r0 + m) * g.WS + c] = W[e];
+      sW[(r0 + m) * G.WS() + c] = W[e];
     }
   }
 }
 
-template <typename SRC>
-__device__ __forceinline__ void cg_pwm_fetch(const CgPwGeom& g, int np, float buf[16], SRC src) {
+template <typename KT, typename SRC>
+__device__ __forceinline__ void cg_pwm_fetch(const CgPwGeom& g, const KT& G, int np, float buf[16], SRC src) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> G.lgq(), pp = 4 * (e & ((1 << G.lgq()) - 1));
     const float* p = pp < np ? src(row) : nullptr;         // nullptr: row outside the tensor
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p != nullptr) {
@@ -70,15 +93,21 @@ __device__ __forceinline__ void cg_pwm_store_quad(const CgPwGeom& g, float* row,
 }
 // the same fetch from row pointers resolved ONCE per kernel (slot r of a thread is the same tile row in every tile): base[r] is the row
 // at sample 0 / position 0 or nullptr, off[r] the element offset of this tile's sample and first position
-__device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, int np, float buf[16], const float* const base[4], const long long off[4]) {
+template <typename KT>
+__device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, const KT& G, int np, float buf[16], const float* const base[4], const long long off[4], const float* safe) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << g.lgq) - 1));
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << G.lgq()) - 1));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (base[r] != nullptr && pp < np) {
+    if (g.vw == 4) {
+      // no branch around the load (`safe`, a readable 16-byte aligned address, stands in for what lies outside the tensor): the loads of a
+      // thread issue back to back
+      const bool in = base[r] != nullptr && pp < np;
+      const float4 w = *reinterpret_cast<const float4*>(in ? base[r] + off[r] + pp : safe);
+      v = make_float4(in ? w.x : 0.f, in ? w.y : 0.f, in ? w.z : 0.f, in ? w.w : 0.f);
+    } else if (base[r] != nullptr && pp < np) {
       const float* p = base[r] + off[r] + pp;
-      if (g.vw == 4) v = *reinterpret_cast<const float4*>(p);
-      else {
+      {
         const float2 lo = *reinterpret_cast<const float2*>(p);
         v.x = lo.x; v.y = lo.y;
         if (pp + 2 < np) { const float2 hi = *reinterpret_cast<const float2*>(p + 2); v.z = hi.x; v.w = hi.y; }
@@ -87,56 +116,59 @@ __device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, int np, flo
     buf[4 * r] = v.x; buf[4 * r + 1] = v.y; buf[4 * r + 2] = v.z; buf[4 * r + 3] = v.w;
   }
 }
-__device__ __forceinline__ void cg_pwm_commit(const CgPwGeom& g, int rows, const float buf[16], float* img) {
+template <typename KT>
+__device__ __forceinline__ void cg_pwm_commit(const KT& G, int rows, const float buf[16], float* img) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> g.lgq, pp = 4 * (e & ((1 << g.lgq) - 1));
-    if (row < rows) *reinterpret_cast<float4*>(img + row * g.PS + pp) = make_float4(buf[4 * r], buf[4 * r + 1], buf[4 * r + 2], buf[4 * r + 3]);
+    const int e = (int)threadIdx.x + CG_PWM_THREADS * r, row = e >> G.lgq(), pp = 4 * (e & ((1 << G.lgq()) - 1));
+    if (row < rows) *reinterpret_cast<float4*>(img + row * G.PS() + pp) = make_float4(buf[4 * r], buf[4 * r + 1], buf[4 * r + 2], buf[4 * r + 3]);
   }
 }
 
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
+template <int NT_, int CT_>
 __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) {
   const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  const CgPwK<NT_, CT_, false> G{g};
   float* sX = reinterpret_cast<float*>(cg_dyn_lds);              // [CinM][PS]
-  float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
-  double* sStat = reinterpret_cast<double*>(sW + g.MM * g.WS + ((g.CinM * g.PS + g.MM * g.WS) & 1));      // [MM][2]
-  float* sBias = reinterpret_cast<float*>(sStat + 2 * g.MM);                                                // [MM]
+  float* sW = sX + G.CinM() * G.PS();                                 // [MM][WS]
+  double* sStat = reinterpret_cast<double*>(sW + G.MM() * G.WS() + ((G.CinM() * G.PS() + G.MM() * G.WS()) & 1));      // [MM][2]
+  float* sBias = reinterpret_cast<float*>(sStat + 2 * G.MM());                                                // [MM]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
   float xbuf[16];
   auto xsrc = [&](int lid) {
-    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT;
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT();
     const float* base = t.x + (long long)b * t.Cin * t.P + p0;
-    cg_pwm_fetch(g, min(g.PT, t.P - p0), xbuf, [&](int row) { return row < t.Cin ? base + (long long)row * t.P : nullptr; });
+    cg_pwm_fetch(g, G, min(G.PT(), t.P - p0), xbuf, [&](int row) { return row < t.Cin ? base + (long long)row * t.P : nullptr; });
   };
   xsrc(lid0);
-  cg_pwm_weights(a, sW);
-  for (int e = tid; e < g.CinM * g.PS; e += CG_PWM_THREADS) sX[e] = 0.f;
+  cg_pwm_weights(a, G, sW);
+  for (int e = tid; e < G.CinM() * G.PS(); e += CG_PWM_THREADS) sX[e] = 0.f;
   const bool stats = t.stats[0] != nullptr;
-  if (stats) for (int e = tid; e < 2 * g.MM; e += CG_PWM_THREADS) sStat[e] = 0.0;
-  for (int r = tid; r < g.MM; r += CG_PWM_THREADS) {
+  if (stats) for (int e = tid; e < 2 * G.MM(); e += CG_PWM_THREADS) sStat[e] = 0.0;
+  for (int r = tid; r < G.MM(); r += CG_PWM_THREADS) {
     const int tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
     sBias[r] = (m < t.M[i] && t.bias[i]) ? t.bias[i][m] : 0.f;
   }
   for (int lid = lid0; lid < lid1; ++lid) {
-    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT(), np = min(G.PT(), t.P - p0);
     __syncthreads();
-    cg_pwm_commit(g, t.Cin, xbuf, sX);
+    cg_pwm_commit(G, t.Cin, xbuf, sX);
     __syncthreads();
     if (lid + 1 < lid1) xsrc(lid + 1);
-    for (int w = wave; w < (g.PT / 32) * g.NT; w += CG_PWM_THREADS / 64) {
-      const int pg = w / g.NT, nt = w - pg * g.NT, n0 = 32 * pg, n1 = n0 + 16;
+    for (int w = wave; w < (G.PT() / 32) * G.NT(); w += CG_PWM_THREADS / 64) {
+      const int pg = w / G.NT(), nt = w - pg * G.NT(), n0 = 32 * pg, n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* wp = cg_tfrag_ptr<0>(sW + 16 * nt * g.WS, g.WS, l15, slot);
-      const float* xp0 = cg_tfrag_ptr<1>(sX + n0, g.PS, l15, slot);
-      const float* xp1 = cg_tfrag_ptr<1>(sX + n1, g.PS, l15, slot);
-      for (int k0 = 0; k0 < g.CinM; k0 += 16) {
+      const float* wp = cg_tfrag_ptr<0>(sW + 16 * nt * G.WS(), G.WS(), l15, slot);
+      const float* xp0 = cg_tfrag_ptr<1>(sX + n0, G.PS(), l15, slot);
+      const float* xp1 = cg_tfrag_ptr<1>(sX + n1, G.PS(), l15, slot);
+      for (int k0 = 0; k0 < G.CinM(); k0 += 16) {
         float wv[4], x0v[4], x1v[4];
-        cg_tfrag<0>(wp, g.WS, k0, wv); cg_tfrag<1>(xp0, g.PS, k0, x0v); cg_tfrag<1>(xp1, g.PS, k0, x1v);
+        cg_tfrag<0>(wp, G.WS(), k0, wv); cg_tfrag<1>(xp0, G.PS(), k0, x0v); cg_tfrag<1>(xp1, G.PS(), k0, x1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {                     // C[position][output channel]
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0v[s], wv[s], c0, 0, 0, 0);
@@ -164,7 +196,7 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
   }
   if (stats) {
     __syncthreads();
-    for (int e = tid; e < 2 * g.MM; e += CG_PWM_THREADS) {
+    for (int e = tid; e < 2 * G.MM(); e += CG_PWM_THREADS) {
       const int r = e >> 1, tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
       if (m < t.M[i]) atomicAdd(&t.stats[i][((long long)(blockIdx.x % CG_STAT_REPLICAS) * t.M[i] + m) * 2 + (e & 1)], sStat[e]);
     }
@@ -191,11 +223,13 @@ extern "C" int cg_pwm_set_stamps(void* p) { return (int)hipMemcpyToSymbol(HIP_SY
 
 #define CG_PWM_MAXW 4        // weight-gradient register tiles per wave: (stacked rows / 16) * (Cin / 16) <= 32 over 8 waves (128 x 64, 64 x 128, 32 x 112 ...)
 
+template <int NT_, int CT_>
 __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) {
   const CgPwMaps& t = a.t; const CgPwGeom& g = a.g;
+  const CgPwK<NT_, CT_, true> G{g};
   float* sD = reinterpret_cast<float*>(cg_dyn_lds);              // [MM][PS]   dy of every map, stacked
-  float* sX = sD + g.MM * g.PS;                                   // [CinM][PS]
-  float* sW = sX + g.CinM * g.PS;                                 // [MM][WS]
+  float* sX = sD + G.MM() * G.PS();                                   // [CinM][PS]
+  float* sW = sX + G.CinM() * G.PS();                                 // [MM][WS]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_PWM_THREADS / 64;
   const int lid0 = blockIdx.x * g.per, lid1 = min(g.total, lid0 + g.per);
   if (lid0 >= g.total) return;
@@ -212,11 +246,11 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   float ybuf[16];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = ((int)threadIdx.x + CG_PWM_THREADS * r) >> g.lgq;
+    const int row = ((int)threadIdx.x + CG_PWM_THREADS * r) >> G.lgq();
     xrow[r] = row < t.Cin ? t.x + (long long)row * t.P : nullptr;
     drow[r] = nullptr; yrow[r] = nullptr; dstr[r] = 0;
     k_mean[r] = 0.f; k_rstd[r] = 0.f; k_scale[r] = 0.f; k_beta[r] = 0.f; k_m1[r] = 0.f; k_m2[r] = 0.f; k_alpha[r] = 1.f;
-    if (row < g.MM) {
+    if (row < G.MM()) {
       const int tile = row >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (row & 15);
       if (m < t.M[i]) {
         drow[r] = t.dy[i] + (long long)m * t.P; dstr[r] = (long long)t.M[i] * t.P;
@@ -233,21 +267,22 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
       }
     }
   }
+  const float* const xsafe = t.x;                       // rows are 16-byte aligned when vw == 4 (P % 4 == 0), and so is the tensor's base
   auto fetch = [&](int lid) {
-    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT(), np = min(G.PT(), t.P - p0);
     long long xo[4], doff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { xo[r] = (long long)b * t.Cin * t.P + p0; doff[r] = (long long)b * dstr[r] + p0; }
-    cg_pwm_fetch_rows(g, np, xbuf, xrow, xo);
-    cg_pwm_fetch_rows(g, np, dbuf, drow, doff);
-    if (undo) cg_pwm_fetch_rows(g, np, ybuf, yrow, doff);
+    cg_pwm_fetch_rows(g, G, np, xbuf, xrow, xo, xsafe);
+    cg_pwm_fetch_rows(g, G, np, dbuf, drow, doff, xsafe);
+    if (undo) cg_pwm_fetch_rows(g, G, np, ybuf, yrow, doff, xsafe);
   };
   // gradient in front of the BatchNorm from the one behind the PReLU (cg_norm_act's backward, applied to the staged values; zeros of the
   // padding stay zeros only where dy AND the sums' terms vanish: rows / positions outside the tensor are masked by their null row pointer)
   auto undo_rows = [&](int np) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << g.lgq) - 1));
+      const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << G.lgq()) - 1));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float d = ybuf[4 * r + j] - k_mean[r];
@@ -259,8 +294,8 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
     }
   };
   fetch(lid0);
-  cg_pwm_weights(a, sW);
-  for (int e = tid; e < (g.MM + g.CinM) * g.PS; e += CG_PWM_THREADS) sD[e] = 0.f;
+  cg_pwm_weights(a, G, sW);
+  for (int e = tid; e < (G.MM() + G.CinM()) * G.PS(); e += CG_PWM_THREADS) sD[e] = 0.f;
   cg_f32x4 wacc[CG_PWM_MAXW], bacc[CG_PWM_MAXW];      // bacc: row sums of dy (bias gradient) on the tiles of the first channel column
 #pragma unroll
   for (int u = 0; u < CG_PWM_MAXW; ++u) { wacc[u] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; bacc[u] = wacc[u]; }
@@ -268,34 +303,61 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
   for (int i = 0; i < t.n; ++i) want_db = want_db || t.db[i] != nullptr;
   CG_PSTAMP();
   for (int lid = lid0; lid < lid1; ++lid) {
-    const int b = lid / g.tps, p0 = (lid - b * g.tps) * g.PT, np = min(g.PT, t.P - p0);
+    const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT(), np = min(G.PT(), t.P - p0);
     __syncthreads();
     CG_PSTAMP();
     if (undo) undo_rows(np);
-    cg_pwm_commit(g, g.MM, dbuf, sD);                              // rows of the padding and positions beyond the tensor arrive as zeros
-    cg_pwm_commit(g, t.Cin, xbuf, sX);
+    cg_pwm_commit(G, G.MM(), dbuf, sD);                              // rows of the padding and positions beyond the tensor arrive as zeros
+    cg_pwm_commit(G, t.Cin, xbuf, sX);
     __syncthreads();
     CG_PSTAMP();
     if (lid + 1 < lid1) fetch(lid + 1);
     CG_PSTAMP();
-    // dW[m][c] += sum_p dy[m][p] x[c][p]: two register tiles at a time (independent MFMA chains)
+    // dW[m][c] += sum_p dy[m][p] x[c][p]
+    if (NT_) {
+      // known geometry: tile id = u * nw + wave = mt * CT + ct with ct = wave % CT (nw % CT == 0): the NU tiles of a wave share their x
+      // fragment and advance through the positions together - 1 + NU LDS reads for 4 NU MFMAs in NU independent chains
+      constexpr int CTc = CT_ ? CT_ : 1, NU = NT_ * CTc / (CG_PWM_THREADS / 64) ? NT_ * CTc / (CG_PWM_THREADS / 64) : 1;
+      static_assert(NT_ == 0 || ((NT_ * CTc) % (CG_PWM_THREADS / 64) == 0 && (CG_PWM_THREADS / 64) % CTc == 0 && NU <= CG_PWM_MAXW), "tile split of the eight waves");
+      const int ct = wave % CTc, mtb = wave / CTc;
+      const bool dbw = want_db && ct == 0;                 // wave-uniform
+      auto product = [&](auto with_db) {
 #pragma unroll
-    for (int u = 0; u < CG_PWM_MAXW; u += 2) {
-      const int id0 = u * nw + wave, id1 = (u + 1) * nw + wave;
-      if (id0 < g.NT * g.CT) {
-        const bool two = id1 < g.NT * g.CT;
-        const int mt0 = id0 / g.CT, ct0 = id0 - mt0 * g.CT, mt1 = two ? id1 / g.CT : mt0, ct1 = two ? id1 - mt1 * g.CT : ct0;
-        const float* ap0 = cg_tfrag_ptr<0>(sD + 16 * mt0 * g.PS, g.PS, l15, slot);
-        const float* bp0 = cg_tfrag_ptr<0>(sX + 16 * ct0 * g.PS, g.PS, l15, slot);
-        const float* ap1 = cg_tfrag_ptr<0>(sD + 16 * mt1 * g.PS, g.PS, l15, slot);
-        const float* bp1 = cg_tfrag_ptr<0>(sX + 16 * ct1 * g.PS, g.PS, l15, slot);
+        for (int k0 = 0; k0 < G.PT(); k0 += 16) {
+          float bv[4];
+          cg_tfrag<0>(cg_tfrag_ptr<0>(sX + 16 * ct * G.PS(), G.PS(), l15, slot), G.PS(), k0, bv);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            float av[4];
+            cg_tfrag<0>(cg_tfrag_ptr<0>(sD + 16 * (mtb + u * ((CG_PWM_THREADS / 64) / CTc)) * G.PS(), G.PS(), l15, slot), G.PS(), k0, av);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], wacc[u], 0, 0, 0);
+            if (decltype(with_db)::value) {                // dy . 1: every column of the tile = the row sums
+#pragma unroll
+              for (int s = 0; s < 4; ++s) bacc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], 1.f, bacc[u], 0, 0, 0);
+            }
+          }
+        }
+      };
+      if (dbw) product(std::true_type{}); else product(std::false_type{});
+    } else {
+    // two register tiles at a time (independent MFMA chains)
+#pragma unroll
+    for (int u = 0; u < CG_PWM_MAXW; u += 2) {      const int id0 = u * nw + wave, id1 = (u + 1) * nw + wave;
+      if (id0 < G.NT() * G.CT()) {
+        const bool two = id1 < G.NT() * G.CT();
+        const int mt0 = id0 / G.CT(), ct0 = id0 - mt0 * G.CT(), mt1 = two ? id1 / G.CT() : mt0, ct1 = two ? id1 - mt1 * G.CT() : ct0;
+        const float* ap0 = cg_tfrag_ptr<0>(sD + 16 * mt0 * G.PS(), G.PS(), l15, slot);
+        const float* bp0 = cg_tfrag_ptr<0>(sX + 16 * ct0 * G.PS(), G.PS(), l15, slot);
+        const float* ap1 = cg_tfrag_ptr<0>(sD + 16 * mt1 * G.PS(), G.PS(), l15, slot);
+        const float* bp1 = cg_tfrag_ptr<0>(sX + 16 * ct1 * G.PS(), G.PS(), l15, slot);
         cg_f32x4 w0 = wacc[u], w1 = wacc[u + 1];
         const bool db0 = want_db && ct0 == 0, db1 = want_db && two && ct1 == 0;      // wave-uniform
         cg_f32x4 s0 = bacc[u], s1 = bacc[u + 1];
 #pragma unroll 2
-        for (int k0 = 0; k0 < g.PT; k0 += 16) {
+        for (int k0 = 0; k0 < G.PT(); k0 += 16) {
           float a0[4], b0[4], a1[4], b1[4];
-          cg_tfrag<0>(ap0, g.PS, k0, a0); cg_tfrag<0>(bp0, g.PS, k0, b0); cg_tfrag<0>(ap1, g.PS, k0, a1); cg_tfrag<0>(bp1, g.PS, k0, b1);
+          cg_tfrag<0>(ap0, G.PS(), k0, a0); cg_tfrag<0>(bp0, G.PS(), k0, b0); cg_tfrag<0>(ap1, G.PS(), k0, a1); cg_tfrag<0>(bp1, G.PS(), k0, b1);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             w0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s], b0[s], w0, 0, 0, 0);
@@ -314,17 +376,18 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
         if (two) { wacc[u + 1] = w1; bacc[u + 1] = s1; }
       }
     }
+    }
     CG_PSTAMP();
     // dx[p][c] = sum_m dy[m][p] W[m][c]
-    for (int w = wave; w < (g.PT / 32) * g.CT; w += nw) {
-      const int pg = w / g.CT, ct = w - pg * g.CT, n0 = 32 * pg, n1 = n0 + 16;
+    for (int w = wave; w < (G.PT() / 32) * G.CT(); w += nw) {
+      const int pg = w / G.CT(), ct = w - pg * G.CT(), n0 = 32 * pg, n1 = n0 + 16;
       cg_f32x4 c0 = cg_f32x4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      const float* wp = cg_tfrag_ptr<1>(sW + 16 * ct, g.WS, l15, slot);
-      const float* dp0 = cg_tfrag_ptr<1>(sD + n0, g.PS, l15, slot);
-      const float* dp1 = cg_tfrag_ptr<1>(sD + n1, g.PS, l15, slot);
-      for (int k0 = 0; k0 < g.MM; k0 += 16) {
+      const float* wp = cg_tfrag_ptr<1>(sW + 16 * ct, G.WS(), l15, slot);
+      const float* dp0 = cg_tfrag_ptr<1>(sD + n0, G.PS(), l15, slot);
+      const float* dp1 = cg_tfrag_ptr<1>(sD + n1, G.PS(), l15, slot);
+      for (int k0 = 0; k0 < G.MM(); k0 += 16) {
         float wv[4], d0v[4], d1v[4];
-        cg_tfrag<1>(wp, g.WS, k0, wv); cg_tfrag<1>(dp0, g.PS, k0, d0v); cg_tfrag<1>(dp1, g.PS, k0, d1v);
+        cg_tfrag<1>(wp, G.WS(), k0, wv); cg_tfrag<1>(dp0, G.PS(), k0, d0v); cg_tfrag<1>(dp1, G.PS(), k0, d1v);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(d0v[s], wv[s], c0, 0, 0, 0);
@@ -347,8 +410,8 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
 #pragma unroll
   for (int u = 0; u < CG_PWM_MAXW; ++u) {
     const int id = u * nw + wave;
-    if (id < g.NT * g.CT) {
-      const int mt = id / g.CT, ct = id - mt * g.CT;
+    if (id < G.NT() * G.CT()) {
+      const int mt = id / G.CT(), ct = id - mt * G.CT();
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 16 * mt + 4 * slot + q, c = 16 * ct + l15;
@@ -416,6 +479,15 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   return CG_OK;
 }
 
+// the instantiations with compile-time geometry: (stacked 16-row tiles, input 16-row tiles) of the shipped configurations; anything else
+// takes the run-time form
+#define CG_PWM_DISPATCH(G_, LAUNCH)                                   \
+  if ((G_).NT == 8 && (G_).CT == 4) LAUNCH(8, 4)        /* four 32-channel towers of a 64-channel block (and 2 x 64 residual maps) */ \
+  else if ((G_).NT == 8 && (G_).CT == 1) LAUNCH(8, 1)   /* 128 stacked rows of the 10-channel input block */                         \
+  else if ((G_).NT == 4 && (G_).CT == 2) LAUNCH(4, 2)   /* four 16-channel towers of a 32-channel block */                           \
+  else if ((G_).NT == 4 && (G_).CT == 4) LAUNCH(4, 4)                                                                                \
+  else LAUNCH(0, 0)
+
 extern "C" long long cg_pointwise_maps_ws_floats(int Cin) { return (long long)CG_PWM_REPLICAS * CG_PWM_MAXROWS * (Cin + 1); }      // + the bias-gradient rows
 
 // include/cistgcn_hip.h : cg_pointwise_maps_fwd / cg_pointwise_maps_bwd
@@ -429,10 +501,15 @@ extern "C" int cg_pointwise_maps_fwd(const CgPwMaps* t, void* stream_) {
     if ((t->stats[i] != nullptr) != (t->stats[0] != nullptr)) return CG_EARG;
   }
   const size_t lds = ((size_t)a.g.CinM * a.g.PS + (size_t)a.g.MM * a.g.WS + 2 + (size_t)5 * a.g.MM) * sizeof(float);
-  hipError_t e = cg_lds_limit((const void*)cg_pwm_fwd_kernel, lds);
-  if (e != hipSuccess) return (int)e;
   const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
-  hipLaunchKernelGGL(cg_pwm_fwd_kernel, dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, (hipStream_t)stream_, a);
+#define CG_PWM_FWD_LAUNCH(N, C)                                                                                         \
+  {                                                                                                                    \
+    hipError_t e = cg_lds_limit((const void*)cg_pwm_fwd_kernel<N, C>, lds);                                            \
+    if (e != hipSuccess) return (int)e;                                                                                \
+    hipLaunchKernelGGL((cg_pwm_fwd_kernel<N, C>), dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, (hipStream_t)stream_, a); \
+  }
+  CG_PWM_DISPATCH(a.g, CG_PWM_FWD_LAUNCH)
+#undef CG_PWM_FWD_LAUNCH
   return cg_launch_status();
 }
 
@@ -448,11 +525,16 @@ extern "C" int cg_pointwise_maps_bwd(const CgPwMaps* t, void* stream_) {
     if (t->yraw[i] && (!t->bn_save[i] || !t->bn_gamma[i] || !t->bn_beta[i] || !t->prelu[i] || (t->bn_train && !t->bn_red[i]))) return CG_EARG;
   }
   const size_t lds = ((size_t)(a.g.MM + a.g.CinM) * a.g.PS + (size_t)a.g.MM * a.g.WS) * sizeof(float);
-  hipError_t e = cg_lds_limit((const void*)cg_pwm_bwd_kernel, lds);
-  if (e != hipSuccess) return (int)e;
   const int nwg = (a.g.total + a.g.per - 1) / a.g.per;
   hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(cg_pwm_bwd_kernel, dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, stream, a);
+#define CG_PWM_BWD_LAUNCH(N, C)                                                                                         \
+  {                                                                                                                    \
+    hipError_t e = cg_lds_limit((const void*)cg_pwm_bwd_kernel<N, C>, lds);                                            \
+    if (e != hipSuccess) return (int)e;                                                                                \
+    hipLaunchKernelGGL((cg_pwm_bwd_kernel<N, C>), dim3((unsigned)nwg), dim3(CG_PWM_THREADS), lds, stream, a);            \
+  }
+  CG_PWM_DISPATCH(a.g, CG_PWM_BWD_LAUNCH)
+#undef CG_PWM_BWD_LAUNCH
   st = cg_launch_status();
   if (st != CG_OK) return st;
   hipLaunchKernelGGL(cg_pwm_fold_kernel, dim3(8, (unsigned)t->n), dim3(256), 0, stream, a);

@@ -874,7 +874,7 @@ def check_model_branch_replay(device, C, T, V, B, mode="train", seed=0, scale=35
             "worst_attr": worst_attr, "dropout_sites": drp.sites if dropping else 0, "dropped": drp.dropped if dropping else 0}
 
 
-def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11))):
+def check_dstd_tail(device, shapes=((3, 20, 7, 9), (2, 8, 10, 22), (5, 64, 6, 11), (3, 32, 5, 8), (4, 16, 6, 6), (2, 40, 4, 5))):      # widths of every instantiation of the matrix phases: (1,1) (1,2) (2,4) (4,8) and the run-time form (20, 40)
     """ops.dstd_tail (phase kernels of csrc/dstd_tail.hip) against the same chain built from the row kernels and the generic
     contraction (pinned to the oracle by the model tests): identical dropout draws (same seed word and site ids), train and
     eval mode, output, emitted channel sums, every input / parameter gradient, running statistics."""
@@ -1064,7 +1064,7 @@ def check_gate_head(device, shapes=((5, 8, 10, 2), (37, 64, 102, 2), (4, 3, 46, 
                     assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, kname), rel=1e-5)
 
 
-def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14), (3, 64, (32, 32, 32, 32), 5, 12))):
+def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 16), 6, 6), (2, 12, (16, 5, 7), 3, 14), (3, 64, (32, 32, 32, 32), 5, 12), (2, 32, (16, 16, 16, 16), 5, 8))):
     """ops.tower_maps (pointwise maps + BatchNorm2d + PReLU as one operator; backward: cg_norm_act_bwd_reduce_many + cg_pointwise_maps_bwd
     undoing BatchNorm / PReLU on load) against stock PyTorch in fp64: outputs, dx, every dW / dgamma / dbeta / dalpha, running statistics,
     train and eval mode.  shapes: (B, Cin, (M_i), T, V)."""
@@ -1241,7 +1241,7 @@ def check_context_heads(device, shapes=((3, 5, 12, 7), (4, 25, 66, 64), (2, 3, 1
 
 
 def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (32, 32, 32, 32), 5, 12), (2, 20, (10, 33), 6, 6),
-                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6), (2, 1, (64, 64), 25, 66), (3, 32, (16, 16, 16, 16), 5, 10), (3, 100, (25,), 10, 22), (2, 128, (3,), 6, 6))):      # P % 4 == 2: (25, 66) and (5, 10); the last two: more than 64 input channels (FPN compress)
+                                          (3, 10, (64, 64), 5, 8), (2, 64, (10, 10, 10), 6, 6), (2, 1, (64, 64), 25, 66), (3, 32, (16, 16, 16, 16), 5, 10), (3, 100, (25,), 10, 22), (2, 128, (3,), 6, 6), (2, 64, (16, 16, 16, 16), 4, 6))):      # P % 4 == 2: (25, 66) and (5, 10); the last two: more than 64 input channels (FPN compress)
     """ops.pointwise_maps (csrc/tower_maps.hip) against one generic contraction per map: outputs, f64 channel sums, the summed
     input gradient, every weight gradient; every other shape with biases on all maps but the last (the residual maps of a block,
     nn.Conv2d(cin, cout, 1) with its default bias) and their gradients.  shapes: (B, Cin, (M_i), T, V)."""

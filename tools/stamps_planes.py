@@ -9,7 +9,7 @@ OUT = os.path.join(ROOT, "build", "libcistgcn_stamps.so")
 if "--build" in sys.argv:
     from cistgcn_amd import build
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_DOMP_STAMPS", "-DCG_TAIL_STAMPS", "-I", build.CSRC, "-o", OUT] + build.sources()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCG_DOMP_STAMPS", "-DCG_TAIL_STAMPS", "-DCG_ADJ_STAMPS", "-I", build.CSRC, "-o", OUT] + build.sources()
     subprocess.check_call(cmd)
     print(OUT)
     sys.exit(0)
