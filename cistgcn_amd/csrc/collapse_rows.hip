@@ -23,70 +23,92 @@ struct CgRowsArgs { CgRowsConv t; CgRowsGeom g; };
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
+// OT: 16-row tiles of the O outputs (compile time: the accumulators are registers).  The operands come straight from global memory, a
+// wave walks ~K / 128 groups of 16 rows k: with one group per iteration every iteration waited out a full memory latency in front of its
+// 16-32 MFMAs (one workgroup per CU: nothing else to run meanwhile; 34 us for 36 MB).  Now four groups of a wave are in flight: the loads
+// of group g + 4 are issued right behind the MFMAs of group g.  No load sits behind a branch: indices outside the tensor are clamped to
+// a neighbouring element (rows o >= O and columns v >= V land in results that are never stored), only rows k >= K are zeroed.
+template <int OT>
 __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRowsArgs a) {
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
-  const int b = blockIdx.x, K = g.K, V = t.V;
-  float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][33] partial sums of the eight waves
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4, nw = CG_ROWS_FWD_THREADS / 64;
-  for (int e = tid; e < 16 * g.OT * 33; e += CG_ROWS_FWD_THREADS) sY[e] = 0.f;
-  __syncthreads();
+  const int b = blockIdx.x, K = g.K, V = t.V, O = t.O;
+  constexpr int nw = CG_ROWS_FWD_THREADS / 64, DEPTH = 4;
+  float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [nw][16 * OT][33] partial tiles of the eight waves (no LDS atomics: 1 000 cycles each)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const float* xb = t.x + (long long)b * K * V;
-  cg_f32x4 acc[4][2];
+  cg_f32x4 acc[OT][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { acc[i][0] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+  for (int i = 0; i < OT; ++i) { acc[i][0] = cg_f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
   // groups of 16 consecutive k: lane (l15, slot) takes k = k0 + 4 slot + s in MFMA step s (both operands agree, a sum does not
   // care about the order)
   const int ngroups = (K + 15) >> 4;
-  const bool v0ok = l15 < V, v1ok = 16 + l15 < V;
-#pragma unroll 4
-  for (int gi = wave; gi < ngroups; gi += nw) {
+  const int vA = min(l15, V - 1), vB = min(16 + l15, V - 1);
+  const float* wrow[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) wrow[i] = t.W + (long long)min(16 * i + l15, O - 1) * K;
+  struct Frag { float4 w[OT]; float x0[4], x1[4]; float mask; };      // mask: 0 for rows k >= K (applied in front of the MFMAs: arithmetic on a
+                                                                        // loaded value right behind its load would wait for it there)
+  auto load = [&](int gi, Frag& f) {
     const int k = 16 * gi + 4 * slot;
-    float4 wv[4];
-    float x0[4], x1[4];
+    const bool kin = k < K;                                 // K % 4 == 0: a lane's four rows are inside or outside together
+    const int kc = kin ? k : K - 4;
+    f.mask = kin ? 1.f : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = 16 * i + l15;
-      wv[i] = (i < g.OT && o < t.O && k < K) ? *reinterpret_cast<const float4*>(t.W + (long long)o * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < OT; ++i) f.w[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
+    const float* xr = xb + (long long)kc * V;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { f.x0[s] = xr[s * V + vA]; f.x1[s] = xr[s * V + vB]; }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      const float w4[4] = {f.w[i].x * f.mask, f.w[i].y * f.mask, f.w[i].z * f.mask, f.w[i].w * f.mask};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], f.x0[s], acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], f.x1[s], acc[i][1], 0, 0, 0);
+      }
     }
+  };
+  Frag f[DEPTH];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool kok = k + s < K;
-      x0[s] = (kok && v0ok) ? xb[(long long)(k + s) * V + l15] : 0.f;
-      x1[s] = (kok && v1ok) ? xb[(long long)(k + s) * V + 16 + l15] : 0.f;
-    }
+  for (int j = 0; j < DEPTH; ++j)
+    if (wave + j * nw < ngroups) load(wave + j * nw, f[j]);
+  for (int gi = wave; gi < ngroups; gi += DEPTH * nw) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < g.OT) {
-        const float w4[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], x0[s], acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], x1[s], acc[i][1], 0, 0, 0);
-        }
+    for (int j = 0; j < DEPTH; ++j) {
+      const int gj = gi + j * nw;
+      if (gj < ngroups) {
+        mma(f[j]);
+        if (gj + DEPTH * nw < ngroups) load(gj + DEPTH * nw, f[j]);
       }
     }
   }
+  float* mine = sY + wave * 16 * OT * 33;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < g.OT) {
+  for (int i = 0; i < OT; ++i) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int o = 16 * i + 4 * slot + q;
-        atomicAdd(&sY[o * 33 + l15], acc[i][0][q]);
-        atomicAdd(&sY[o * 33 + 16 + l15], acc[i][1][q]);
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int o = 16 * i + 4 * slot + q;
+      mine[o * 33 + l15] = acc[i][0][q];
+      mine[o * 33 + 16 + l15] = acc[i][1][q];
     }
   }
   __syncthreads();
-  for (int e = tid; e < t.O * V; e += CG_ROWS_FWD_THREADS) {
+  for (int e = tid; e < O * V; e += CG_ROWS_FWD_THREADS) {
     const int o = e / V, v = e - o * V;
-    t.y[(long long)b * t.O * V + e] = sY[o * 33 + v];
+    float y = 0.f;
+#pragma unroll
+    for (int w = 0; w < nw; ++w) y += sY[(w * 16 * OT + o) * 33 + v];
+    t.y[(long long)b * O * V + e] = y;
+    sY[o * 33 + v] = y;                                    // this thread's own element of slot 0: the channel sums below read it
   }
   if (t.stats) {                                       // f64 channel sums for the BatchNorm behind the convolution
-    for (int o = tid; o < t.O; o += CG_ROWS_FWD_THREADS) {
+    __syncthreads();
+    for (int o = tid; o < O; o += CG_ROWS_FWD_THREADS) {
       double s1 = 0.0, s2 = 0.0;
       for (int v = 0; v < V; ++v) { const double y = (double)sY[o * 33 + v]; s1 += y; s2 += y * y; }
-      double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * t.O + o) * 2;
+      double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * O + o) * 2;
       atomicAdd(&rep[0], s1); atomicAdd(&rep[1], s2);
     }
   }
@@ -95,6 +117,9 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
 // ======================================================================================================================
 // backward: workgroup = (64 rows k of W, slice of the samples)
 // ======================================================================================================================
+// (Round 4 tried this kernel with compile-time OT, dy of the next sample through registers and clamped instead of conditional loads:
+// 90 us instead of 100 on the 64-output gate convolutions, but 152 us instead of 47 on the 32-output tower convolutions; not understood,
+// not shipped.)
 __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRowsArgs a) {
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
   const int K = g.K, V = t.V, O = t.O;
@@ -105,9 +130,20 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
   float* sDY = sW + 16 * g.OT * (CG_ROWS_KB + 4);                 // [2][16 * OT][36]   dy of the current / next sample, v padded with zeros
   const int WS = CG_ROWS_KB + 4, DS = 36;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
-  for (int e = tid; e < 16 * g.OT * WS; e += CG_ROWS_BWD_THREADS) {
-    const int o = e / WS, kk = e - o * WS;
-    sW[e] = (o < O && kk < CG_ROWS_KB && k0 + kk < K) ? t.W[(long long)o * K + k0 + kk] : 0.f;
+  // eight loads of a thread in flight (a load - store loop waits out one memory latency per element: 9 to 17 of them in this prologue)
+  for (int e0 = tid; e0 < 16 * g.OT * WS; e0 += 8 * CG_ROWS_BWD_THREADS) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + CG_ROWS_BWD_THREADS * j, o = e / WS, kk = e - o * WS;
+      const bool in = o < O && kk < CG_ROWS_KB && k0 + kk < K;
+      v[j] = t.W[in ? (long long)o * K + k0 + kk : (long long)k0];       // W[0][k0] stands in for the padding (k0 < K); zeroed at the store
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + CG_ROWS_BWD_THREADS * j, o = e / WS, kk = e - o * WS;
+      if (e < 16 * g.OT * WS) sW[e] = (o < O && kk < CG_ROWS_KB && k0 + kk < K) ? v[j] : 0.f;
+    }
   }
   for (int e = tid; e < 2 * 16 * g.OT * DS; e += CG_ROWS_BWD_THREADS) sDY[e] = 0.f;
   __syncthreads();
@@ -226,8 +262,22 @@ extern "C" int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream_) {
   if (st != CG_OK) return st;
   if (!t->y) return CG_EARG;
   a.t = *t;
-  const size_t lds = (size_t)16 * a.g.OT * 33 * sizeof(float);
-  hipLaunchKernelGGL(cg_rows_fwd_kernel, dim3((unsigned)t->B), dim3(CG_ROWS_FWD_THREADS), lds, (hipStream_t)stream_, a);
+  const size_t lds = (size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * 33 * sizeof(float);
+  const dim3 grid((unsigned)t->B), block(CG_ROWS_FWD_THREADS);
+  hipStream_t stream = (hipStream_t)stream_;
+#define CG_ROWS_FWD_LAUNCH(N)                                                                   \
+  {                                                                                            \
+    hipError_t e = cg_lds_limit((const void*)cg_rows_fwd_kernel<N>, lds);                       \
+    if (e != hipSuccess) return (int)e;                                                        \
+    hipLaunchKernelGGL((cg_rows_fwd_kernel<N>), grid, block, lds, stream, a);                    \
+  }
+  switch (a.g.OT) {
+    case 1: CG_ROWS_FWD_LAUNCH(1) break;
+    case 2: CG_ROWS_FWD_LAUNCH(2) break;
+    case 3: CG_ROWS_FWD_LAUNCH(3) break;
+    default: CG_ROWS_FWD_LAUNCH(4) break;
+  }
+#undef CG_ROWS_FWD_LAUNCH
   return cg_launch_status();
 }
 

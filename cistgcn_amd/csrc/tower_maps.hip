@@ -12,6 +12,7 @@
 #include "cg_phase.h"
 #include "tower_maps.h"
 #include <type_traits>
+#include <cstdlib>
 
 HIP_DYNAMIC_SHARED(unsigned char, cg_dyn_lds)
 
@@ -94,20 +95,17 @@ __device__ __forceinline__ void cg_pwm_store_quad(const CgPwGeom& g, float* row,
 // the same fetch from row pointers resolved ONCE per kernel (slot r of a thread is the same tile row in every tile): base[r] is the row
 // at sample 0 / position 0 or nullptr, off[r] the element offset of this tile's sample and first position
 template <typename KT>
-__device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, const KT& G, int np, float buf[16], const float* const base[4], const long long off[4], const float* safe) {
+__device__ __forceinline__ void cg_pwm_fetch_rows(const CgPwGeom& g, const KT& G, int np, float buf[16], const float* const base[4], const long long off[4]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int e = (int)threadIdx.x + CG_PWM_THREADS * r, pp = 4 * (e & ((1 << G.lgq()) - 1));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.vw == 4) {
-      // no branch around the load (`safe`, a readable 16-byte aligned address, stands in for what lies outside the tensor): the loads of a
-      // thread issue back to back
-      const bool in = base[r] != nullptr && pp < np;
-      const float4 w = *reinterpret_cast<const float4*>(in ? base[r] + off[r] + pp : safe);
-      v = make_float4(in ? w.x : 0.f, in ? w.y : 0.f, in ? w.z : 0.f, in ? w.w : 0.f);
-    } else if (base[r] != nullptr && pp < np) {
+    // (a branch-free form - every lane loads, rows outside the tensor from one stand-in address - was 60 us SLOWER per launch at the
+    // headline shape: half of the x slots are such rows, and all workgroups then read the same 16 bytes)
+    if (base[r] != nullptr && pp < np) {
       const float* p = base[r] + off[r] + pp;
-      {
+      if (g.vw == 4) v = *reinterpret_cast<const float4*>(p);
+      else {
         const float2 lo = *reinterpret_cast<const float2*>(p);
         v.x = lo.x; v.y = lo.y;
         if (pp + 2 < np) { const float2 hi = *reinterpret_cast<const float2*>(p + 2); v.z = hi.x; v.w = hi.y; }
@@ -267,15 +265,14 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_bwd_kernel(CgPwArgs a) 
       }
     }
   }
-  const float* const xsafe = t.x;                       // rows are 16-byte aligned when vw == 4 (P % 4 == 0), and so is the tensor's base
   auto fetch = [&](int lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT(), np = min(G.PT(), t.P - p0);
     long long xo[4], doff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { xo[r] = (long long)b * t.Cin * t.P + p0; doff[r] = (long long)b * dstr[r] + p0; }
-    cg_pwm_fetch_rows(g, G, np, xbuf, xrow, xo, xsafe);
-    cg_pwm_fetch_rows(g, G, np, dbuf, drow, doff, xsafe);
-    if (undo) cg_pwm_fetch_rows(g, G, np, ybuf, yrow, doff, xsafe);
+    cg_pwm_fetch_rows(g, G, np, xbuf, xrow, xo);
+    cg_pwm_fetch_rows(g, G, np, dbuf, drow, doff);
+    if (undo) cg_pwm_fetch_rows(g, G, np, ybuf, yrow, doff);
   };
   // gradient in front of the BatchNorm from the one behind the PReLU (cg_norm_act's backward, applied to the staged values; zeros of the
   // padding stay zeros only where dy AND the sums' terms vanish: rows / positions outside the tensor are masked by their null row pointer)
@@ -482,7 +479,8 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
 // the instantiations with compile-time geometry: (stacked 16-row tiles, input 16-row tiles) of the shipped configurations; anything else
 // takes the run-time form
 #define CG_PWM_DISPATCH(G_, LAUNCH)                                   \
-  if ((G_).NT == 8 && (G_).CT == 4) LAUNCH(8, 4)        /* four 32-channel towers of a 64-channel block (and 2 x 64 residual maps) */ \
+  if (getenv("CG_PWM_GENERIC")) LAUNCH(0, 0)                         \
+  else if ((G_).NT == 8 && (G_).CT == 4) LAUNCH(8, 4)        /* four 32-channel towers of a 64-channel block (and 2 x 64 residual maps) */ \
   else if ((G_).NT == 8 && (G_).CT == 1) LAUNCH(8, 1)   /* 128 stacked rows of the 10-channel input block */                         \
   else if ((G_).NT == 4 && (G_).CT == 2) LAUNCH(4, 2)   /* four 16-channel towers of a 32-channel block */                           \
   else if ((G_).NT == 4 && (G_).CT == 4) LAUNCH(4, 4)                                                                                \

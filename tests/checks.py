@@ -1275,7 +1275,7 @@ def check_pointwise_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 64, (3
             assert_close(a, b, "%s grad[%d]" % (what, k), rel=5e-5, floor=max(1e-3, float(b.abs().max())))
 
 
-def check_collapse_rows(device, shapes=((3, 6, 4, 7, 5), (2, 32, 50, 22, 32), (5, 64, 10, 22, 64), (2, 10, 6, 25, 20))):
+def check_collapse_rows(device, shapes=((3, 6, 4, 7, 5), (2, 32, 50, 22, 32), (5, 64, 10, 22, 64), (2, 10, 6, 25, 20), (3, 12, 5, 18, 40))):      # O = 5 .. 64: one to four 16-row output tiles; K = 24, 60: a last group of fewer than 16 rows
     """ops.collapse_rows (csrc/collapse_rows.hip) against the generic contraction: output, f64 channel sums, both gradients.
     shapes: (B, C, T, V, O)."""
     g = _gen(61)
