@@ -290,6 +290,9 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
   const bool vec = (P & 3) == 0;
   float4 yq[CG_TAIL_PT / 8], rq[CG_TAIL_PT / 8];
   float wq[CG_TAIL_PT / 8];
+  double fsum[MT_ ? (2 * MT_ + nw - 1) / nw : 1][2];
+#pragma unroll
+  for (int i = 0; i < (MT_ ? (2 * MT_ + nw - 1) / nw : 1); ++i) fsum[i][0] = fsum[i][1] = 0.0;
   if (vec) {
     const int lid = wg * per, b = lid / tiles_per_sample, p0 = (lid - b * tiles_per_sample) * CG_TAIL_PT;
     cg_tail_act_load<CG_TAIL_PT>(t, b, p0, min(CG_TAIL_PT, P - p0), yq, rq, wq);
@@ -377,10 +380,22 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
         }
       }
       if (t.train) {
-        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (slot == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
+        if (MT_) { fsum[MT_ ? ti : 0][0] += (double)s1; fsum[MT_ ? ti : 0][1] += (double)s2; }      // known widths: task ti of a wave is the same channel tile in every tile
+        else {
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (slot == 0 && cok) { atomicAdd(&sStat[2 * co], (double)s1); atomicAdd(&sStat[2 * co + 1], (double)s2); }
+        }
       }
+    }
+  }
+  if (t.train && MT_) {
+    // the channel sums of a lane's tasks, kept in registers over all tiles: one pair of LDS atomics per task and workgroup instead of
+    // two exchanges and a pair of atomics per task and TILE
+#pragma unroll
+    for (int ti = 0; ti < (MT_ ? (2 * MT_ + nw - 1) / nw : 1); ++ti) {
+      const int w = wave + nw * ti, co = 16 * (w >> 1) + l15;
+      if (w < MT * 2 && co < C) { atomicAdd(&sStat[2 * co], fsum[ti][0]); atomicAdd(&sStat[2 * co + 1], fsum[ti][1]); }
     }
   }
   if (t.train) {

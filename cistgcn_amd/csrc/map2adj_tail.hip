@@ -751,6 +751,37 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
         for (int pp = bq - r0 + J * m; pp < np; pp += J, ++m) acc += img[pp] * srow[m];
         sDQ[k * JS + bq] += acc;
       }
+      if (J >= 16) {
+        // dS by (slab, 16 consecutive positions) like the seed image above: at most one step of a inside the run, so a thread ends with
+        // two partial sums, for rows a and a + 1 (clamped to the pad column behind the last row).  The PT / 16 threads of a slab are
+        // adjacent lanes of one wave: they add their sums to the slab's cells one after the other - the LDS operations of a wave are
+        // executed in order, the wave barrier keeps the compiler from merging the phases
+        constexpr int per_row = K::PT >> 4;
+        const int k = tid / per_row, sub = tid - k * per_row, pp0 = 16 * sub, p = p0 + pp0;
+        const int a = (int)cg_adj_div((unsigned)p, magicJ), bp = p - a * J;
+        const float* img = sDO + k * K::PS + pp0; const float* qrow = sQ + k * JS;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 d4 = *reinterpret_cast<const float4*>(img + 4 * j4);
+          const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int bj = bp + 4 * j4 + j;
+            const bool wrap = bj >= J;
+            const float pr = dv[j] * qrow[wrap ? bj - J : bj];        // the image is zero beyond np and in the rows k >= Kc
+            s0 += wrap ? 0.f : pr; s1 += wrap ? pr : 0.f;
+          }
+        }
+        float* c0 = sDS + k * JS + min(a, J); float* c1 = sDS + k * JS + min(a + 1, J);
+#pragma unroll
+        for (int j = 0; j < per_row; ++j) {
+          if (sub == j) { *c0 += s0; *c1 += s1; }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+      } else {
       const int M = (r0 + np - 1) / J + 1;               // rows a of the position grid that the tile touches
       for (int cell = tid; cell < Kc * M; cell += CG_ADJ_THREADS) {
         const int k = cell / M, m = cell - k * M;
@@ -761,6 +792,7 @@ __device__ __forceinline__ void cg_adj_n2_body(const CgAdjTail& t, const CgAdjGe
         for (; pp + 1 < hi; pp += 2) { acc0 += img[pp] * qrow[pp]; acc1 += img[pp + 1] * qrow[pp + 1]; }
         if (pp < hi) acc0 += img[pp] * qrow[pp];
         if (a0 + m < J) sDS[k * JS + a0 + m] += acc0 + acc1;
+      }
       }
     }
   }

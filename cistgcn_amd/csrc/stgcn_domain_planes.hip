@@ -918,6 +918,7 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
   CG_STAMP();
 
   // P2: one wave per frame
+  float dbw[4] = {0.f, 0.f, 0.f, 0.f};                  // bias-gradient partial sums of this lane (channel 16 i + l15) over its frames
   for (int tl = wave; tl < TCn; tl += CG_DOMPT_NW) {
     const int pb = tl * V;                            // first position of the frame inside the pieces
     const int NVT = (V + 15) / 16;                    // 1 or 2 tiles of joints
@@ -1027,13 +1028,16 @@ __global__ __launch_bounds__(CG_DOMPT_THREADS, 2) void cg_stgcn_planes_bwd_time_
           }
         }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float sdbp = dbp[i];
-        sdbp += __shfl_xor(sdbp, 16, 64);
-        sdbp += __shfl_xor(sdbp, 32, 64);
-        if (i < MTo && slot == 0) atomicAdd(&sdb[16 * i + l15], sdbp);
-      }
+      for (int i = 0; i < 4; ++i) dbw[i] += dbp[i];       // a lane's output channels are the same in every frame: registers until the frames are done
     }
+  }
+  // (an LDS atomic per channel tile and FRAME used to sit inside the loop: ~1000 cycles each under load)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float sdbp = dbw[i];
+    sdbp += __shfl_xor(sdbp, 16, 64);
+    sdbp += __shfl_xor(sdbp, 32, 64);
+    if (i < MTo && slot == 0) atomicAdd(&sdb[16 * i + l15], sdbp);
   }
   CG_STAMP();
   __syncthreads();

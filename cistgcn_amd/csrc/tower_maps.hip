@@ -152,6 +152,11 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
     const int tile = r >> 4, i = g.tile_map[tile], m = g.tile_row0[tile] + (r & 15);
     sBias[r] = (m < t.M[i] && t.bias[i]) ? t.bias[i][m] : 0.f;
   }
+  // Known geometry with 8 % NT == 0: every task of a wave has the same row tile nt = wave % NT, so a lane meets ONE output channel in all
+  // its tasks and tiles: its channel sums stay in two f64 registers and reach LDS once (an LDS atomic costs ~1000 cycles under load,
+  // the run-time form pays two per task and tile).
+  constexpr bool kKeepSums = NT_ > 0 && (CG_PWM_THREADS / 64) % (NT_ ? NT_ : 1) == 0;
+  double keep1 = 0.0, keep2 = 0.0;
   for (int lid = lid0; lid < lid1; ++lid) {
     const int b = lid / g.tps, p0 = (lid - b * g.tps) * G.PT(), np = min(G.PT(), t.P - p0);
     __syncthreads();
@@ -188,9 +193,16 @@ __global__ __launch_bounds__(CG_PWM_THREADS) void cg_pwm_fwd_kernel(CgPwArgs a) 
             s1 += (c[0] + c[1]) + (c[2] + c[3]); s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
           }
         }
-        if (stats) { atomicAdd(&sStat[2 * (16 * nt + l15)], (double)s1); atomicAdd(&sStat[2 * (16 * nt + l15) + 1], (double)s2); }
+        if (stats) {
+          if (kKeepSums) { keep1 += (double)s1; keep2 += (double)s2; }       // one channel per lane over every task and tile of this wave
+          else { atomicAdd(&sStat[2 * (16 * nt + l15)], (double)s1); atomicAdd(&sStat[2 * (16 * nt + l15) + 1], (double)s2); }
+        }
       }
     }
+  }
+  if (stats && kKeepSums) {
+    const int nt = wave % (NT_ ? NT_ : 1), i = g.tile_map[nt], m = g.tile_row0[nt] + l15;
+    if (m < t.M[i]) { atomicAdd(&sStat[2 * (16 * nt + l15)], keep1); atomicAdd(&sStat[2 * (16 * nt + l15) + 1], keep2); }
   }
   if (stats) {
     __syncthreads();

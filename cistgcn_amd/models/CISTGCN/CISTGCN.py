@@ -502,12 +502,24 @@ class CISTGCN(nn.Module):
                 o = o[:2] + [None] * 4 + o[2:]
             else:
                 o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
+        res_done = None
         if res_groups:
-            ro = [None] * len(res_convs)
-            for xg, grp in zip(x_resmaps, res_groups):
-                for i, y in zip(grp, ops.pointwise_maps(xg, [res_w[i] for i in grp], tr, biases=[res_convs[i].bias for i in grp])):
-                    ro[i] = y
-            o = o + ro
+            res_bns = ([d.residual[1] for d in doms] if has_res else []) + ([m.residual[1]] if has_bres else [])
+            if self.fused_towers and all(ops.tower_maps_ok(xg, [res_w[i] for i in grp], [None] * len(grp)) for xg, grp in zip(x_resmaps, res_groups)):
+                # the residual maps with their BatchNorm as one operator per group, like the towers: backward is one reduction pass and the
+                # pointwise backward undoing the BatchNorm on load (as two operators: 229 us of cg_norm_act_bwd on the 10 -> 64 block)
+                res_done = [None] * len(res_convs)
+                for xg, grp in zip(x_resmaps, res_groups):
+                    hs = ops.tower_maps(xg, [res_w[i] for i in grp], [res_bns[i] for i in grp], [None] * len(grp), tr, biases=[res_convs[i].bias for i in grp])
+                    for i, h in zip(grp, hs):
+                        res_done[i] = h
+                o = o + [None] * len(res_convs)
+            else:
+                ro = [None] * len(res_convs)
+                for xg, grp in zip(x_resmaps, res_groups):
+                    for i, y in zip(grp, ops.pointwise_maps(xg, [res_w[i] for i in grp], tr, biases=[res_convs[i].bias for i in grp])):
+                        ro[i] = y
+                o = o + ro
         gs, gt, tc = o[0], o[1], o[2:6]
         # 2. their BatchNorm / PReLU tails
         calls = [dict(x=gs, bn=m.conv_s[1], drop=True, prelu=m.conv_s[3]), dict(x=gt, bn=m.conv_t[1], drop=True, prelu=m.conv_t[3])]
@@ -516,17 +528,23 @@ class CISTGCN(nn.Module):
                 calls += [dict(x=tc[2 * i], bn=a.time_compress[1], prelu=a.time_compress[2]),
                           dict(x=tc[2 * i + 1], bn=a.joint_compress[1], prelu=a.joint_compress[2])]
         k = 6
-        if has_res:
-            calls += [dict(x=o[k + i], bn=d.residual[1]) for i, d in enumerate(doms)]
-            k += 2
-        if has_bres:
-            calls.append(dict(x=o[k], bn=m.residual[1]))
+        n_tower_calls = len(calls) - 2
+        if res_done is None:
+            if has_res:
+                calls += [dict(x=o[k + i], bn=d.residual[1]) for i, d in enumerate(doms)]
+                k += 2
+            if has_bres:
+                calls.append(dict(x=o[k], bn=m.residual[1]))
+        # site numbers as on the row-kernel path in every case: gates, four (dropout-free) tower sites, residual maps
         if towers_done is None:
             r = self._na_many(calls)
-        else:                        # site numbers as on the row-kernel path: gates, four (dropout-free) tower sites, residual maps
+        else:
             r = self._na_many(calls[:2])
             self._site += 4
-            r = r + towers_done + (self._na_many(calls[2:]) if len(calls) > 2 else [])
+            r = r + towers_done + (self._na_many(calls[2 + n_tower_calls:]) if len(calls) > 2 + n_tower_calls else [])
+        if res_done is not None:
+            self._site += len(res_done)
+            r = r + res_done
         gs, gt, t1 = r[0], r[1], r[2:6]
         res = r[6:8] if has_res else x_res
         bres = r[-1] if has_bres else x_bres

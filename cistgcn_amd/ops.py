@@ -2068,12 +2068,24 @@ def pointwise_maps(x, weights, want_stats=False, biases=None):
     return [(out[i], out[n + i] if want_stats else None) for i in range(n)]
 
 
+_ONES = {}
+
+
+def _one(dev):
+    """a constant slope 1 (PReLU = identity) for the maps of `tower_maps` that have no PReLU behind their BatchNorm"""
+    if dev not in _ONES:
+        _ONES[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+    return _ONES[dev]
+
+
 class _TowerMaps(torch.autograd.Function):
-    """h_i = PReLU(BN(W_i x)) for up to four 1x1 maps of one input followed by BatchNorm2d + PReLU: the first level of the Map2Adj
-    towers of a block (CISTGCN.py:138-141 / :156-158 applied by :183-186).  Forward = cg_pointwise_maps_fwd + cg_norm_act_fwd_many, as
+    """h_i = PReLU(BN(W_i x + b_i)) for up to four 1x1 maps of one input followed by BatchNorm2d (+ PReLU): the first level of the
+    Map2Adj towers of a block (CISTGCN.py:138-141 / :156-158 applied by :183-186; no bias, PReLU) and the residual maps of a block that
+    changes its width (:246-254 / :357-365: bias, no PReLU).  Forward = cg_pointwise_maps_fwd + cg_norm_act_fwd_many, as
     the two operators do; backward: ONE reduction pass over (dh_i, y_i) and the pointwise backward undoing BatchNorm and PReLU while
     it loads dh_i - the gradient in front of the BatchNorm is never stored (as two operators: reduce + apply passes of cg_norm_act_bwd,
-    432 MB written and read again per block at B = 256).  Tensor inputs: x | W_1..n | gamma_1..n | beta_1..n | alpha_1..n."""
+    432 MB written and read again per block at B = 256).  Tensor inputs: x | W_1..n | gamma_1..n | beta_1..n | alpha_1..n | b_1..n
+    (alpha_i / b_i None: no PReLU / no bias)."""
 
     @staticmethod
     def forward(ctx, cfg, n, x, *ts):
@@ -2083,7 +2095,8 @@ class _TowerMaps(torch.autograd.Function):
         dev, f32, train = x.device, torch.float32, bool(cfg["train"])
         ws = [w if w.is_contiguous() else _copy(w) for w in ts[:n]]
         gammas, betas, alphas = ts[n:2 * n], ts[2 * n:3 * n], ts[3 * n:4 * n]
-        t = _PointwiseMaps._block(x, ws, [None] * n)
+        bs = [None if b is None else (b if b.is_contiguous() else _copy(b)) for b in ts[4 * n:5 * n]]
+        t = _PointwiseMaps._block(x, ws, bs)
         ys = [torch.empty(B, w.shape[0], H, W, dtype=f32, device=dev) for w in ws]
         stats = [_arena(dev).take(2 * w.shape[0] * _lib.STAT_REPLICAS) for w in ws] if train else [None] * n
         for i in range(n):
@@ -2099,7 +2112,8 @@ class _TowerMaps(torch.autograd.Function):
         assert not pending
         _lib.call("cg_norm_act_fwd_many", arr, n, stream)
         ctx.cfg, ctx.n = cfg, n
-        ctx.save_for_backward(x, *ws, *gammas, *betas, *alphas, *ys, *saves)
+        ctx.has_alpha, ctx.has_bias = [a is not None for a in alphas], [b is not None for b in bs]
+        ctx.save_for_backward(x, *ws, *gammas, *betas, *[a if a is not None else _one(dev) for a in alphas], *ys, *saves)
         return tuple(hs)
 
     @staticmethod
@@ -2124,21 +2138,26 @@ class _TowerMaps(torch.autograd.Function):
             a.running_mean, a.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
             a.momentum, a.eps = bn.momentum, bn.eps
             a.save_mean, a.save_rstd = saves[i][0].data_ptr(), saves[i][1].data_ptr()
-            a.alpha, a.alpha_n = alphas[i].data_ptr(), alphas[i].numel()
-            red = _arena(dev).take(2 * M + (_lib.ALPHA_SLOTS if alphas[i].numel() == 1 else alphas[i].numel()))
+            nal = alphas[i].numel() if ctx.has_alpha[i] else 0
+            if nal:
+                a.alpha, a.alpha_n = alphas[i].data_ptr(), nal
+            red = _arena(dev).take(2 * M + (_lib.ALPHA_SLOTS if nal <= 1 else nal))
             small = torch.empty(3, M, dtype=f32, device=dev)
-            a.red, a.dgamma, a.dbeta, a.dalpha = red.data_ptr(), small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr()
+            a.red, a.dgamma, a.dbeta = red.data_ptr(), small[0].data_ptr(), small[1].data_ptr()
+            if nal:
+                a.dalpha = small[2].data_ptr()
             reds.append(red); smalls.append(small)
         _lib.call("cg_norm_act_bwd_reduce_many", arr, n, stream)
-        # pass 2: dx and dW_i with BatchNorm / PReLU undone on load
+        # pass 2: dx and dW_i (db_i) with BatchNorm / PReLU undone on load
         t = _PointwiseMaps._block(x, ws, [None] * n)
         dx = torch.empty_like(x)
         dws = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], dtype=f32, device=dev) if hb else None for w, hb in zip(ws, ctx.has_bias)]
         zb, _ = _zeros(int(_lib.lib().cg_pointwise_maps_ws_floats(x.shape[1])), dev)
         for i in range(n):
-            t.dy[i], t.dW[i] = dhs[i].data_ptr(), dws[i].data_ptr()
+            t.dy[i], t.dW[i], t.db[i] = dhs[i].data_ptr(), dws[i].data_ptr(), _ptr(dbs[i])
             t.yraw[i], t.bn_save[i], t.bn_gamma[i], t.bn_beta[i] = ys[i].data_ptr(), saves[i].data_ptr(), gammas[i].data_ptr(), betas[i].data_ptr()
-            t.bn_red[i], t.prelu[i] = reds[i].data_ptr(), alphas[i].data_ptr()
+            t.bn_red[i], t.prelu[i] = reds[i].data_ptr(), alphas[i].data_ptr()           # slope 1 where there is no PReLU
         t.bn_train = 1 if train else 0
         t.dx, t.dW_ws = dx.data_ptr(), zb.data_ptr()
         _lib.call("cg_pointwise_maps_bwd", ctypes.byref(t), stream)
@@ -2147,19 +2166,23 @@ class _TowerMaps(torch.autograd.Function):
         grads = [dx if need[2] else None] + [dws[i] if need[3 + i] else None for i in range(n)]
         grads += [smalls[i][0] if need[3 + n + i] else None for i in range(n)]
         grads += [smalls[i][1] if need[3 + 2 * n + i] else None for i in range(n)]
-        grads += [smalls[i][2, :1].reshape(alphas[i].shape) if need[3 + 3 * n + i] else None for i in range(n)]
+        grads += [smalls[i][2, :1].reshape(alphas[i].shape) if (ctx.has_alpha[i] and need[3 + 3 * n + i]) else None for i in range(n)]
+        grads += [dbs[i] if (dbs[i] is not None and need[3 + 4 * n + i]) else None for i in range(n)]
         return (None, None) + tuple(grads)
 
 
 def tower_maps_ok(x, weights, prelus):
-    return pointwise_maps_ok(x, weights) and all(p.weight.numel() == 1 for p in prelus)
+    return pointwise_maps_ok(x, weights) and all(p is None or p.weight.numel() == 1 for p in prelus)
 
 
-def tower_maps(x, weights, bns, prelus, train):
-    """[h_i] = PReLU(BN(W_i x)) for the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W) with their BatchNorm2d / PReLU holders."""
+def tower_maps(x, weights, bns, prelus, train, biases=None):
+    """[h_i] = PReLU(BN(W_i x + b_i)) for the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W) with their BatchNorm2d / PReLU holders
+    (`prelus[i]` None: no PReLU; `biases[i]` None: no bias)."""
     n = len(weights)
+    biases = [None] * n if biases is None else list(biases)
     cfg = {"train": bool(train), "bn": tuple(bns)}
-    return list(_TowerMaps.apply(cfg, n, x, *weights, *[b.weight for b in bns], *[b.bias for b in bns], *[p.weight for p in prelus]))
+    return list(_TowerMaps.apply(cfg, n, x, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
+                                 *[None if p is None else p.weight for p in prelus], *biases))
 
 
 class _SplitChannels(torch.autograd.Function):

@@ -1075,12 +1075,17 @@ def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 1
                 gg = _gen(500 + C)
                 mods = []
                 for k, M in enumerate(Ms):
-                    conv, bn, pr = nn.Conv2d(C, M, 1, bias=False), nn.BatchNorm2d(M), nn.PReLU()
+                    # residual-map form (conv bias, no PReLU: nn.Identity stands in) on the second map of the shapes with an even Cin
+                    plain = k == 1 and C % 2 == 0
+                    conv, bn, pr = nn.Conv2d(C, M, 1, bias=plain), nn.BatchNorm2d(M), (nn.Identity() if plain else nn.PReLU())
                     with torch.no_grad():
                         conv.weight.copy_(torch.randn(conv.weight.shape, generator=gg) * 0.4)
+                        if plain:
+                            conv.bias.copy_(0.3 * torch.randn(M, generator=gg))
                         bn.weight.copy_(1 + 0.3 * torch.randn(M, generator=gg)); bn.bias.copy_(0.3 * torch.randn(M, generator=gg))
                         bn.running_mean.copy_(0.2 * torch.randn(M, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(M, generator=gg))
-                        pr.weight.fill_(0.1 + 0.1 * k)
+                        if not plain:
+                            pr.weight.fill_(0.1 + 0.1 * k)
                     mods.append(nn.Sequential(conv, bn, pr))
                 return nn.ModuleList(mods).to(dt)
             x0 = 0.3 + _rand(g, B, C, T, V)
@@ -1093,14 +1098,15 @@ def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 1
             net = make(torch.float32).to(device).train(train)
             xd = _leaf(x0, device)
             ops.begin_step(device)
-            hd = ops.tower_maps(xd, [m[0].weight.view(m[0].out_channels, C) for m in net], [m[1] for m in net], [m[2] for m in net], train)
+            hd = ops.tower_maps(xd, [m[0].weight.view(m[0].out_channels, C) for m in net], [m[1] for m in net],
+                                [m[2] if isinstance(m[2], nn.PReLU) else None for m in net], train, biases=[m[0].bias for m in net])
             torch.autograd.backward(hd, [t.to(device) for t in gs])
             for a, b in zip(hd, hr):
                 assert_close(a, b, what + " output", rel=2e-5)
             assert_close(xd.grad, xr.grad, what + " dx", rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
             for (k, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
                 floor = max(1e-3, float(pb.grad.abs().max()))
-                if train and k.endswith("0.weight"):           # in front of a train-mode BatchNorm: the remainder of cancelling sums
+                if train and (k.endswith("0.weight") or k.endswith("0.bias")):           # in front of a train-mode BatchNorm: the remainder of cancelling sums
                     floor = max(floor, float(ref[int(k.split(".")[0])][1].weight.grad.abs().max()))
                 assert_close(pa.grad, pb.grad, "%s grad %s" % (what, k), rel=5e-5, floor=floor)
             for (k, ba), (_, bb) in zip(net.named_buffers(), ref.named_buffers()):

@@ -61,6 +61,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 }  // namespace hipemu
 
 static inline void __syncthreads() { hipemu::syncthreads(); }
+// wave-level barrier / fence (ordering of LDS accesses between the lanes of a wave): a real barrier of the wave's 64 fibers here
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier((int)threadIdx.x / 64); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 
 template <typename T>
 static inline T __shfl_down(T v, unsigned delta, int width = 64) {
