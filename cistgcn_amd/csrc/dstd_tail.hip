@@ -50,6 +50,8 @@ __device__ __forceinline__ float cg_tail_keep(const CgDstdTail& t, int i, unsign
   return cg_drop_scale(t.drop_p, seed, t.salt[i], ((unsigned long long)b * t.C + c) * P + p);
 }
 
+__device__ __forceinline__ void cg_tail_keep4(const CgDstdTail& t, int i, unsigned long long seed, unsigned long long idx0, float keep[4]);
+
 // ======================================================================================================================
 // F1: channel sums of z_i = w_i * x_i     grid (C, batch chunks, 2)
 // ======================================================================================================================
@@ -57,26 +59,52 @@ __global__ void cg_tail_f1_kernel(CgDstdTail t, int rb) {
   __shared__ double red[32];
   const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb;
   if (b0 >= t.B) return;
-  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const int P = t.T * t.V, nb = min(rb, t.B - b0), C = t.C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const double cnt = (double)t.B * P;
-  const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, cnt, t.train, false, blockIdx.y == 0 && threadIdx.x == 0);
+  const CgAff at = cg_tail_aff(t.bn_t[i], c, C, cnt, t.train, false, blockIdx.y == 0 && threadIdx.x == 0);
   const float ad = t.alpha_d[i][0];
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
   const float* __restrict__ y = t.y[i]; const float* __restrict__ r = t.r[i];
+  float* const tap = t.tap_x[i];
   double s = 0.0, q = 0.0;
-  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
-    const int br = e / P, p = e - br * P, b = b0 + br;
-    const long long off = ((long long)b * t.C + c) * P + p;
-    float u;
-    const float x = cg_tail_x(at, ad, y[off], r[off], cg_tail_keep(t, i, seed, b, c, p), u);
-    const float z = t.w[i][(long long)b * t.C + c] * x;
-    if (t.tap_x[i]) t.tap_x[i][off] = x;
-    s += (double)z; q += (double)z * (double)z;
+  // a wave per row (b, c), four consecutive positions per lane and step: 16-byte loads, one dropout hash per quad (the first form of
+  // this kernel walked the elements one by one, a division and a hash each: 3.2 TB/s against 5.2 for K4, which was written this way)
+  for (int br = wave; br < nb; br += nw) {
+    const int b = b0 + br;
+    const long long base = ((long long)b * C + c) * P;
+    const float wv = t.w[i][(long long)b * C + c];
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        float keep[4];
+        cg_tail_keep4(t, i, seed, (unsigned long long)(base + p), keep);
+        const float4 y4 = *reinterpret_cast<const float4*>(y + base + p), r4 = *reinterpret_cast<const float4*>(r + base + p);
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+        float xv[4], zs = 0.f, zq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u;
+          xv[j] = cg_tail_x(at, ad, yv[j], rv[j], keep[j], u);
+          const float z = wv * xv[j];
+          zs += z; zq += z * z;
+        }
+        if (tap) *reinterpret_cast<float4*>(tap + base + p) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        s += (double)zs; q += (double)zq;
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) {
+        float u;
+        const float x = cg_tail_x(at, ad, y[base + p], r[base + p], cg_tail_keep(t, i, seed, b, c, p), u);
+        const float z = wv * x;
+        if (tap) tap[base + p] = x;
+        s += (double)z; q += (double)z * (double)z;
+      }
+    }
   }
   s = cg_block_sum(s, red);
   q = cg_block_sum(q, red + 16);
   if (threadIdx.x == 0) {
-    double* rep = t.bn_p[i].stats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * t.C;
+    double* rep = t.bn_p[i].stats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * C;
     atomicAdd(&rep[2 * c], s); atomicAdd(&rep[2 * c + 1], q);
   }
 }
@@ -409,40 +437,69 @@ __global__ __launch_bounds__(CG_TAIL_THREADS, 2) void cg_tail_f2_kernel(CgDstdTa
 // F3: pooled[b,c] = mean_p PReLU_c(BN_c(h0))     one workgroup per (c, b) row
 // F4: out = h * gate[b,c] + bres   (+ channel sums of out)
 // ======================================================================================================================
-__global__ void cg_tail_f3_kernel(CgDstdTail t) {
-  __shared__ double red[16];
-  const int c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
-  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, (double)t.B * P, t.train, false, b == 0 && threadIdx.x == 0);
+__global__ void cg_tail_f3_kernel(CgDstdTail t, int rb) {
+  const int c = blockIdx.x, b0 = blockIdx.y * rb, P = t.T * t.V, C = t.C;
+  if (b0 >= t.B) return;
+  const int nb = min(rb, t.B - b0), lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, C, (double)t.B * P, t.train, false, blockIdx.y == 0 && threadIdx.x == 0);
   const float alpha = t.alpha_c[0];
-  const float* __restrict__ h0 = t.h0 + ((long long)b * t.C + c) * P;
-  double s = 0.0;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) s += (double)cg_prelu(cg_bn(ac, h0[p]), alpha);
-  s = cg_block_sum(s, red);
-  if (threadIdx.x == 0) t.pooled[(long long)b * t.C + c] = (float)(s / (double)P);
+  for (int br = wave; br < nb; br += nw) {                 // a wave per row: its mean needs no LDS (one workgroup per row was 16 K tiny workgroups)
+    const int b = b0 + br;
+    const float* __restrict__ h0 = t.h0 + ((long long)b * C + c) * P;
+    float s = 0.f;
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        const float4 h4 = *reinterpret_cast<const float4*>(h0 + p);
+        s += (cg_prelu(cg_bn(ac, h4.x), alpha) + cg_prelu(cg_bn(ac, h4.y), alpha)) + (cg_prelu(cg_bn(ac, h4.z), alpha) + cg_prelu(cg_bn(ac, h4.w), alpha));
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) s += cg_prelu(cg_bn(ac, h0[p]), alpha);
+    }
+    const double sd = cg_wave_sum((double)s);
+    if (lane == 0) t.pooled[(long long)b * C + c] = (float)(sd / (double)P);
+  }
 }
 
 __global__ void cg_tail_f4_kernel(CgDstdTail t, int rb) {
   __shared__ double red[32];
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
   if (b0 >= t.B) return;
-  const int P = t.T * t.V, nb = min(rb, t.B - b0);
-  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, (double)t.B * P, t.train, true, false);      // saved by F3
+  const int P = t.T * t.V, nb = min(rb, t.B - b0), C = t.C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, C, (double)t.B * P, t.train, true, false);      // saved by F3
   const float alpha = t.alpha_c[0];
+  float* const tap = t.tap_h;
   double s = 0.0, q = 0.0;
-  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
-    const int br = e / P, p = e - br * P, b = b0 + br;
-    const long long off = ((long long)b * t.C + c) * P + p;
-    const float h = cg_prelu(cg_bn(ac, t.h0[off]), alpha);
-    if (t.tap_h) t.tap_h[off] = h;
-    const float v = h * t.gate[(long long)b * t.C + c] + t.bres[off];
-    t.out[off] = v;
-    s += (double)v; q += (double)v * (double)v;
+  for (int br = wave; br < nb; br += nw) {
+    const int b = b0 + br;
+    const long long base = ((long long)b * C + c) * P;
+    const float gate = t.gate[(long long)b * C + c];
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        const float4 h4 = *reinterpret_cast<const float4*>(t.h0 + base + p), r4 = *reinterpret_cast<const float4*>(t.bres + base + p);
+        const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+        float h[4], v[4], vs = 0.f, vq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = cg_prelu(cg_bn(ac, hv[j]), alpha); v[j] = h[j] * gate + rv[j]; vs += v[j]; vq += v[j] * v[j]; }
+        if (tap) *reinterpret_cast<float4*>(tap + base + p) = make_float4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<float4*>(t.out + base + p) = make_float4(v[0], v[1], v[2], v[3]);
+        s += (double)vs; q += (double)vq;
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) {
+        const float h = cg_prelu(cg_bn(ac, t.h0[base + p]), alpha);
+        if (tap) tap[base + p] = h;
+        const float v = h * gate + t.bres[base + p];
+        t.out[base + p] = v;
+        s += (double)v; q += (double)v * (double)v;
+      }
+    }
   }
   if (t.ostats) {
     s = cg_block_sum(s, red);
     q = cg_block_sum(q, red + 16);
     if (threadIdx.x == 0) {
-      double* rep = t.ostats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * t.C;
+      double* rep = t.ostats + (long long)(blockIdx.y % CG_STAT_REPLICAS) * 2 * C;
       atomicAdd(&rep[2 * c], s); atomicAdd(&rep[2 * c + 1], q);
     }
   }
@@ -452,16 +509,28 @@ __global__ void cg_tail_f4_kernel(CgDstdTail t, int rb) {
 // backward
 // ======================================================================================================================
 // K1: dgate[b,c] = sum_p dout * h
-__global__ void cg_tail_k1_kernel(CgDstdTail t) {
-  __shared__ double red[16];
-  const int c = blockIdx.x, b = blockIdx.y, P = t.T * t.V;
-  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, 0.0, t.train, true, false);
+__global__ void cg_tail_k1_kernel(CgDstdTail t, int rb) {
+  const int c = blockIdx.x, b0 = blockIdx.y * rb, P = t.T * t.V, C = t.C;
+  if (b0 >= t.B) return;
+  const int nb = min(rb, t.B - b0), lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, C, 0.0, t.train, true, false);
   const float alpha = t.alpha_c[0];
-  const long long base = ((long long)b * t.C + c) * P;
-  double s = 0.0;
-  for (int p = threadIdx.x; p < P; p += blockDim.x) s += (double)t.dout[base + p] * (double)cg_prelu(cg_bn(ac, t.h0[base + p]), alpha);
-  s = cg_block_sum(s, red);
-  if (threadIdx.x == 0) t.dgate[(long long)b * t.C + c] = (float)s;
+  for (int br = wave; br < nb; br += nw) {
+    const int b = b0 + br;
+    const long long base = ((long long)b * C + c) * P;
+    float s = 0.f;
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        const float4 d4 = *reinterpret_cast<const float4*>(t.dout + base + p), h4 = *reinterpret_cast<const float4*>(t.h0 + base + p);
+        s += (d4.x * cg_prelu(cg_bn(ac, h4.x), alpha) + d4.y * cg_prelu(cg_bn(ac, h4.y), alpha)) +
+             (d4.z * cg_prelu(cg_bn(ac, h4.z), alpha) + d4.w * cg_prelu(cg_bn(ac, h4.w), alpha));
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) s += t.dout[base + p] * cg_prelu(cg_bn(ac, t.h0[base + p]), alpha);
+    }
+    const double sd = cg_wave_sum((double)s);
+    if (lane == 0) t.dgate[(long long)b * C + c] = (float)sd;
+  }
 }
 
 // gradient in front of the compressor's PReLU for one element: g_c = (dout * gate + dpooled / P) * PReLU_c'(u); returns g_c, u
@@ -476,22 +545,42 @@ __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
   __shared__ double red[48];
   const int c = blockIdx.x, b0 = blockIdx.y * rb;
   if (b0 >= t.B) return;
-  const int P = t.T * t.V, nb = min(rb, t.B - b0);
-  const CgAff ac = cg_tail_aff(t.bn_c, c, t.C, 0.0, t.train, true, false);
+  const int P = t.T * t.V, nb = min(rb, t.B - b0), C = t.C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+  const CgAff ac = cg_tail_aff(t.bn_c, c, C, 0.0, t.train, true, false);
   const float alpha = t.alpha_c[0], invP = 1.f / (float)P;
   double s1 = 0.0, s2 = 0.0, sa = 0.0;
-  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
-    const int br = e / P, p = e - br * P, b = b0 + br;
-    const long long off = ((long long)b * t.C + c) * P + p;
-    float u;
-    const float g = cg_tail_gc(t, ac, alpha, off, b, c, invP, u);
-    s1 += (double)g;
-    s2 += (double)g * (double)((t.h0[off] - ac.mean) * ac.rstd);
-    if (!(u > 0.f)) sa += (double)(t.dout[off] * t.gate[(long long)b * t.C + c] + t.dpooled[(long long)b * t.C + c] * invP) * (double)u;
+  for (int br = wave; br < nb; br += nw) {
+    const int b = b0 + br;
+    const long long base = ((long long)b * C + c) * P;
+    const float gate = t.gate[(long long)b * C + c], dp = t.dpooled[(long long)b * C + c] * invP;
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        const float4 d4 = *reinterpret_cast<const float4*>(t.dout + base + p), h4 = *reinterpret_cast<const float4*>(t.h0 + base + p);
+        const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+        float g1 = 0.f, g2 = 0.f, ga = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float u = cg_bn(ac, hv[j]), dh = dv[j] * gate + dp;
+          const float g = u > 0.f ? dh : alpha * dh;
+          g1 += g; g2 += g * ((hv[j] - ac.mean) * ac.rstd);
+          ga += u > 0.f ? 0.f : dh * u;
+        }
+        s1 += (double)g1; s2 += (double)g2; sa += (double)ga;
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) {
+        float u;
+        const float g = cg_tail_gc(t, ac, alpha, base + p, b, c, invP, u);
+        s1 += (double)g;
+        s2 += (double)g * (double)((t.h0[base + p] - ac.mean) * ac.rstd);
+        if (!(u > 0.f)) sa += (double)(t.dout[base + p] * gate + dp) * (double)u;
+      }
+    }
   }
   s1 = cg_block_sum(s1, red); s2 = cg_block_sum(s2, red + 16); sa = cg_block_sum(sa, red + 32);
   if (threadIdx.x == 0) {
-    atomicAdd(&t.red_c[2 * c], s1); atomicAdd(&t.red_c[2 * c + 1], s2); atomicAdd(&t.red_c[2 * t.C + ((c + 5 * (int)blockIdx.y) & (CG_ALPHA_SLOTS - 1))], sa);
+    atomicAdd(&t.red_c[2 * c], s1); atomicAdd(&t.red_c[2 * c + 1], s2); atomicAdd(&t.red_c[2 * C + ((c + 5 * (int)blockIdx.y) & (CG_ALPHA_SLOTS - 1))], sa);
   }
 }
 
@@ -888,17 +977,43 @@ __global__ void cg_tail_k4_kernel(CgDstdTail t, int rb) {
 __global__ void cg_tail_k5_kernel(CgDstdTail t, int rb) {
   const int i = blockIdx.z, c = blockIdx.x, b0 = blockIdx.y * rb;
   if (b0 >= t.B) return;
-  const int P = t.T * t.V, nb = min(rb, t.B - b0);
+  const int P = t.T * t.V, nb = min(rb, t.B - b0), C = t.C;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
   const double cnt = (double)t.B * P;
-  const CgAff at = cg_tail_aff(t.bn_t[i], c, t.C, 0.0, t.train, true, false);
+  const CgAff at = cg_tail_aff(t.bn_t[i], c, C, 0.0, t.train, true, false);
   const unsigned long long seed = (t.train && t.drop_p > 0.f) ? *t.seed : 0ull;
+  const bool train = t.train != 0;
   float m1 = 0.f, m2 = 0.f;
-  if (t.train) { m1 = (float)(t.red_t[i][2 * c] / cnt); m2 = (float)(t.red_t[i][2 * c + 1] / cnt); }
-  for (int e = threadIdx.x; e < nb * P; e += blockDim.x) {
-    const int br = e / P, p = e - br * P, b = b0 + br;
-    const long long off = ((long long)b * t.C + c) * P + p;
-    const float gt = t.dr[i][off] * cg_tail_keep(t, i, seed, b, c, p);
-    t.dy[i][off] = t.train ? at.gamma * at.rstd * (gt - m1 - (t.y[i][off] - at.mean) * at.rstd * m2) : gt * at.gamma * at.rstd;
+  if (train) { m1 = (float)(t.red_t[i][2 * c] / cnt); m2 = (float)(t.red_t[i][2 * c + 1] / cnt); }
+  const float scale = at.gamma * at.rstd, rm2 = at.rstd * m2;
+  const float* __restrict__ dr = t.dr[i]; const float* __restrict__ y = t.y[i]; float* __restrict__ dy = t.dy[i];
+  for (int br = wave; br < nb; br += nw) {                 // a wave per row, 16-byte accesses, one dropout hash per quad (as K4)
+    const int b = b0 + br;
+    const long long base = ((long long)b * C + c) * P;
+    if ((P & 3) == 0) {
+      for (int p = 4 * lane; p < P; p += 256) {
+        float keep[4];
+        cg_tail_keep4(t, i, seed, (unsigned long long)(base + p), keep);
+        const float4 g4 = *reinterpret_cast<const float4*>(dr + base + p);
+        const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float o[4];
+        if (train) {
+          const float4 y4 = *reinterpret_cast<const float4*>(y + base + p);
+          const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = scale * (gv[j] * keep[j] - m1 - (yv[j] - at.mean) * rm2);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = gv[j] * keep[j] * scale;
+        }
+        *reinterpret_cast<float4*>(dy + base + p) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else {
+      for (int p = lane; p < P; p += 64) {
+        const float gt = dr[base + p] * cg_tail_keep(t, i, seed, b, c, p);
+        dy[base + p] = train ? scale * (gt - m1 - (y[base + p] - at.mean) * rm2) : gt * scale;
+      }
+    }
   }
   if (blockIdx.y == 0 && threadIdx.x == 0) {
     t.dgamma_t[i][c] = (float)t.red_t[i][2 * c + 1]; t.dbeta_t[i][c] = (float)t.red_t[i][2 * c];
@@ -975,7 +1090,7 @@ extern "C" int cg_dstd_tail_fwd(const CgDstdTail* t, int phase, void* stream_) {
 #undef CG_TAIL_F2_LAUNCH
   } else if (phase == 3) {
     if (!t->pooled || (t->train && !t->bn_c.stats)) return CG_EARG;
-    hipLaunchKernelGGL(cg_tail_f3_kernel, dim3((unsigned)t->C, (unsigned)t->B), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+    hipLaunchKernelGGL(cg_tail_f3_kernel, rows, dim3(256), 0, stream, *t, rb);
   } else if (phase == 4) {
     if (!t->gate || !t->bres || !t->out) return CG_EARG;
     hipLaunchKernelGGL(cg_tail_f4_kernel, rows, dim3(256), 0, stream, *t, rb);
@@ -993,7 +1108,7 @@ extern "C" int cg_dstd_tail_bwd(const CgDstdTail* t, int phase, void* stream_) {
   const dim3 rows((unsigned)C, (unsigned)((t->B + rb - 1) / rb), 1);
   if (phase == 1) {
     if (!t->dgate) return CG_EARG;
-    hipLaunchKernelGGL(cg_tail_k1_kernel, dim3((unsigned)C, (unsigned)t->B), dim3(P <= 256 ? 64 : 256), 0, stream, *t);
+    hipLaunchKernelGGL(cg_tail_k1_kernel, rows, dim3(256), 0, stream, *t, rb);
   } else if (phase == 2) {
     if (!t->dpooled || !t->red_c) return CG_EARG;
     hipLaunchKernelGGL(cg_tail_k2_kernel, rows, dim3(256), 0, stream, *t, rb);
