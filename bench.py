@@ -287,7 +287,7 @@ def attach_traffic(fams, workload):
 
 def block_roofline(C, B, T, V, device, dropout, reps=5):
     """SURVEY 8(d) bytes of ONE DSTD_GC invocation (C -> C on (T,V): three of the six blocks, and the bulk of the step)
-    divided by the summed time of all its kernels, forward and backward, HIP events around the eager block."""
+    divided by the summed time of all its kernels, forward and backward: HIP events around every library call of the eager block."""
     from cistgcn_amd import ops
     from cistgcn_amd.models import CISTGCN_0
     torch.manual_seed(0)
@@ -295,25 +295,29 @@ def block_roofline(C, B, T, V, device, dropout, reps=5):
     blk = net.st_gcnns[1]
     x = torch.randn(B, C, T, V, device=device, requires_grad=True)
     tf = tb = 0.0
+    nf = nb = 0
     for r in range(reps + 2):
         ops.begin_step(device, bump_seed=False)
         net._site = 0
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         x.grad = None
-        e[0].record()
-        y = net._block_staged(blk, x)
-        y = y[0] if isinstance(y, tuple) else y
-        e[1].record()
-        y.backward(torch.ones_like(y))
-        e[2].record()
+        # every library call of the block bracketed by HIP events on its stream, the brackets summed: kernel time.  (Events around the
+        # whole eager block measured the host as well: ~45 launches of a few tens of microseconds of Python each are as long as the
+        # block's kernels since round 4 - the figure moved with the box's CPU, not with the kernels.)
+        with CallProbe() as pf:
+            y = net._block_staged(blk, x)
+            y = y[0] if isinstance(y, tuple) else y
+        with CallProbe() as pb:
+            y.backward(torch.ones_like(y))
         torch.cuda.synchronize()
         if r >= 2:
-            tf += e[0].elapsed_time(e[1]) * 1e-3
-            tb += e[1].elapsed_time(e[2]) * 1e-3
+            tf += sum(e0.elapsed_time(e1) for _, _, e0, e1 in pf.rows) * 1e-3
+            tb += sum(e0.elapsed_time(e1) for _, _, e0, e1 in pb.rows) * 1e-3
+            nf, nb = len(pf.rows), len(pb.rows)
     tf, tb = tf / reps, tb / reps
     bf, bb = block_bytes(C, C, T, V)
     flops = 2.0 * B * (C * V * T * T + C * T * V * V + 2 * C * C * T * V + 2 * C * C * T * V)   # both graph products, both tcn, compressor
     return {"block": "DSTD_GC %d->%d on (T=%d, V=%d), B=%d, train mode, eager launches" % (C, C, T, V, B), "bound": "hbm",
+            "library_calls_fwd": nf, "library_calls_bwd": nb, "timing": "sum of the HIP-event brackets of every library call",
             "algorithmic_bytes_fwd": B * bf, "algorithmic_bytes_bwd": B * bb, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6,
             "achieved": B * (bf + bb) / (tf + tb) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": B * (bf + bb) / (tf + tb) / 1e9 / HBM_PEAK_GBS,
             "fwd_frac": B * bf / tf / 1e9 / HBM_PEAK_GBS, "bwd_frac": B * bb / tb / 1e9 / HBM_PEAK_GBS,

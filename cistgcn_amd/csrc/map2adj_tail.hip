@@ -139,8 +139,10 @@ __device__ __forceinline__ void cg_adj_m1_body(const CgAdjTail& t, const CgAdjGe
     for (int k0 = 0; k0 < K::KcM; k0 += 16) {
       float av[4], b0v[4], b1v[4];
       cg_tfrag<0>(ap, K::WS, k0, av);
-      cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, oka ? aa : 0, oka ? pa - aa * t.J : 0, oka, b0v);
-      cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, okb ? ab : 0, okb ? pb - ab * t.J : 0, okb, b1v);
+      // (positions beyond the tensor read the tables at (0, 0): their result rows are never stored, so nothing is masked - a condition
+      // here turns into a branch and a wait around every one of the LDS reads)
+      cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, oka ? aa : 0, oka ? pa - aa * t.J : 0, true, b0v);
+      cg_adj_seed_frag_k(sS, sQ, g.JS, k0, slot, okb ? ab : 0, okb ? pb - ab * t.J : 0, true, b1v);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0v[s], av[s], c0, 0, 0, 0);

@@ -42,14 +42,14 @@ for n in sorted(set(int(v) for v in st[:, 0].unique()) - {0}):
     rows = st[st[:, 0] == n][:, 1:n + 1].double()
     d = rows[:, 1:] - rows[:, :-1]
     m = d.mean(0)
-    tiles = (n - 4) // 7
+    tiles = (n - 4) // 8
     print("== workgroups with %d stamps (%d tiles): %d workgroups, lifetime mean %.0f ticks" % (n, tiles, rows.shape[0], float((rows[:, -1] - rows[:, 0]).mean())))
     print("   prologue (tables, weights, constants, first fetch issue): %.0f" % float(m[0]))
-    acc = [0.0] * 7
+    acc = [0.0] * 8
     for t in range(tiles):
-        for j in range(7):
-            acc[j] += float(m[1 + 7 * t + j])
-    lab = ["E'->A top barrier", "A->A1 wait for the prefetched tile, commit de", "A1->A2 seed image", "A2->A3 barrier", "A3->B prefetch issue", "B->C dW0 product", "C->E do product, dS / dQ atomics"]
-    for j in range(7):
+        for j in range(8):
+            acc[j] += float(m[1 + 8 * t + j])
+    lab = ["E'->A dQ / dS cells of the previous tile + top barrier", "A->A1 wait for the prefetched tile, commit de", "A1->A2 seed image", "A2->A3 barrier", "A3->B prefetch issue", "B->C dW0 product", "C->D barrier", "D->E do product + image + barrier"]
+    for j in range(8):
         print("   %-50s %8.1f per tile" % (lab[j], acc[j] / max(tiles, 1)))
-    print("   last barrier %.0f | epilogue: part + dW atomics %.0f" % (float(m[1 + 7 * tiles]), float(m[-1])))
+    print("   last cells + barrier %.0f | epilogue: part + dW atomics %.0f" % (float(m[1 + 8 * tiles]), float(m[-1])))
