@@ -93,7 +93,7 @@ FAM_CONTRACT = "contraction (cg_contract_many)"
 FAM_ADJ = "Map2Adj tail phases (cg_map2adj_tail_fwd/bwd)"
 FAM_ROWS = "row kernels (cg_norm_act_fwd/bwd, cg_chan_stats)"
 FAM_PWM = "stacked tower maps (cg_pointwise_maps_fwd/bwd)"
-FAM_ROWSCONV = "frame-collapsing convolutions (cg_collapse_rows_fwd/bwd)"
+FAM_ROWSCONV = "frame- / joint-collapsing convolutions (cg_collapse_rows_fwd/bwd, cg_collapse_cols_fwd/bwd)"
 FAM_FPN = "time-extrapolator convolutions (cg_fpn_conv_fwd/bwd)"
 FAM_STATS = "block input: global_norm + statistics (cg_block_input_fwd/bwd, cg_dstd_stats_fwd/bwd)"
 FAM_CTX = "ContextLayer heads (cg_context_heads_fwd/bwd)"
@@ -105,7 +105,7 @@ FAMILY_KERNELS = {          # device-kernel name prefixes of each family, as roc
     FAM_ADJ: ("cg_adj_",),
     FAM_ROWS: ("cg_norm_act_", "cg_chan_stats"),
     FAM_PWM: ("cg_pwm_",),
-    FAM_ROWSCONV: ("cg_rows_",),
+    FAM_ROWSCONV: ("cg_rows_", "cg_cols_"),
     FAM_FPN: ("cg_fpn_",),
     FAM_STATS: ("cg_bin_", "cg_dstd_stats"),
     FAM_CTX: ("cg_ctx_",),
@@ -166,7 +166,7 @@ def _call_bytes(name, args):
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.PwMaps)).contents
         x, ys = 4 * t.B * t.Cin * t.P, sum(4 * t.B * t.M[i] * t.P for i in range(t.n))
         return FAM_PWM, (x + ys) if name.endswith("fwd") else (2 * x + ys)
-    if name in ("cg_collapse_rows_fwd", "cg_collapse_rows_bwd"):
+    if name in ("cg_collapse_rows_fwd", "cg_collapse_rows_bwd", "cg_collapse_cols_fwd", "cg_collapse_cols_bwd"):
         import ctypes
         t = ctypes.cast(args[0], ctypes.POINTER(_lib.RowsConv)).contents
         x = 4 * t.B * t.C * t.T * t.V
@@ -653,7 +653,7 @@ def main():
             # `traffic`: HBM bytes of one such invocation from the PMC passes over tools/prof_block.py (profiles/r04_traffic.json).
             out["roofline"] = {"bound": "hbm", "achieved": blk["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": blk["frac"],
                                "traffic": blk_traffic,
-                               "kernel": "every kernel of one DSTD_GC block invocation, forward + backward (cg_bin_*, cg_pwm_*, cg_rows_*, cg_contract*, "
+                               "kernel": "every kernel of one DSTD_GC block invocation, forward + backward (cg_bin_*, cg_pwm_*, cg_rows_*, cg_cols_*, cg_contract*, "
                                          "cg_norm_act_*, cg_adj_*, cg_stgcn_*, cg_tail_*, cg_se_gate_*)",
                                "unit_of_work": blk["block"],
                                "algorithmic_bytes_per_launch": blk["algorithmic_bytes_fwd"] + blk["algorithmic_bytes_bwd"],

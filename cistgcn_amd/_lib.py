@@ -200,6 +200,10 @@ _SIGNATURES = {
     "cg_collapse_rows_fwd": [POINTER(RowsConv), P],
     "cg_collapse_rows_bwd": [POINTER(RowsConv), P],
     "cg_collapse_rows_ws_floats": [c_int, c_int, c_int],
+    "cg_collapse_cols_fwd": [POINTER(RowsConv), P],
+    "cg_collapse_cols_bwd": [POINTER(RowsConv), P],
+    "cg_collapse_cols_supported": [c_int, c_int, c_int, c_int],
+    "cg_collapse_cols_ws_floats": [c_int, c_int, c_int],
     "cg_fpn_conv_fwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_bwd": [POINTER(FpnConv), P],
     "cg_fpn_conv_supported": [c_int, c_int, c_int, c_int, c_int],

@@ -238,6 +238,223 @@ __global__ void cg_rows_fold_kernel(CgRowsArgs a) {
   }
 }
 
+// ======================================================================================================================
+// The same for the JOINT axis (reference: nn.Conv2d(C, O, (1, V)) of Map2Adj.joint_compress, CISTGCN.py:152-163):
+//   y[b,o,t] = sum_{c,v} W[o,c,v] x[b,c,t,v]        per sample  Y_b (O x T) = W (O x K) X_b (K x T),  K = C * V
+// x[b] lies in memory as [c][t][v]: row k = (c, v) of X_b is a column of stride V.  A lane's four consecutive k of an MFMA step are
+// four consecutive v of one frame (a 16-byte run; a step that crosses from channel c to c + 1 splits), the 16 lanes of a row take 16
+// frames.  Round 3 ran this through the generic contraction (split-K with atomics: 92 / 154 us per block next to the gate items).
+//   forward   one 512-thread workgroup per sample, eight waves split K, operands straight from global memory, DEPTH groups in flight
+//   backward  a workgroup owns 64 rows k for a slice of the samples (dx[b,k,t] from W^T dy, dW[o,k] in registers over the slice)
+// T <= 64 (NT tiles of 16 frames), O <= 64, C * V % 4 == 0.
+// ======================================================================================================================
+__device__ __forceinline__ unsigned cg_cols_div(unsigned n, unsigned magic) { return magic ? (unsigned)(((unsigned long long)n * magic) >> 32) : n; }
+
+template <int OT, int NT>
+__global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRowsArgs a, unsigned magicV) {
+  const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
+  const int b = blockIdx.x, K = g.K, V = t.V, T = t.T, O = t.O, TV = T * V;
+  constexpr int nw = CG_ROWS_FWD_THREADS / 64, DEPTH = 3, YS = 16 * NT + 1;
+  float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [nw][16 * OT][YS] partial tiles of the eight waves
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
+  const float* xb = t.x + (long long)b * K * T;
+  cg_f32x4 acc[OT][NT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ngroups = (K + 15) >> 4;
+  const float* wrow[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) wrow[i] = t.W + (long long)min(16 * i + l15, O - 1) * K;
+  int toff[NT];                                                   // frame of this lane in tile j (clamped: columns t >= T are never stored)
+#pragma unroll
+  for (int j = 0; j < NT; ++j) toff[j] = min(16 * j + l15, T - 1) * V;
+  struct Frag { float4 w[OT]; float x[NT][4]; float mask; };
+  auto load = [&](int gi, Frag& f) {
+    const int k = 16 * gi + 4 * slot;
+    const bool kin = k < K;                                       // K % 4 == 0
+    const int kc = kin ? k : K - 4;
+    f.mask = kin ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < OT; ++i) f.w[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int kk = kc + s, c = (int)cg_cols_div((unsigned)kk, magicV), v = kk - c * V;
+      const float* xr = xb + c * TV + v;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) f.x[j][s] = xr[toff[j]];
+    }
+  };
+  auto mma = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+      const float w4[4] = {f.w[i].x * f.mask, f.w[i].y * f.mask, f.w[i].z * f.mask, f.w[i].w * f.mask};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s], f.x[j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+  Frag f[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH; ++j)
+    if (wave + j * nw < ngroups) load(wave + j * nw, f[j]);
+  for (int gi = wave; gi < ngroups; gi += DEPTH * nw) {
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) {
+      const int gj = gi + j * nw;
+      if (gj < ngroups) {
+        mma(f[j]);
+        if (gj + DEPTH * nw < ngroups) load(gj + DEPTH * nw, f[j]);
+      }
+    }
+  }
+  float* mine = sY + wave * 16 * OT * YS;
+#pragma unroll
+  for (int i = 0; i < OT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mine[(16 * i + 4 * slot + q) * YS + 16 * j + l15] = acc[i][j][q];
+  __syncthreads();
+  for (int e = tid; e < O * T; e += CG_ROWS_FWD_THREADS) {
+    const int o = e / T, tt = e - o * T;
+    float y = 0.f;
+#pragma unroll
+    for (int w = 0; w < nw; ++w) y += sY[(w * 16 * OT + o) * YS + tt];
+    t.y[(long long)b * O * T + e] = y;
+    sY[o * YS + tt] = y;                                   // this thread's own element of slot 0: the channel sums below read it
+  }
+  if (t.stats) {
+    __syncthreads();
+    for (int o = tid; o < O; o += CG_ROWS_FWD_THREADS) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int tt = 0; tt < T; ++tt) { const double y = (double)sY[o * YS + tt]; s1 += y; s2 += y * y; }
+      double* rep = t.stats + ((long long)(b % CG_STAT_REPLICAS) * O + o) * 2;
+      atomicAdd(&rep[0], s1); atomicAdd(&rep[1], s2);
+    }
+  }
+}
+
+template <int OT, int NT>
+__global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRowsArgs a, unsigned magicV) {
+  const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
+  const int K = g.K, V = t.V, T = t.T, O = t.O, TV = T * V;
+  const int kr = blockIdx.x, sl = blockIdx.y, k0 = kr * CG_ROWS_KB;
+  const int b0 = sl * g.per, b1 = min(t.B, b0 + g.per);
+  if (b0 >= t.B) return;
+  constexpr int WS = CG_ROWS_KB + 4, DS = 16 * NT + 4;
+  float* sW = reinterpret_cast<float*>(cg_dyn_lds);              // [16 * OT][KB + 4]  W[o][k0 ..]
+  float* sDY = sW + 16 * OT * WS;                                 // [2][16 * OT][DS]   dy of the current / next sample, frames padded with zeros
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
+  for (int e0 = tid; e0 < 16 * OT * WS; e0 += 8 * CG_ROWS_BWD_THREADS) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + CG_ROWS_BWD_THREADS * j, o = e / WS, kk = e - o * WS;
+      const bool in = o < O && kk < CG_ROWS_KB && k0 + kk < K;
+      v[j] = t.W[in ? (long long)o * K + k0 + kk : (long long)k0];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + CG_ROWS_BWD_THREADS * j, o = e / WS, kk = e - o * WS;
+      if (e < 16 * OT * WS) sW[e] = (o < O && kk < CG_ROWS_KB && k0 + kk < K) ? v[j] : 0.f;
+    }
+  }
+  for (int e = tid; e < 2 * 16 * OT * DS; e += CG_ROWS_BWD_THREADS) sDY[e] = 0.f;
+  __syncthreads();
+  auto stage_dy = [&](int b, int buf) {
+    const float* src = t.dy + (long long)b * O * T;
+    float* dst = sDY + buf * 16 * OT * DS;
+    for (int e = tid; e < O * T; e += CG_ROWS_BWD_THREADS) { const int o = e / T, tt = e - o * T; dst[o * DS + tt] = src[e]; }
+  };
+  stage_dy(b0, 0);
+  // a wave owns the 16 rows k = k0 + 16 wave + .. of the range: dW tiles [o][k] in registers over the slice
+  cg_f32x4 wacc[OT];
+#pragma unroll
+  for (int i = 0; i < OT; ++i) wacc[i] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kw = k0 + 16 * wave;
+  // row k = (c, v) of this lane as the B operand of the dW product (x[b][c][t][v], t = 16 tt + 4 slot + s), clamped: rows k >= K are never stored
+  const int kl = min(kw + l15, K - 1), cl = (int)cg_cols_div((unsigned)kl, magicV);
+  const int xoff = cl * TV + (kl - cl * V);
+  int tx[NT][4];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) tx[tt][s] = min(16 * tt + 4 * slot + s, T - 1) * V;      // frames >= T meet dy = 0
+  // rows k = kw + 4 slot + q of this lane's dx results
+  int doff[4]; bool dok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = kw + 4 * slot + q, kc = min(k, K - 1), c = (int)cg_cols_div((unsigned)kc, magicV);
+    doff[q] = c * TV + (kc - c * V); dok[q] = k < K;
+  }
+  auto load_x = [&](int b, float xv[NT][4]) {
+    const float* xr = t.x + (long long)b * K * T + xoff;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xv[tt][s] = xr[tx[tt][s]];
+  };
+  float xa[NT][4], xn[NT][4];
+  load_x(b0, xa);
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
+    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xn); }
+    const float* dyb = sDY + buf * 16 * OT * DS;
+    float* dxb = t.dx + (long long)b * K * T;
+    // dx[k][t] = sum_o W[o][k] dy[o][t]: rows k of this wave, NT tiles of frames
+    cg_f32x4 c[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) c[j] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int oc = 0; oc < 16 * OT; oc += 16) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int o = oc + 4 * slot + s;
+        const float w = sW[o * WS + 16 * wave + l15];              // A[i = k][kk = o]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, dyb[o * DS + 16 * j + l15], c[j], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int tt = 16 * j + l15;
+      if (tt < T) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dok[q]) dxb[doff[q] + tt * V] = c[j][q];
+      }
+    }
+    // dW[o][k] += sum_t dy[o][t] x[k][t]: A[i = o][kk = t] from LDS (float4 along t), B[kk = t][j = k] = this lane's x values
+#pragma unroll
+    for (int i = 0; i < OT; ++i) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt) {
+        const float4 d4 = *reinterpret_cast<const float4*>(dyb + (16 * i + l15) * DS + 16 * tt + 4 * slot);
+        const float e4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wacc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(e4[s], xa[tt][s], wacc[i], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xa[tt][s] = xn[tt][s];
+  }
+  float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
+#pragma unroll
+  for (int i = 0; i < OT; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = 16 * i + 4 * slot + q, k = kw + l15;
+      if (o < O && k < K) atomicAdd(&ws[(long long)o * K + k], wacc[i][q]);
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int cg_rows_geometry(const CgRowsConv* t, CgRowsGeom* g) {
   if (!t || !t->x || !t->W) return CG_EARG;
@@ -290,6 +507,82 @@ extern "C" int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream_) {
   const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * 36) * sizeof(float);
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(cg_rows_bwd_kernel, dim3((unsigned)a.g.kranges, (unsigned)a.g.slices), dim3(CG_ROWS_BWD_THREADS), lds, stream, a);
+  st = cg_launch_status();
+  if (st != CG_OK) return st;
+  hipLaunchKernelGGL(cg_rows_fold_kernel, dim3(128), dim3(256), 0, stream, a);
+  return cg_launch_status();
+}
+
+// ---- joint axis ----
+static unsigned cg_cols_magic(int d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
+static int cg_cols_geometry(const CgRowsConv* t, CgRowsGeom* g) {
+  if (!t || !t->x || !t->W) return CG_EARG;
+  if (t->B <= 0 || t->C <= 0 || t->T <= 0 || t->V <= 0 || t->T > 64 || t->O <= 0 || t->O > 64) return CG_ESHAPE;
+  const long long K = (long long)t->C * t->V;
+  if (K > (1 << 20) || (K & 3) || K * t->T >= (1ll << 31)) return CG_ESHAPE;
+  g->K = (int)K; g->OT = (t->O + 15) / 16;
+  g->kranges = (g->K + CG_ROWS_KB - 1) / CG_ROWS_KB;
+  int slices = 768 / g->kranges;
+  slices = slices < 1 ? 1 : (slices > t->B ? t->B : slices);
+  g->per = (t->B + slices - 1) / slices;
+  g->slices = (t->B + g->per - 1) / g->per;
+  return CG_OK;
+}
+static int cg_cols_nt(int T) { return T <= 16 ? 1 : T <= 32 ? 2 : 4; }
+
+extern "C" int cg_collapse_cols_supported(int C, int T, int V, int O) { return T >= 1 && T <= 64 && O >= 1 && O <= 64 && (((long long)C * V) & 3) == 0 ? 1 : 0; }
+extern "C" long long cg_collapse_cols_ws_floats(int C, int V, int O) { return (long long)CG_ROWS_REPLICAS * O * C * V; }
+
+#define CG_COLS_DISPATCH(OT_, NT_, LAUNCH)                         \
+  switch (4 * ((OT_) - 1) + ((NT_) == 1 ? 0 : (NT_) == 2 ? 1 : 2)) { \
+    case 0: LAUNCH(1, 1) break; case 1: LAUNCH(1, 2) break; case 2: LAUNCH(1, 4) break;       \
+    case 4: LAUNCH(2, 1) break; case 5: LAUNCH(2, 2) break; case 6: LAUNCH(2, 4) break;       \
+    case 8: LAUNCH(3, 1) break; case 9: LAUNCH(3, 2) break; case 10: LAUNCH(3, 4) break;      \
+    case 12: LAUNCH(4, 1) break; case 13: LAUNCH(4, 2) break; default: LAUNCH(4, 4) break;    \
+  }
+
+// include/cistgcn_hip.h : cg_collapse_cols_fwd / cg_collapse_cols_bwd
+extern "C" int cg_collapse_cols_fwd(const CgRowsConv* t, void* stream_) {
+  CgRowsArgs a;
+  int st = cg_cols_geometry(t, &a.g);
+  if (st != CG_OK) return st;
+  if (!t->y) return CG_EARG;
+  a.t = *t;
+  const int nt = cg_cols_nt(t->T);
+  const size_t lds = (size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * (16 * nt + 1) * sizeof(float);
+  const dim3 grid((unsigned)t->B), block(CG_ROWS_FWD_THREADS);
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned magic = cg_cols_magic(t->V);
+#define CG_COLS_FWD_LAUNCH(N, M)                                                                \
+  {                                                                                            \
+    hipError_t e = cg_lds_limit((const void*)cg_cols_fwd_kernel<N, M>, lds);                    \
+    if (e != hipSuccess) return (int)e;                                                        \
+    hipLaunchKernelGGL((cg_cols_fwd_kernel<N, M>), grid, block, lds, stream, a, magic);          \
+  }
+  CG_COLS_DISPATCH(a.g.OT, nt, CG_COLS_FWD_LAUNCH)
+#undef CG_COLS_FWD_LAUNCH
+  return cg_launch_status();
+}
+
+extern "C" int cg_collapse_cols_bwd(const CgRowsConv* t, void* stream_) {
+  CgRowsArgs a;
+  int st = cg_cols_geometry(t, &a.g);
+  if (st != CG_OK) return st;
+  if (!t->dy || !t->dx || !t->dW || !t->ws) return CG_EARG;
+  a.t = *t;
+  const int nt = cg_cols_nt(t->T);
+  const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * (16 * nt + 4)) * sizeof(float);
+  const dim3 grid((unsigned)a.g.kranges, (unsigned)a.g.slices), block(CG_ROWS_BWD_THREADS);
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned magic = cg_cols_magic(t->V);
+#define CG_COLS_BWD_LAUNCH(N, M)                                                                \
+  {                                                                                            \
+    hipError_t e = cg_lds_limit((const void*)cg_cols_bwd_kernel<N, M>, lds);                    \
+    if (e != hipSuccess) return (int)e;                                                        \
+    hipLaunchKernelGGL((cg_cols_bwd_kernel<N, M>), grid, block, lds, stream, a, magic);          \
+  }
+  CG_COLS_DISPATCH(a.g.OT, nt, CG_COLS_BWD_LAUNCH)
+#undef CG_COLS_BWD_LAUNCH
   st = cg_launch_status();
   if (st != CG_OK) return st;
   hipLaunchKernelGGL(cg_rows_fold_kernel, dim3(128), dim3(256), 0, stream, a);

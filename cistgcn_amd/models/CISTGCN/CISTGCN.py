@@ -235,6 +235,7 @@ class CISTGCN(nn.Module):
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
         self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
         self.fused_input = __import__("os").environ.get("CISTGCN_FUSED_INPUT", "1") != "0"   # global_norm + block statistics (and their backward with the fan-in sum) as one operator
+        self.fused_cols = __import__("os").environ.get("CISTGCN_FUSED_COLS", "1") != "0"      # (1,V) convolutions of the joint towers through csrc/collapse_rows.hip (cg_collapse_cols_*)
         self.fused_towers = __import__("os").environ.get("CISTGCN_FUSED_TOWERS", "1") != "0"   # first tower level + BatchNorm + PReLU as one operator (backward without the BatchNorm input gradient)
         self.fused_gates = __import__("os").environ.get("CISTGCN_FUSED_GATES", "1") != "0"    # the gate paths behind their (1,V) convolutions as one launch
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
@@ -550,7 +551,7 @@ class CISTGCN(nn.Module):
         bres = r[-1] if has_bres else x_bres
         # 3. collapsing convolutions
         items = [_cols_item(gs, m.conv_s[4], tr), _cols_item(gt, m.conv_t[4], tr)]
-        rows3 = {}
+        rows3, cols3 = {}, {}
         for i, a in enumerate(maps):
             c3 = a.time_compress[3]
             x3 = t1[2 * i][0] if isinstance(t1[2 * i], tuple) else t1[2 * i]
@@ -560,13 +561,20 @@ class CISTGCN(nn.Module):
                 rows3[i] = (y3.unsqueeze(2), st3)
             else:
                 items.append(_rows_item(t1[2 * i], c3, tr))
-            items.append(_cols_item(t1[2 * i + 1], a.joint_compress[3], tr))
+            c4 = a.joint_compress[3]
+            x4 = t1[2 * i + 1][0] if isinstance(t1[2 * i + 1], tuple) else t1[2 * i + 1]
+            w4 = c4.weight.view(c4.out_channels, c4.in_channels, -1)
+            if big and self.fused_cols and c4.bias is None and ops.collapse_cols_ok(x4, w4):
+                y4, st4 = ops.collapse_cols(x4, w4, tr)                  # whole-sample kernel for the joint axis (csrc/collapse_rows.hip)
+                cols3[i] = (y4.unsqueeze(3), st4)
+            else:
+                items.append(_cols_item(t1[2 * i + 1], c4, tr))
         o = _run_items(items)
-        if rows3:                                                        # back into the order gates | (time, joint) per tower
+        if rows3 or cols3:                                               # back into the order gates | (time, joint) per tower
             rest, o = o[2:], o[:2]
             for i in range(len(maps)):
                 o.append(rows3[i] if i in rows3 else rest.pop(0))
-                o.append(rest.pop(0))
+                o.append(cols3[i] if i in cols3 else rest.pop(0))
         # 4. BatchNorm tails
         Cg = m.conv_s[4].out_channels
         gate_fused = (self.fused_gates and o[0][0].shape[1] == Cg and o[0][0].numel() == B * Cg and

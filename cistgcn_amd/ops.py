@@ -2280,3 +2280,52 @@ class _CollapseRows(torch.autograd.Function):
 def collapse_rows(x, w, want_stats=False):
     """(y (B,O,V), f64 channel sums or None) of the frame-collapsing convolution w (O,C,T) of x (B,C,T,V)."""
     return _CollapseRows.apply(bool(want_stats), x, w)
+
+
+def collapse_cols_ok(x, w):
+    """True when `collapse_cols` takes the (1,V) convolution `w` (O,C,V) of x (B,C,T,V)."""
+    if not _ROWS_KERNELS or x.dim() != 4 or not x.is_contiguous() or w.dim() != 3:
+        return False
+    B, C, T, V = x.shape
+    return w.shape[1] == C and w.shape[2] == V and T <= 64 and w.shape[0] <= 64 and (C * V) % 4 == 0 and C * T * V < 2 ** 31
+
+
+class _CollapseCols(torch.autograd.Function):
+    """y[b,o,t] = sum_{c,v} w[o,c,v] x[b,c,t,v] (nn.Conv2d(C, O, (1,V)), CISTGCN.py:152-163), see csrc/collapse_rows.hip"""
+
+    @staticmethod
+    def forward(ctx, want_stats, x, w):
+        ctx.set_materialize_grads(False)
+        _chk(x)
+        w = w if w.is_contiguous() else _copy(w)
+        B, C, T, V = x.shape
+        O = w.shape[0]
+        t = _CollapseRows._block(x, w)
+        y = torch.empty(B, O, T, dtype=torch.float32, device=x.device)
+        stats = _arena(x.device).take(2 * O * _lib.STAT_REPLICAS) if want_stats else None
+        t.y, t.stats = y.data_ptr(), _ptr(stats)
+        _lib.call("cg_collapse_cols_fwd", ctypes.byref(t), _stream(x))
+        ctx.save_for_backward(x, w)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _=None):
+        x, w = ctx.saved_tensors
+        if dy is None:
+            return None, None, None
+        dy = dy if dy.is_contiguous() else _copy(dy)
+        B, C, T, V = x.shape
+        t = _CollapseRows._block(x, w)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        zb, _z = _zeros(int(_lib.lib().cg_collapse_cols_ws_floats(C, V, w.shape[0])), x.device)
+        t.dy, t.dx, t.dW, t.ws = dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), zb.data_ptr()
+        _lib.call("cg_collapse_cols_bwd", ctypes.byref(t), _stream(x))
+        return None, dx if ctx.needs_input_grad[1] else None, dw if ctx.needs_input_grad[2] else None
+
+
+def collapse_cols(x, w, want_stats=False):
+    """(y (B,O,T), f64 channel sums or None) of the joint-collapsing convolution w (O,C,V) of x (B,C,T,V)."""
+    return _CollapseCols.apply(bool(want_stats), x, w)

@@ -252,6 +252,13 @@ typedef struct CgRowsConv {
 int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream);
 int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream);
 long long cg_collapse_rows_ws_floats(int C, int T, int O);
+/* The same for the joint axis: nn.Conv2d(C, O, (1, V)) (no bias), second convolution of Map2Adj.joint_compress, CISTGCN.py:152-163.
+ * y[b,o,t] = sum_{c,v} W[o,c,v] x[b,c,t,v]; same argument block with W (O, C*V), y (B,O,T), dy (B,O,T), ws of
+ * cg_collapse_cols_ws_floats(C, V, O) zeroed floats; T <= 64, O <= 64, C*V % 4 == 0 (cg_collapse_cols_supported; else cg_contract_many). */
+int cg_collapse_cols_fwd(const CgRowsConv* t, void* stream);
+int cg_collapse_cols_bwd(const CgRowsConv* t, void* stream);
+int cg_collapse_cols_supported(int C, int T, int V, int O);
+long long cg_collapse_cols_ws_floats(int C, int V, int O);
 
 /* ---- dilated 3x3 convolutions of the time extrapolator, FPN CISTGCN.py:54-79: n <= 3 convolutions with padding = dilation =
  * dil[i] of ONE input (B,C,H,W) = (batch, frames, channels, joints).  A sample fits in LDS with its halo: forward, input gradient

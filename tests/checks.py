@@ -1307,6 +1307,33 @@ def check_collapse_rows(device, shapes=((3, 6, 4, 7, 5), (2, 32, 50, 22, 32), (5
         assert_close(res[0][3], res[1][3], what + " dW", rel=5e-5, floor=max(1e-3, float(res[1][3].abs().max())))
 
 
+
+def check_collapse_cols(device, shapes=((3, 6, 4, 8, 5), (2, 32, 50, 22, 32), (4, 64, 10, 22, 64), (2, 10, 6, 22, 20), (3, 12, 25, 18, 40), (2, 32, 50, 25, 32), (3, 5, 3, 4, 3))):
+    """ops.collapse_cols (joint-collapsing convolution, csrc/collapse_rows.hip) against the generic contraction: output, f64 channel sums,
+    both gradients.  shapes: (B, C, T, V, O): one to four 16-row output tiles, 1 / 2 / 4 tiles of frames (T = 3 .. 50), K = C * V with and
+    without a partial last group, steps that cross from one channel to the next (V = 22, 18, 25 are no multiples of 4)."""
+    g = _gen(67)
+    for (B, C, T, V, O) in shapes:
+        x0, w0 = _rand(g, B, C, T, V), 0.2 * _rand(g, O, C, V)
+        gy = _rand(g, B, O, T).to(device)
+        res = []
+        for fused in (True, False):
+            x, w = _leaf(x0, device), _leaf(w0, device)
+            ops.begin_step(device)
+            if fused:
+                assert ops.collapse_cols_ok(x, w)
+                y, st = ops.collapse_cols(x, w, want_stats=True)
+            else:
+                y, st = ops.contract_stats("ocw,bchw->boh", w, x)
+            y.backward(gy)
+            res.append((y.detach(), _chan_sums(st) if st is not None else None, x.grad, w.grad))
+        what = "collapse_cols B%d C%d T%d V%d O%d" % (B, C, T, V, O)
+        assert_close(res[0][0], res[1][0], what + " y", rel=2e-5)
+        if res[1][1] is not None:
+            assert_close(res[0][1], res[1][1], what + " sums", rel=1e-5)
+        assert_close(res[0][2], res[1][2], what + " dx", rel=5e-5, floor=max(1e-3, float(res[1][2].abs().max())))
+        assert_close(res[0][3], res[1][3], what + " dW", rel=5e-5, floor=max(1e-3, float(res[1][3].abs().max())))
+
 def check_flat_adam(device):
     """cg_adam_flat + FlatGrads against torch.optim.Adam with the reference's settings (weight decay, no amsgrad)."""
     from cistgcn_amd.runtime import FlatAdam
