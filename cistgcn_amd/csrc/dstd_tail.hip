@@ -80,16 +80,15 @@ __global__ void cg_tail_f1_kernel(CgDstdTail t, int rb) {
         cg_tail_keep4(t, i, seed, (unsigned long long)(base + p), keep);
         const float4 y4 = *reinterpret_cast<const float4*>(y + base + p), r4 = *reinterpret_cast<const float4*>(r + base + p);
         const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
-        float xv[4], zs = 0.f, zq = 0.f;
+        float xv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float u;
           xv[j] = cg_tail_x(at, ad, yv[j], rv[j], keep[j], u);
-          const float z = wv * xv[j];
-          zs += z; zq += z * z;
-        }
+          const double z = (double)(wv * xv[j]);
+          s += z; q += z * z;                              // f64 per element, as every BatchNorm sum of this library (a quad summed in f32 first
+        }                                                  // moved a cancelling bias gradient two layers down by 3e-3 of its size)
         if (tap) *reinterpret_cast<float4*>(tap + base + p) = make_float4(xv[0], xv[1], xv[2], xv[3]);
-        s += (double)zs; q += (double)zq;
       }
     } else {
       for (int p = lane; p < P; p += 64) {
@@ -478,12 +477,11 @@ __global__ void cg_tail_f4_kernel(CgDstdTail t, int rb) {
       for (int p = 4 * lane; p < P; p += 256) {
         const float4 h4 = *reinterpret_cast<const float4*>(t.h0 + base + p), r4 = *reinterpret_cast<const float4*>(t.bres + base + p);
         const float hv[4] = {h4.x, h4.y, h4.z, h4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
-        float h[4], v[4], vs = 0.f, vq = 0.f;
+        float h[4], v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = cg_prelu(cg_bn(ac, hv[j]), alpha); v[j] = h[j] * gate + rv[j]; vs += v[j]; vq += v[j] * v[j]; }
+        for (int j = 0; j < 4; ++j) { h[j] = cg_prelu(cg_bn(ac, hv[j]), alpha); v[j] = h[j] * gate + rv[j]; s += (double)v[j]; q += (double)v[j] * (double)v[j]; }
         if (tap) *reinterpret_cast<float4*>(tap + base + p) = make_float4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<float4*>(t.out + base + p) = make_float4(v[0], v[1], v[2], v[3]);
-        s += (double)vs; q += (double)vq;
       }
     } else {
       for (int p = lane; p < P; p += 64) {
@@ -558,15 +556,13 @@ __global__ void cg_tail_k2_kernel(CgDstdTail t, int rb) {
       for (int p = 4 * lane; p < P; p += 256) {
         const float4 d4 = *reinterpret_cast<const float4*>(t.dout + base + p), h4 = *reinterpret_cast<const float4*>(t.h0 + base + p);
         const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
-        float g1 = 0.f, g2 = 0.f, ga = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float u = cg_bn(ac, hv[j]), dh = dv[j] * gate + dp;
           const float g = u > 0.f ? dh : alpha * dh;
-          g1 += g; g2 += g * ((hv[j] - ac.mean) * ac.rstd);
-          ga += u > 0.f ? 0.f : dh * u;
+          s1 += (double)g; s2 += (double)g * (double)((hv[j] - ac.mean) * ac.rstd);
+          sa += u > 0.f ? 0.0 : (double)dh * (double)u;
         }
-        s1 += (double)g1; s2 += (double)g2; sa += (double)ga;
       }
     } else {
       for (int p = lane; p < P; p += 64) {
