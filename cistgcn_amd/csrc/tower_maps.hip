@@ -488,10 +488,12 @@ static int cg_pwm_geometry(const CgPwMaps* t, bool bwd, CgPwGeom* g) {
   return CG_OK;
 }
 
+// A/B aid (read once, only in a process started with CISTGCN_ABLATION=1): CG_PWM_GENERIC=1 sends every shape to the run-time form
+static bool cg_pwm_generic() { static const bool v = getenv("CISTGCN_ABLATION") && getenv("CG_PWM_GENERIC"); return v; }
 // the instantiations with compile-time geometry: (stacked 16-row tiles, input 16-row tiles) of the shipped configurations; anything else
 // takes the run-time form
 #define CG_PWM_DISPATCH(G_, LAUNCH)                                   \
-  if (getenv("CG_PWM_GENERIC")) LAUNCH(0, 0)                         \
+  if (cg_pwm_generic()) LAUNCH(0, 0)                                  \
   else if ((G_).NT == 8 && (G_).CT == 4) LAUNCH(8, 4)        /* four 32-channel towers of a 64-channel block (and 2 x 64 residual maps) */ \
   else if ((G_).NT == 8 && (G_).CT == 1) LAUNCH(8, 1)   /* 128 stacked rows of the 10-channel input block */                         \
   else if ((G_).NT == 4 && (G_).CT == 2) LAUNCH(4, 2)   /* four 16-channel towers of a 32-channel block */                           \
