@@ -29,12 +29,22 @@ struct CgRowsArgs { CgRowsConv t; CgRowsGeom g; };
 // of group g + 4 are issued right behind the MFMAs of group g.  No load sits behind a branch: indices outside the tensor are clamped to
 // a neighbouring element (rows o >= O and columns v >= V land in results that are never stored), only rows k >= K are zeroed.
 template <int OT>
-__global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRowsArgs a) {
+__global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRowsArgs a, unsigned magicT) {
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
   const int b = blockIdx.x, K = g.K, V = t.V, O = t.O;
   constexpr int nw = CG_ROWS_FWD_THREADS / 64, DEPTH = 4;
   float* sY = reinterpret_cast<float*>(cg_dyn_lds);              // [nw][16 * OT][33] partial tiles of the eight waves (no LDS atomics: 1 000 cycles each)
+  float* sTab = sY + nw * 16 * OT * 33;                           // [C][4] input transform: mean, gamma * rstd, beta, -
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
+  const bool tr = t.in_on != 0;
+  const float in_alpha = tr ? t.in_alpha[0] : 1.f;
+  if (tr) {
+    for (int c = tid; c < t.C; c += CG_ROWS_FWD_THREADS) {
+      const CgAff af = cg_tail_aff(t.in_bn, c, t.C, (double)t.B * t.T * V, t.in_train, false, blockIdx.x == 0);
+      sTab[4 * c] = af.mean; sTab[4 * c + 1] = af.gamma * af.rstd; sTab[4 * c + 2] = af.beta; sTab[4 * c + 3] = 0.f;
+    }
+    __syncthreads();
+  }
   const float* xb = t.x + (long long)b * K * V;
   cg_f32x4 acc[OT][2];
 #pragma unroll
@@ -46,20 +56,29 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
   const float* wrow[OT];
 #pragma unroll
   for (int i = 0; i < OT; ++i) wrow[i] = t.W + (long long)min(16 * i + l15, O - 1) * K;
-  struct Frag { float4 w[OT]; float x0[4], x1[4]; float mask; };      // mask: 0 for rows k >= K (applied in front of the MFMAs: arithmetic on a
-                                                                        // loaded value right behind its load would wait for it there)
+  struct Frag { float4 w[OT]; float x0[4], x1[4]; float mask; int kc; };      // mask: 0 for rows k >= K (applied in front of the MFMAs: arithmetic on a
+                                                                                // loaded value right behind its load would wait for it there)
   auto load = [&](int gi, Frag& f) {
     const int k = 16 * gi + 4 * slot;
     const bool kin = k < K;                                 // K % 4 == 0: a lane's four rows are inside or outside together
     const int kc = kin ? k : K - 4;
-    f.mask = kin ? 1.f : 0.f;
+    f.mask = kin ? 1.f : 0.f; f.kc = kc;
 #pragma unroll
     for (int i = 0; i < OT; ++i) f.w[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
     const float* xr = xb + (long long)kc * V;
 #pragma unroll
     for (int s = 0; s < 4; ++s) { f.x0[s] = xr[s * V + vA]; f.x1[s] = xr[s * V + vB]; }
   };
-  auto mma = [&](const Frag& f) {
+  auto mma = [&](Frag& f) {
+    if (tr) {                                               // PReLU(BatchNorm(x)) of the four rows k = (c, t) of this lane, constants of channel c from LDS
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c = (int)(magicT ? (unsigned)(((unsigned long long)(unsigned)(f.kc + s) * magicT) >> 32) : (unsigned)(f.kc + s));
+        const float4 k4 = *reinterpret_cast<const float4*>(sTab + 4 * c);
+        f.x0[s] = cg_prelu((f.x0[s] - k4.x) * k4.y + k4.z, in_alpha);
+        f.x1[s] = cg_prelu((f.x1[s] - k4.x) * k4.y + k4.z, in_alpha);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
       const float w4[4] = {f.w[i].x * f.mask, f.w[i].y * f.mask, f.w[i].z * f.mask, f.w[i].w * f.mask};
@@ -172,8 +191,22 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
       xc_[s] = (krow < K && 16 + v < V) ? xb[(long long)krow * V + 16 + v] : 0.f;
     }
   };
+  // optional input transform (see CgRowsConv.in_on): this lane's row k = (c, t) has ONE channel c; the values outside the tensor meet dy = 0
+  const bool tr = t.in_on != 0;
+  float tm = 0.f, ts = 1.f, tb = 0.f, ta = 1.f;
+  if (tr) {
+    const CgAff af = cg_tail_aff(t.in_bn, min(krow, K - 1) / t.T, t.C, 0.0, t.in_train, true, false);
+    tm = af.mean; ts = af.gamma * af.rstd; tb = af.beta; ta = t.in_alpha[0];
+  }
+  auto act = [&](float xv[4]) {
+    if (tr) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) xv[s] = cg_prelu((xv[s] - tm) * ts + tb, ta);
+    }
+  };
   float xa[4], xc[4], xna[4], xnc[4];
   load_x(b0, xa, xc);
+  act(xa); act(xc);
   for (int b = b0; b < b1; ++b) {
     const int buf = (b - b0) & 1;
     __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
@@ -215,6 +248,7 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) { xa[s] = xna[s]; xc[s] = xnc[s]; }
+    if (b + 1 < b1) { act(xa); act(xc); }
   }
   float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
 #pragma unroll
@@ -271,12 +305,22 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRows
   int toff[NT];                                                   // frame of this lane in tile j (clamped: columns t >= T are never stored)
 #pragma unroll
   for (int j = 0; j < NT; ++j) toff[j] = min(16 * j + l15, T - 1) * V;
-  struct Frag { float4 w[OT]; float x[NT][4]; float mask; };
+  float* sTab = sY + nw * 16 * OT * YS;                           // [C][4] input transform: mean, gamma * rstd, beta, -
+  const bool tr = t.in_on != 0;
+  const float in_alpha = tr ? t.in_alpha[0] : 1.f;
+  if (tr) {
+    for (int c = tid; c < t.C; c += CG_ROWS_FWD_THREADS) {
+      const CgAff af = cg_tail_aff(t.in_bn, c, t.C, (double)t.B * T * V, t.in_train, false, blockIdx.x == 0);
+      sTab[4 * c] = af.mean; sTab[4 * c + 1] = af.gamma * af.rstd; sTab[4 * c + 2] = af.beta; sTab[4 * c + 3] = 0.f;
+    }
+    __syncthreads();
+  }
+  struct Frag { float4 w[OT]; float x[NT][4]; float mask; int kc; };
   auto load = [&](int gi, Frag& f) {
     const int k = 16 * gi + 4 * slot;
     const bool kin = k < K;                                       // K % 4 == 0
     const int kc = kin ? k : K - 4;
-    f.mask = kin ? 1.f : 0.f;
+    f.mask = kin ? 1.f : 0.f; f.kc = kc;
 #pragma unroll
     for (int i = 0; i < OT; ++i) f.w[i] = *reinterpret_cast<const float4*>(wrow[i] + kc);
 #pragma unroll
@@ -287,7 +331,16 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRows
       for (int j = 0; j < NT; ++j) f.x[j][s] = xr[toff[j]];
     }
   };
-  auto mma = [&](const Frag& f) {
+  auto mma = [&](Frag& f) {
+    if (tr) {                                               // PReLU(BatchNorm(x)) of the rows k = (c, v) of this lane
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c = (int)cg_cols_div((unsigned)(f.kc + s), magicV);
+        const float4 k4 = *reinterpret_cast<const float4*>(sTab + 4 * c);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) f.x[j][s] = cg_prelu((f.x[j][s] - k4.x) * k4.y + k4.z, in_alpha);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
       const float w4[4] = {f.w[i].x * f.mask, f.w[i].y * f.mask, f.w[i].z * f.mask, f.w[i].w * f.mask};
@@ -398,8 +451,23 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRows
 #pragma unroll
       for (int s = 0; s < 4; ++s) xv[tt][s] = xr[tx[tt][s]];
   };
+  const bool tr = t.in_on != 0;                                   // optional input transform: this lane's row k = (c, v) has one channel
+  float tm = 0.f, ts = 1.f, tb = 0.f, ta = 1.f;
+  if (tr) {
+    const CgAff af = cg_tail_aff(t.in_bn, cl, t.C, 0.0, t.in_train, true, false);
+    tm = af.mean; ts = af.gamma * af.rstd; tb = af.beta; ta = t.in_alpha[0];
+  }
+  auto act = [&](float xv[NT][4]) {
+    if (tr) {
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xv[tt][s] = cg_prelu((xv[tt][s] - tm) * ts + tb, ta);
+    }
+  };
   float xa[NT][4], xn[NT][4];
   load_x(b0, xa);
+  act(xa);
   for (int b = b0; b < b1; ++b) {
     const int buf = (b - b0) & 1;
     __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
@@ -444,6 +512,7 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRows
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) xa[tt][s] = xn[tt][s];
+    if (b + 1 < b1) act(xa);
   }
   float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
 #pragma unroll
@@ -480,14 +549,16 @@ extern "C" int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream_) {
   if (st != CG_OK) return st;
   if (!t->y) return CG_EARG;
   a.t = *t;
-  const size_t lds = (size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * 33 * sizeof(float);
+  if (t->in_on && (!t->in_alpha || !t->in_bn.gamma || !t->in_bn.beta || !t->in_bn.save || (t->in_train ? !t->in_bn.stats : !t->in_bn.running_mean))) return CG_EARG;
+  const size_t lds = ((size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * 33 + (size_t)4 * t->C) * sizeof(float);
   const dim3 grid((unsigned)t->B), block(CG_ROWS_FWD_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
+  const unsigned magicT = t->T > 1 ? (unsigned)((0x100000000ULL + t->T - 1) / t->T) : 0u;
 #define CG_ROWS_FWD_LAUNCH(N)                                                                   \
   {                                                                                            \
     hipError_t e = cg_lds_limit((const void*)cg_rows_fwd_kernel<N>, lds);                       \
     if (e != hipSuccess) return (int)e;                                                        \
-    hipLaunchKernelGGL((cg_rows_fwd_kernel<N>), grid, block, lds, stream, a);                    \
+    hipLaunchKernelGGL((cg_rows_fwd_kernel<N>), grid, block, lds, stream, a, magicT);            \
   }
   switch (a.g.OT) {
     case 1: CG_ROWS_FWD_LAUNCH(1) break;
@@ -504,6 +575,7 @@ extern "C" int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream_) {
   int st = cg_rows_geometry(t, &a.g);
   if (st != CG_OK) return st;
   if (!t->dy || !t->dx || !t->dW || !t->ws) return CG_EARG;
+  if (t->in_on && (!t->in_alpha || !t->in_bn.gamma || !t->in_bn.beta || !t->in_bn.save)) return CG_EARG;
   a.t = *t;
   const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * 36) * sizeof(float);
   hipStream_t stream = (hipStream_t)stream_;
@@ -550,7 +622,8 @@ extern "C" int cg_collapse_cols_fwd(const CgRowsConv* t, void* stream_) {
   if (!t->y) return CG_EARG;
   a.t = *t;
   const int nt = cg_cols_nt(t->T);
-  const size_t lds = (size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * (16 * nt + 1) * sizeof(float);
+  if (t->in_on && (!t->in_alpha || !t->in_bn.gamma || !t->in_bn.beta || !t->in_bn.save || (t->in_train ? !t->in_bn.stats : !t->in_bn.running_mean))) return CG_EARG;
+  const size_t lds = ((size_t)(CG_ROWS_FWD_THREADS / 64) * 16 * a.g.OT * (16 * nt + 1) + (size_t)4 * t->C + 4) * sizeof(float);
   const dim3 grid((unsigned)t->B), block(CG_ROWS_FWD_THREADS);
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned magic = cg_cols_magic(t->V);
@@ -570,6 +643,7 @@ extern "C" int cg_collapse_cols_bwd(const CgRowsConv* t, void* stream_) {
   int st = cg_cols_geometry(t, &a.g);
   if (st != CG_OK) return st;
   if (!t->dy || !t->dx || !t->dW || !t->ws) return CG_EARG;
+  if (t->in_on && (!t->in_alpha || !t->in_bn.gamma || !t->in_bn.beta || !t->in_bn.save)) return CG_EARG;
   a.t = *t;
   const int nt = cg_cols_nt(t->T);
   const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * (16 * nt + 4)) * sizeof(float);

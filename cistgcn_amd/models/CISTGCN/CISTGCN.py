@@ -235,6 +235,7 @@ class CISTGCN(nn.Module):
         self.fused_maps = __import__("os").environ.get("CISTGCN_FUSED_MAPS", "1") != "0"
         self.fused_context = __import__("os").environ.get("CISTGCN_FUSED_CONTEXT", "1") != "0"   # ContextLayer heads 1 / 3 without their activations
         self.fused_input = __import__("os").environ.get("CISTGCN_FUSED_INPUT", "1") != "0"   # global_norm + block statistics (and their backward with the fan-in sum) as one operator
+        self.fused_defer = __import__("os").environ.get("CISTGCN_FUSED_DEFER", "1") != "0"    # BatchNorm + PReLU of the first tower level applied by the collapsing kernels on load
         self.fused_cols = __import__("os").environ.get("CISTGCN_FUSED_COLS", "1") != "0"      # (1,V) convolutions of the joint towers through csrc/collapse_rows.hip (cg_collapse_cols_*)
         self.fused_towers = __import__("os").environ.get("CISTGCN_FUSED_TOWERS", "1") != "0"   # first tower level + BatchNorm + PReLU as one operator (backward without the BatchNorm input gradient)
         self.fused_gates = __import__("os").environ.get("CISTGCN_FUSED_GATES", "1") != "0"    # the gate paths behind their (1,V) convolutions as one launch
@@ -489,14 +490,28 @@ class CISTGCN(nn.Module):
         if gates:
             yg = gate_rows if gate_rows is not None else o.pop(0)[0]
             o = [(g.unsqueeze(2), None) for g in ops.split_channels(yg, (O, O))] + o
-        towers_done = None
+        towers_done, tower_tr = None, None
         if stacked:
             tb = [b for a in maps for b in (a.time_compress[1], a.joint_compress[1])]
             tp = [b for a in maps for b in (a.time_compress[2], a.joint_compress[2])]
             if self.fused_towers and ops.tower_maps_ok(x_maps, tower_w, tp):
                 # first level of the four towers with its BatchNorm + PReLU as one operator: backward never stores the gradient in front of
                 # the BatchNorm (the pointwise backward undoes BatchNorm and PReLU while loading)
-                towers_done = ops.tower_maps(x_maps, tower_w, tb, tp, tr)
+                # ... and, when every map goes into a whole-sample collapsing kernel, the BatchNorm + PReLU themselves move into that
+                # kernel's load path: the four activated (B, C/2, T, V) maps are never stored (branch records need them: not then)
+                def _collapse_ok(k, wmap):
+                    a_, tower = maps[k // 2], (maps[k // 2].time_compress if k % 2 == 0 else maps[k // 2].joint_compress)
+                    c_ = tower[3]
+                    probe = torch.empty(0, device=x_maps.device).new_empty((B, wmap.shape[0], T, V))
+                    wv = c_.weight.view(c_.out_channels, c_.in_channels, -1)
+                    if c_.bias is not None:
+                        return False
+                    return ops.collapse_rows_ok(probe, wv) if k % 2 == 0 else (self.fused_cols and ops.collapse_cols_ok(probe, wv))
+                defer = self.fused_defer and self.act_trace is None and big and all(_collapse_ok(k, wmap) for k, wmap in enumerate(tower_w))
+                if defer:
+                    towers_done, tower_tr = ops.tower_maps(x_maps, tower_w, tb, tp, tr, defer=True)
+                else:
+                    towers_done = ops.tower_maps(x_maps, tower_w, tb, tp, tr)
                 if self.act_trace is not None:
                     for mod, h in zip(tp, towers_done):
                         self.act_trace[mod] = (h.detach(), None)
@@ -557,17 +572,19 @@ class CISTGCN(nn.Module):
             x3 = t1[2 * i][0] if isinstance(t1[2 * i], tuple) else t1[2 * i]
             w3 = c3.weight.view(c3.out_channels, c3.in_channels, -1)
             if big and c3.bias is None and ops.collapse_rows_ok(x3, w3):
-                y3, st3 = ops.collapse_rows(x3, w3, tr)                  # whole-sample kernel (csrc/collapse_rows.hip)
+                y3, st3 = ops.collapse_rows(x3, w3, tr, transform=tower_tr[2 * i] if tower_tr else None)      # whole-sample kernel (csrc/collapse_rows.hip)
                 rows3[i] = (y3.unsqueeze(2), st3)
             else:
+                assert tower_tr is None, "a deferred tower map needs its collapsing kernel"
                 items.append(_rows_item(t1[2 * i], c3, tr))
             c4 = a.joint_compress[3]
             x4 = t1[2 * i + 1][0] if isinstance(t1[2 * i + 1], tuple) else t1[2 * i + 1]
             w4 = c4.weight.view(c4.out_channels, c4.in_channels, -1)
             if big and self.fused_cols and c4.bias is None and ops.collapse_cols_ok(x4, w4):
-                y4, st4 = ops.collapse_cols(x4, w4, tr)                  # whole-sample kernel for the joint axis (csrc/collapse_rows.hip)
+                y4, st4 = ops.collapse_cols(x4, w4, tr, transform=tower_tr[2 * i + 1] if tower_tr else None)  # whole-sample kernel for the joint axis
                 cols3[i] = (y4.unsqueeze(3), st4)
             else:
+                assert tower_tr is None, "a deferred tower map needs its collapsing kernel"
                 items.append(_cols_item(t1[2 * i + 1], c4, tr))
         o = _run_items(items)
         if rows3 or cols3:                                               # back into the order gates | (time, joint) per tower

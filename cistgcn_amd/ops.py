@@ -2103,15 +2103,25 @@ class _TowerMaps(torch.autograd.Function):
             t.y[i], t.stats[i] = ys[i].data_ptr(), _ptr(stats[i])
         stream = _stream(x)
         _lib.call("cg_pointwise_maps_fwd", ctypes.byref(t), stream)
-        arr = (NormAct * n)()
-        hs, saves, pending = [], [], []
-        for i in range(n):
-            h, save, _, _ = _na_fill_fwd(arr[i], ys[i], None, None, gammas[i], betas[i], alphas[i],
-                                         {"bn": cfg["bn"][i], "train": train, "stats": stats[i]}, pending)
-            hs.append(h); saves.append(save)
-        assert not pending
-        _lib.call("cg_norm_act_fwd_many", arr, n, stream)
-        ctx.cfg, ctx.n = cfg, n
+        if cfg.get("defer") is not None:
+            # the BatchNorm / PReLU of every map is applied by its consumer while it loads (collapse_rows / collapse_cols with `transform`):
+            # the outputs handed on are the RAW maps, the consumers fill `save` (mean, rstd) and update the running statistics, and their
+            # backward returns the gradient with respect to the ACTIVATED tensor - exactly what this function's backward expects
+            hs = ys
+            saves = [torch.empty(2, w.shape[0], dtype=f32, device=dev) for w in ws]
+            for i in range(n):
+                cfg["defer"].append({"bn": cfg["bn"][i], "gamma": gammas[i], "beta": betas[i], "alpha": alphas[i], "stats": stats[i],
+                                     "save": saves[i], "train": train})
+        else:
+            arr = (NormAct * n)()
+            hs, saves, pending = [], [], []
+            for i in range(n):
+                h, save, _, _ = _na_fill_fwd(arr[i], ys[i], None, None, gammas[i], betas[i], alphas[i],
+                                             {"bn": cfg["bn"][i], "train": train, "stats": stats[i]}, pending)
+                hs.append(h); saves.append(save)
+            assert not pending
+            _lib.call("cg_norm_act_fwd_many", arr, n, stream)
+        ctx.cfg, ctx.n = {"train": cfg["train"], "bn": cfg["bn"]}, n
         ctx.has_alpha, ctx.has_bias = [a is not None for a in alphas], [b is not None for b in bs]
         ctx.save_for_backward(x, *ws, *gammas, *betas, *[a if a is not None else _one(dev) for a in alphas], *ys, *saves)
         return tuple(hs)
@@ -2175,14 +2185,20 @@ def tower_maps_ok(x, weights, prelus):
     return pointwise_maps_ok(x, weights) and all(p is None or p.weight.numel() == 1 for p in prelus)
 
 
-def tower_maps(x, weights, bns, prelus, train, biases=None):
+def tower_maps(x, weights, bns, prelus, train, biases=None, defer=False):
     """[h_i] = PReLU(BN(W_i x + b_i)) for the 1x1 maps `weights` (each (M_i, C)) of x (B,C,H,W) with their BatchNorm2d / PReLU holders
-    (`prelus[i]` None: no PReLU; `biases[i]` None: no bias)."""
+    (`prelus[i]` None: no PReLU; `biases[i]` None: no bias).
+    defer=True (every map with a shared-slope PReLU): returns ([raw maps y_i], [transform_i]) instead - EVERY y_i must then be consumed by
+    exactly one `collapse_rows(y_i, w, stats, transform=transform_i)` or `collapse_cols(...)`, which applies BatchNorm + PReLU while it
+    loads (the activated tensors are never stored)."""
     n = len(weights)
     biases = [None] * n if biases is None else list(biases)
     cfg = {"train": bool(train), "bn": tuple(bns)}
-    return list(_TowerMaps.apply(cfg, n, x, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
-                                 *[None if p is None else p.weight for p in prelus], *biases))
+    if defer:
+        cfg["defer"] = []
+    out = list(_TowerMaps.apply(cfg, n, x, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
+                                *[None if p is None else p.weight for p in prelus], *biases))
+    return (out, cfg["defer"]) if defer else out
 
 
 class _SplitChannels(torch.autograd.Function):
@@ -2237,21 +2253,30 @@ class _CollapseRows(torch.autograd.Function):
     """y[b,o,v] = sum_{c,t} w[o,c,t] x[b,c,t,v] (nn.Conv2d(C, O, (T,1)), CISTGCN.py:138-150 / :331-336), see csrc/collapse_rows.hip"""
 
     @staticmethod
-    def _block(x, w):
+    def _block(x, w, tr=None):
         B, C, T, V = x.shape
         t = _lib.RowsConv()
         t.B, t.C, t.T, t.V, t.O = B, C, T, V, w.shape[0]
         t.x, t.W = x.data_ptr(), w.data_ptr()
+        if tr is not None:                                   # PReLU(BatchNorm(x)) applied on load (`tower_maps(..., defer=True)`)
+            bn = tr["bn"]
+            t.in_on, t.in_train = 1, 1 if tr["train"] else 0
+            t.in_bn.stats, t.in_bn.gamma, t.in_bn.beta = _ptr(tr["stats"]), tr["gamma"].data_ptr(), tr["beta"].data_ptr()
+            t.in_bn.running_mean, t.in_bn.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            t.in_bn.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+            t.in_bn.momentum, t.in_bn.eps, t.in_bn.save = bn.momentum, bn.eps, tr["save"].data_ptr()
+            t.in_alpha = tr["alpha"].data_ptr()
         return t
 
     @staticmethod
-    def forward(ctx, want_stats, x, w):
+    def forward(ctx, want_stats, tr, x, w):
         ctx.set_materialize_grads(False)
         _chk(x)
         w = w if w.is_contiguous() else _copy(w)
         B, C, T, V = x.shape
         O = w.shape[0]
-        t = _CollapseRows._block(x, w)
+        t = _CollapseRows._block(x, w, tr)
+        ctx.tr = tr
         y = torch.empty(B, O, V, dtype=torch.float32, device=x.device)
         stats = _arena(x.device).take(2 * O * _lib.STAT_REPLICAS) if want_stats else None
         t.y, t.stats = y.data_ptr(), _ptr(stats)
@@ -2265,21 +2290,22 @@ class _CollapseRows(torch.autograd.Function):
     def backward(ctx, dy, _=None):
         x, w = ctx.saved_tensors
         if dy is None:
-            return None, None, None
+            return None, None, None, None
         dy = dy if dy.is_contiguous() else _copy(dy)
         B, C, T, V = x.shape
-        t = _CollapseRows._block(x, w)
+        t = _CollapseRows._block(x, w, ctx.tr)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         zb, _z = _zeros(int(_lib.lib().cg_collapse_rows_ws_floats(C, T, w.shape[0])), x.device)
         t.dy, t.dx, t.dW, t.ws = dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), zb.data_ptr()
         _lib.call("cg_collapse_rows_bwd", ctypes.byref(t), _stream(x))
-        return None, dx if ctx.needs_input_grad[1] else None, dw if ctx.needs_input_grad[2] else None
+        return None, None, dx if ctx.needs_input_grad[2] else None, dw if ctx.needs_input_grad[3] else None
 
 
-def collapse_rows(x, w, want_stats=False):
-    """(y (B,O,V), f64 channel sums or None) of the frame-collapsing convolution w (O,C,T) of x (B,C,T,V)."""
-    return _CollapseRows.apply(bool(want_stats), x, w)
+def collapse_rows(x, w, want_stats=False, transform=None):
+    """(y (B,O,V), f64 channel sums or None) of the frame-collapsing convolution w (O,C,T) of x (B,C,T,V); `transform`: x is a raw map of
+    `tower_maps(..., defer=True)`, its BatchNorm + PReLU are applied on load."""
+    return _CollapseRows.apply(bool(want_stats), transform, x, w)
 
 
 def collapse_cols_ok(x, w):
@@ -2294,13 +2320,14 @@ class _CollapseCols(torch.autograd.Function):
     """y[b,o,t] = sum_{c,v} w[o,c,v] x[b,c,t,v] (nn.Conv2d(C, O, (1,V)), CISTGCN.py:152-163), see csrc/collapse_rows.hip"""
 
     @staticmethod
-    def forward(ctx, want_stats, x, w):
+    def forward(ctx, want_stats, tr, x, w):
         ctx.set_materialize_grads(False)
         _chk(x)
         w = w if w.is_contiguous() else _copy(w)
         B, C, T, V = x.shape
         O = w.shape[0]
-        t = _CollapseRows._block(x, w)
+        t = _CollapseRows._block(x, w, tr)
+        ctx.tr = tr
         y = torch.empty(B, O, T, dtype=torch.float32, device=x.device)
         stats = _arena(x.device).take(2 * O * _lib.STAT_REPLICAS) if want_stats else None
         t.y, t.stats = y.data_ptr(), _ptr(stats)
@@ -2314,18 +2341,18 @@ class _CollapseCols(torch.autograd.Function):
     def backward(ctx, dy, _=None):
         x, w = ctx.saved_tensors
         if dy is None:
-            return None, None, None
+            return None, None, None, None
         dy = dy if dy.is_contiguous() else _copy(dy)
         B, C, T, V = x.shape
-        t = _CollapseRows._block(x, w)
+        t = _CollapseRows._block(x, w, ctx.tr)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         zb, _z = _zeros(int(_lib.lib().cg_collapse_cols_ws_floats(C, V, w.shape[0])), x.device)
         t.dy, t.dx, t.dW, t.ws = dy.data_ptr(), dx.data_ptr(), dw.data_ptr(), zb.data_ptr()
         _lib.call("cg_collapse_cols_bwd", ctypes.byref(t), _stream(x))
-        return None, dx if ctx.needs_input_grad[1] else None, dw if ctx.needs_input_grad[2] else None
+        return None, None, dx if ctx.needs_input_grad[2] else None, dw if ctx.needs_input_grad[3] else None
 
 
-def collapse_cols(x, w, want_stats=False):
-    """(y (B,O,T), f64 channel sums or None) of the joint-collapsing convolution w (O,C,V) of x (B,C,T,V)."""
-    return _CollapseCols.apply(bool(want_stats), x, w)
+def collapse_cols(x, w, want_stats=False, transform=None):
+    """(y (B,O,T), f64 channel sums or None) of the joint-collapsing convolution w (O,C,V) of x (B,C,T,V); `transform` as in `collapse_rows`."""
+    return _CollapseCols.apply(bool(want_stats), transform, x, w)

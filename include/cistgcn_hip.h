@@ -248,6 +248,14 @@ typedef struct CgRowsConv {
   float* y; double* stats;          /* stats: optional [CG_STAT_REPLICAS][O][2] f64 sums of y, zero on entry */
   const float* dy; float* dx; float* dW;
   float* ws;                        /* cg_collapse_rows_ws_floats(C, T, O) zeroed floats */
+  /* optional transform of the input on load (in_on != 0): x' = PReLU(BatchNorm2d(x)) over the C input channels with the shared slope
+   * in_alpha[0]: the first level of a Map2Adj tower (CISTGCN.py:138-141 / :156-158) folded into the load path of its collapsing
+   * convolution - the activated tensor is never stored.  Forward: in_bn.stats = f64 channel sums of x (train; workgroup 0 writes
+   * in_bn.save and the running statistics), eval: running statistics.  Backward: in_bn.save; dx is then the gradient with respect to
+   * x' (the BatchNorm / PReLU backward is applied by the producer of x: cg_pointwise_maps_bwd with `yraw`). */
+  int in_on, in_train;
+  CgTailBN in_bn;
+  const float* in_alpha;
 } CgRowsConv;
 int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream);
 int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream);

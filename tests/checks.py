@@ -1113,6 +1113,66 @@ def check_tower_maps(device, shapes=((3, 10, (5, 5, 5, 5), 7, 8), (2, 20, (10, 1
                 assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, k), rel=1e-5)
 
 
+def check_tower_collapse(device, shapes=((3, 10, (8, 8, 8, 8), 6, 8, 5), (2, 64, (32, 32, 32, 32), 50, 22, 32), (3, 16, (8, 8, 8, 8), 10, 18, 20), (2, 12, (16, 12), 5, 6, 7))):
+    """The first tower level DEFERRED into its collapsing convolutions (`ops.tower_maps(defer=True)` + `ops.collapse_rows / collapse_cols`
+    with `transform`: BatchNorm2d + PReLU applied on load, the activated maps never stored) against stock PyTorch in fp64: collapsed outputs,
+    their channel sums, dx, every gradient (map weights, BatchNorm, PReLU slope, collapsing weights), running statistics; train and eval.
+    Maps alternate between the frame-collapsing (T,1) and the joint-collapsing (1,V) convolution.  shapes: (B, Cin, (M_i), T, V, O)."""
+    g = _gen(89)
+    for (B, C, Ms, T, V, O) in shapes:
+        for train in (True, False):
+            def make(dt):
+                gg = _gen(700 + C)
+                mods = []
+                for k, M in enumerate(Ms):
+                    conv, bn, pr = nn.Conv2d(C, M, 1, bias=False), nn.BatchNorm2d(M), nn.PReLU()
+                    col = nn.Conv2d(M, O, (T, 1) if k % 2 == 0 else (1, V), bias=False)
+                    with torch.no_grad():
+                        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gg) * 0.4)
+                        col.weight.copy_(torch.randn(col.weight.shape, generator=gg) * 0.2)
+                        bn.weight.copy_(1 + 0.3 * torch.randn(M, generator=gg)); bn.bias.copy_(0.3 * torch.randn(M, generator=gg))
+                        bn.running_mean.copy_(0.2 * torch.randn(M, generator=gg)); bn.running_var.copy_(0.5 + torch.rand(M, generator=gg))
+                        pr.weight.fill_(0.1 + 0.1 * k)
+                    mods.append(nn.Sequential(conv, bn, pr, col))
+                return nn.ModuleList(mods).to(dt)
+            x0 = 0.3 + _rand(g, B, C, T, V)
+            gs = [_rand(g, B, O, 1, V) if k % 2 == 0 else _rand(g, B, O, T, 1) for k in range(len(Ms))]
+            what = "tower_collapse B%d C%d M%s T%d V%d O%d %s" % (B, C, Ms, T, V, O, "train" if train else "eval")
+            ref = make(torch.float64).train(train)
+            xr = _leaf(x0.double(), "cpu")
+            yr = [m(xr) for m in ref]
+            torch.autograd.backward(yr, [t.double() for t in gs])
+            net = make(torch.float32).to(device).train(train)
+            xd = _leaf(x0, device)
+            ops.begin_step(device)
+            ys, trs = ops.tower_maps(xd, [m[0].weight.view(m[0].out_channels, C) for m in net], [m[1] for m in net], [m[2] for m in net], train, defer=True)
+            outs = []
+            for k, m in enumerate(net):
+                w = m[3].weight.view(O, m[3].in_channels, -1)
+                if k % 2 == 0:
+                    assert ops.collapse_rows_ok(ys[k], w)
+                    y, st = ops.collapse_rows(ys[k], w, want_stats=True, transform=trs[k])
+                    outs.append((y.unsqueeze(2), st))
+                else:
+                    assert ops.collapse_cols_ok(ys[k], w)
+                    y, st = ops.collapse_cols(ys[k], w, want_stats=True, transform=trs[k])
+                    outs.append((y.unsqueeze(3), st))
+            torch.autograd.backward([o for o, _ in outs], [t.to(device) for t in gs])
+            for (a, st), b in zip(outs, yr):
+                assert_close(a, b, what + " output", rel=3e-5)
+                sums = _chan_sums(st).double().cpu().view(-1, 2)
+                bb = b.detach()
+                assert_close(sums[:, 0], bb.sum((0, 2, 3)), what + " sums", rel=1e-4, floor=max(1.0, float(bb.abs().sum((0, 2, 3)).max())))
+            assert_close(xd.grad, xr.grad, what + " dx", rel=5e-5, floor=max(1e-3, float(xr.grad.abs().max())))
+            for (k, pa), (_, pb) in zip(net.named_parameters(), ref.named_parameters()):
+                floor = max(1e-3, float(pb.grad.abs().max()))
+                if train and k.endswith("0.weight"):
+                    floor = max(floor, float(ref[int(k.split(".")[0])][1].weight.grad.abs().max()))
+                assert_close(pa.grad, pb.grad, "%s grad %s" % (what, k), rel=5e-5, floor=floor)
+            for (k, ba), (_, bb) in zip(net.named_buffers(), ref.named_buffers()):
+                assert_close(ba.float(), bb.float(), "%s buffer %s" % (what, k), rel=1e-5)
+
+
 def check_block_input(device, shapes=((3, 5, 4, 6, 3), (2, 10, 10, 22, 7), (4, 64, 5, 22, 8), (2, 6, 5, 5, 2), (3, 3, 22, 25, 4))):
     """ops.block_input (csrc/block_input.hip) against stock PyTorch BatchNorm2d + the oracle's block statistics (CISTGCN.py:360-379):
     the aliases of xn, the statistics, running statistics; backward with a different gradient on every alias and on both statistics

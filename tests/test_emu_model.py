@@ -49,6 +49,13 @@ def test_every_gradient_within_1e4_on_the_same_branches(cfg, mode):
     print("branch replay %s %s: %s" % (cfg, mode, r))
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_model_without_branch_records(mode):
+    """No `act_trace`: the launch plan of production - the first tower level deferred into the collapsing kernels (`tower_maps(defer=True)`),
+    which the branch-replay tests switch off because they need the activated maps.  Kink-free network (all slopes 1), every layer stacked."""
+    checks.check_model_vs_oracle("cpu", 8, 10, 22, 4, mode, smooth=True, stack_all=True)
+
+
 def test_tiny_model_every_gradient_strict():
     checks.check_model_branch_replay("cpu", 4, 4, 5, 3, "train", To=8, hidden=8, grad_floor=0.1, blocks=1, txc=1)   # B=3: batch statistics over two samples are ill-conditioned
 

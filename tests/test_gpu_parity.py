@@ -30,7 +30,7 @@ REL_BOUND = 2e-3
 
 @pytest.mark.parametrize("check", [checks.check_contract, checks.check_norm_act, checks.check_batched_ops, checks.check_dropout,
                                    checks.check_reduce_and_gate, checks.check_copies, checks.check_dilated_convs,
-                                   checks.check_stage_kernels, checks.check_stgcn_domain, checks.check_flat_adam, checks.check_zero_pool, checks.check_contract_kred, checks.check_contract_stream, checks.check_rank1_adj, checks.check_eval_harness, checks.check_contract_chain, checks.check_dstd_tail, checks.check_map2adj_tail, checks.check_pointwise_maps, checks.check_collapse_rows, checks.check_collapse_cols, checks.check_context_heads, checks.check_block_input, checks.check_tower_maps, checks.check_gate_head], ids=lambda f: f.__name__)
+                                   checks.check_stage_kernels, checks.check_stgcn_domain, checks.check_flat_adam, checks.check_zero_pool, checks.check_contract_kred, checks.check_contract_stream, checks.check_rank1_adj, checks.check_eval_harness, checks.check_contract_chain, checks.check_dstd_tail, checks.check_map2adj_tail, checks.check_pointwise_maps, checks.check_collapse_rows, checks.check_collapse_cols, checks.check_tower_collapse, checks.check_context_heads, checks.check_block_input, checks.check_tower_maps, checks.check_gate_head], ids=lambda f: f.__name__)
 def test_operator(check):
     if check is checks.check_context_heads:
         check("cuda", shapes=((3, 5, 12, 7), (4, 25, 66, 64), (2, 3, 10, 33), (64, 25, 66, 64), (16, 25, 75, 64)))
