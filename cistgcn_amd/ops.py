@@ -2110,8 +2110,11 @@ class _TowerMaps(torch.autograd.Function):
             hs = ys
             saves = [torch.empty(2, w.shape[0], dtype=f32, device=dev) for w in ws]
             for i in range(n):
+                if alphas[i] is None or alphas[i].numel() != 1:
+                    raise ValueError("tower_maps(defer=True) needs a shared-slope PReLU behind every map")
                 cfg["defer"].append({"bn": cfg["bn"][i], "gamma": gammas[i], "beta": betas[i], "alpha": alphas[i], "stats": stats[i],
-                                     "save": saves[i], "train": train})
+                                     "save": saves[i], "train": train, "consumed": False})
+            ctx.deferred = cfg["defer"]
         else:
             arr = (NormAct * n)()
             hs, saves, pending = [], [], []
@@ -2133,6 +2136,9 @@ class _TowerMaps(torch.autograd.Function):
         x, ws, gammas, betas, alphas, ys, saves = sv[0], sv[1:1 + n], sv[1 + n:1 + 2 * n], sv[1 + 2 * n:1 + 3 * n], sv[1 + 3 * n:1 + 4 * n], sv[1 + 4 * n:1 + 5 * n], sv[1 + 5 * n:1 + 6 * n]
         if any(d is None for d in dhs):
             raise RuntimeError("tower_maps: every map needs a gradient")
+        if any(not tr["consumed"] for tr in getattr(ctx, "deferred", ())):
+            raise RuntimeError("tower_maps(defer=True): a raw map was not consumed by collapse_rows / collapse_cols with its transform "
+                               "(its BatchNorm statistics were never finalised)")
         dhs = [d if d.is_contiguous() else _copy(d) for d in dhs]
         dev, f32, train = x.device, torch.float32, bool(cfg["train"])
         stream = _stream(x)
@@ -2260,6 +2266,7 @@ class _CollapseRows(torch.autograd.Function):
         t.x, t.W = x.data_ptr(), w.data_ptr()
         if tr is not None:                                   # PReLU(BatchNorm(x)) applied on load (`tower_maps(..., defer=True)`)
             bn = tr["bn"]
+            tr["consumed"] = True                            # the consumer fills `save`: the producer's backward checks that there was one
             t.in_on, t.in_train = 1, 1 if tr["train"] else 0
             t.in_bn.stats, t.in_bn.gamma, t.in_bn.beta = _ptr(tr["stats"]), tr["gamma"].data_ptr(), tr["beta"].data_ptr()
             t.in_bn.running_mean, t.in_bn.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
