@@ -20,4 +20,6 @@ struct CgRowsConv {
   int in_on, in_train;
   CgTailBN in_bn;
   const float* in_alpha;
+  double* in_red;                   // backward, optional (with in_on): [2 C + CG_ALPHA_SLOTS] f64, zero on entry: sums of g = dx' PReLU'(u) and g * xhat per
+                                    // input channel and the slope-gradient partial sums - what cg_norm_act_bwd_reduce would compute from (dx', x) in a pass of its own
 };

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
 // (Round 4 tried this kernel with compile-time OT, dy of the next sample through registers and clamped instead of conditional loads:
 // 90 us instead of 100 on the 64-output gate convolutions, but 152 us instead of 47 on the 32-output tower convolutions; not understood,
 // not shipped.)
+template <bool RD>
 __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRowsArgs a) {
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
   const int K = g.K, V = t.V, O = t.O;
@@ -204,13 +205,37 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
       for (int s = 0; s < 4; ++s) xv[s] = cg_prelu((xv[s] - tm) * ts + tb, ta);
     }
   };
+  // optional reduction of the BatchNorm / PReLU backward (in_red): the raw x at the positions of this lane's dx results (rows k = kw + 4 slot + q,
+  // columns l15 and 16 + l15), requested a sample ahead like the operands; per-row constants; f64 sums per row over the slice
+  const bool rd = RD && tr && t.in_red != nullptr;
+  float qm[4], qr[4], qs[4], qb[4];
+  long long qoff[4];
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, sal = 0.0;
+  const int vA = min(l15, V - 1), vB = min(16 + l15, V - 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = min(kw + 4 * slot + q, K - 1);
+    qoff[q] = (long long)k * V;
+    qm[q] = 0.f; qr[q] = 1.f; qs[q] = 1.f; qb[q] = 0.f;
+    if (rd) {
+      const CgAff af = cg_tail_aff(t.in_bn, k / t.T, t.C, 0.0, t.in_train, true, false);
+      qm[q] = af.mean; qr[q] = af.rstd; qs[q] = af.gamma * af.rstd; qb[q] = af.beta;
+    }
+  }
+  auto load_r = [&](int b, float r0[4], float r1[4]) {
+    const float* xb = t.x + (long long)b * K * V;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { r0[q] = xb[qoff[q] + vA]; r1[q] = xb[qoff[q] + vB]; }
+  };
+  float ra0[4], ra1[4], rn0[4], rn1[4];
+  if (rd) load_r(b0, ra0, ra1);
   float xa[4], xc[4], xna[4], xnc[4];
   load_x(b0, xa, xc);
   act(xa); act(xc);
   for (int b = b0; b < b1; ++b) {
     const int buf = (b - b0) & 1;
     __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
-    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xna, xnc); }
+    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xna, xnc); if (rd) load_r(b + 1, rn0, rn1); }
     const float* dyb = sDY + buf * 16 * g.OT * DS;
     float* dxb = t.dx + (long long)b * K * V;
     // dx[k][v] = sum_o W[o][k] dy[o][v]: rows k of this wave, both halves of v
@@ -232,6 +257,20 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
         if (v1ok) dxb[(long long)k * V + 16 + l15] = c1[q];
       }
     }
+    if (rd) {
+      // g = dx' PReLU'(u), u = BatchNorm(x): rows k >= K and columns v >= V carry dx' = 0 (zero columns of sW, zero padding of dy)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float xr = h ? ra1[q] : ra0[q], dh = h ? c1[q] : c0[q];
+          const float d = xr - qm[q], u = d * qs[q] + qb[q];
+          const float gh = u > 0.f ? dh : ta * dh;
+          s1[q] += (double)gh; s2[q] += (double)gh * (double)(d * qr[q]);
+          if (!(u > 0.f)) sal += (double)dh * (double)u;
+        }
+      }
+    }
     // dW[o][k] += sum_v dy[o][v] x[k][v]: A[i = o][kk = v] from LDS (float4 along v), B[kk = v][j = k] = this lane's x values
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -249,6 +288,32 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_rows_bwd_kernel(CgRows
 #pragma unroll
     for (int s = 0; s < 4; ++s) { xa[s] = xna[s]; xc[s] = xnc[s]; }
     if (b + 1 < b1) { act(xa); act(xc); }
+    if (rd) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ra0[q] = rn0[q]; ra1[q] = rn1[q]; }
+    }
+  }
+  if (rd) {
+    // the 16 lanes of a DPP row hold the same four rows k: their sums first, then one f64 word per (row, sum) into the workgroup's
+    // per-channel words (a 64-row range spans 64 / T + 2 channels at most), then one global atomic per channel and workgroup
+    __syncthreads();
+    double* sR = reinterpret_cast<double*>(sDY);                  // dy images are dead: [CG_ROWS_KB + 1][2] f64 + [1]
+    const int c_lo = min(k0, K - 1) / t.T, c_hi = min(k0 + CG_ROWS_KB - 1, K - 1) / t.T, nch = c_hi - c_lo + 1;
+    for (int e = tid; e < 2 * nch + 1; e += CG_ROWS_BWD_THREADS) sR[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double a1 = cg_row16_sum(s1[q]), a2 = cg_row16_sum(s2[q]);
+      if (l15 == 0) {
+        const int c = min(kw + 4 * slot + q, K - 1) / t.T - c_lo;
+        atomicAdd(&sR[2 * c], a1); atomicAdd(&sR[2 * c + 1], a2);
+      }
+    }
+    sal = cg_wave_sum(sal);
+    if (lane == 0) atomicAdd(&sR[2 * nch], sal);
+    __syncthreads();
+    for (int e = tid; e < 2 * nch; e += CG_ROWS_BWD_THREADS) atomicAdd(&t.in_red[2 * c_lo + e], sR[e]);
+    if (tid == 0) atomicAdd(&t.in_red[2 * t.C + ((kr + 5 * sl) & (CG_ALPHA_SLOTS - 1))], sR[2 * nch]);
   }
   float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
 #pragma unroll
@@ -391,7 +456,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRows
   }
 }
 
-template <int OT, int NT>
+template <int OT, int NT, bool RD>
 __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRowsArgs a, unsigned magicV) {
   const CgRowsConv& t = a.t; const CgRowsGeom& g = a.g;
   const int K = g.K, V = t.V, T = t.T, O = t.O, TV = T * V;
@@ -465,13 +530,38 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRows
         for (int s = 0; s < 4; ++s) xv[tt][s] = cg_prelu((xv[tt][s] - tm) * ts + tb, ta);
     }
   };
+  // optional reduction of the BatchNorm / PReLU backward (in_red), as in cg_rows_bwd_kernel: raw x at the positions of this lane's dx results
+  const bool rd = RD && tr && t.in_red != nullptr;
+  float qm[4], qr[4], qs[4], qb[4];
+  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, sal = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    qm[q] = 0.f; qr[q] = 1.f; qs[q] = 1.f; qb[q] = 0.f;
+    if (rd) {
+      const int kc = min(kw + 4 * slot + q, K - 1);
+      const CgAff af = cg_tail_aff(t.in_bn, (int)cg_cols_div((unsigned)kc, magicV), t.C, 0.0, t.in_train, true, false);
+      qm[q] = af.mean; qr[q] = af.rstd; qs[q] = af.gamma * af.rstd; qb[q] = af.beta;
+    }
+  }
+  int tcol[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) tcol[j] = min(16 * j + l15, T - 1) * V;
+  auto load_r = [&](int b, float r[NT][4]) {
+    const float* xb = t.x + (long long)b * K * T;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[j][q] = xb[doff[q] + tcol[j]];
+  };
+  float ra[NT][4], rn[NT][4];
+  if (rd) load_r(b0, ra);
   float xa[NT][4], xn[NT][4];
   load_x(b0, xa);
   act(xa);
   for (int b = b0; b < b1; ++b) {
     const int buf = (b - b0) & 1;
     __syncthreads();                                              // dy[b] is in sDY[buf]; the other buffer is free
-    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xn); }
+    if (b + 1 < b1) { stage_dy(b + 1, buf ^ 1); load_x(b + 1, xn); if (rd) load_r(b + 1, rn); }
     const float* dyb = sDY + buf * 16 * OT * DS;
     float* dxb = t.dx + (long long)b * K * T;
     // dx[k][t] = sum_o W[o][k] dy[o][t]: rows k of this wave, NT tiles of frames
@@ -497,6 +587,17 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRows
           if (dok[q]) dxb[doff[q] + tt * V] = c[j][q];
       }
     }
+    if (rd) {                                                     // rows k >= K and frames t >= T carry dx' = 0
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dh = c[j][q], d = ra[j][q] - qm[q], u = d * qs[q] + qb[q];
+          const float gh = u > 0.f ? dh : ta * dh;
+          s1[q] += (double)gh; s2[q] += (double)gh * (double)(d * qr[q]);
+          if (!(u > 0.f)) sal += (double)dh * (double)u;
+        }
+    }
     // dW[o][k] += sum_t dy[o][t] x[k][t]: A[i = o][kk = t] from LDS (float4 along t), B[kk = t][j = k] = this lane's x values
 #pragma unroll
     for (int i = 0; i < OT; ++i) {
@@ -513,6 +614,32 @@ __global__ __launch_bounds__(CG_ROWS_BWD_THREADS) void cg_cols_bwd_kernel(CgRows
 #pragma unroll
       for (int s = 0; s < 4; ++s) xa[tt][s] = xn[tt][s];
     if (b + 1 < b1) act(xa);
+    if (rd) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[j][q] = rn[j][q];
+    }
+  }
+  if (rd) {
+    __syncthreads();
+    double* sR = reinterpret_cast<double*>(sDY);                  // dy images are dead: [channels of the range][2] f64 + [1]
+    const int c_lo = (int)cg_cols_div((unsigned)min(k0, K - 1), magicV), c_hi = (int)cg_cols_div((unsigned)min(k0 + CG_ROWS_KB - 1, K - 1), magicV), nch = c_hi - c_lo + 1;
+    for (int e = tid; e < 2 * nch + 1; e += CG_ROWS_BWD_THREADS) sR[e] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double a1 = cg_row16_sum(s1[q]), a2 = cg_row16_sum(s2[q]);
+      if (l15 == 0) {
+        const int cc = (int)cg_cols_div((unsigned)min(kw + 4 * slot + q, K - 1), magicV) - c_lo;
+        atomicAdd(&sR[2 * cc], a1); atomicAdd(&sR[2 * cc + 1], a2);
+      }
+    }
+    sal = cg_wave_sum(sal);
+    if (lane == 0) atomicAdd(&sR[2 * nch], sal);
+    __syncthreads();
+    for (int e = tid; e < 2 * nch; e += CG_ROWS_BWD_THREADS) atomicAdd(&t.in_red[2 * c_lo + e], sR[e]);
+    if (tid == 0) atomicAdd(&t.in_red[2 * t.C + ((kr + 5 * sl) & (CG_ALPHA_SLOTS - 1))], sR[2 * nch]);
   }
   float* ws = t.ws + (long long)(sl % CG_ROWS_REPLICAS) * O * K;
 #pragma unroll
@@ -579,7 +706,8 @@ extern "C" int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream_) {
   a.t = *t;
   const size_t lds = ((size_t)16 * a.g.OT * (CG_ROWS_KB + 4) + (size_t)2 * 16 * a.g.OT * 36) * sizeof(float);
   hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(cg_rows_bwd_kernel, dim3((unsigned)a.g.kranges, (unsigned)a.g.slices), dim3(CG_ROWS_BWD_THREADS), lds, stream, a);
+  if (t->in_on && t->in_red) hipLaunchKernelGGL((cg_rows_bwd_kernel<true>), dim3((unsigned)a.g.kranges, (unsigned)a.g.slices), dim3(CG_ROWS_BWD_THREADS), lds, stream, a);
+  else hipLaunchKernelGGL((cg_rows_bwd_kernel<false>), dim3((unsigned)a.g.kranges, (unsigned)a.g.slices), dim3(CG_ROWS_BWD_THREADS), lds, stream, a);
   st = cg_launch_status();
   if (st != CG_OK) return st;
   hipLaunchKernelGGL(cg_rows_fold_kernel, dim3(128), dim3(256), 0, stream, a);
@@ -652,9 +780,15 @@ extern "C" int cg_collapse_cols_bwd(const CgRowsConv* t, void* stream_) {
   const unsigned magic = cg_cols_magic(t->V);
 #define CG_COLS_BWD_LAUNCH(N, M)                                                                \
   {                                                                                            \
-    hipError_t e = cg_lds_limit((const void*)cg_cols_bwd_kernel<N, M>, lds);                    \
-    if (e != hipSuccess) return (int)e;                                                        \
-    hipLaunchKernelGGL((cg_cols_bwd_kernel<N, M>), grid, block, lds, stream, a, magic);          \
+    if (t->in_on && t->in_red) {                                                               \
+      hipError_t e = cg_lds_limit((const void*)cg_cols_bwd_kernel<N, M, true>, lds);             \
+      if (e != hipSuccess) return (int)e;                                                      \
+      hipLaunchKernelGGL((cg_cols_bwd_kernel<N, M, true>), grid, block, lds, stream, a, magic);  \
+    } else {                                                                                   \
+      hipError_t e = cg_lds_limit((const void*)cg_cols_bwd_kernel<N, M, false>, lds);            \
+      if (e != hipSuccess) return (int)e;                                                      \
+      hipLaunchKernelGGL((cg_cols_bwd_kernel<N, M, false>), grid, block, lds, stream, a, magic); \
+    }                                                                                          \
   }
   CG_COLS_DISPATCH(a.g.OT, nt, CG_COLS_BWD_LAUNCH)
 #undef CG_COLS_BWD_LAUNCH

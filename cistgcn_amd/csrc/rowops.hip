@@ -582,6 +582,20 @@ extern "C" int cg_norm_act_bwd_reduce_many(const CgNormAct* arr, int n, void* st
   return cg_launch_status();
 }
 
+// include/cistgcn_hip.h : cg_norm_act_params_many - dgamma / dbeta / dalpha from `red` alone, for a consumer whose producer-side kernel
+// has filled `red` already (cg_collapse_rows_bwd / cg_collapse_cols_bwd with in_red): no pass over the tensors at all
+extern "C" int cg_norm_act_params_many(const CgNormAct* arr, int n, void* stream_) {
+  if (!arr || n <= 0 || n > CG_ROW_MAX_BATCH) return CG_EARG;
+  CgNormActBatch batch;
+  batch.n = n; batch.pad = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!arr[i].red) return CG_EARG;
+    batch.a[i] = arr[i]; batch.rb[i] = 1; batch.vec[i] = 0;
+  }
+  hipLaunchKernelGGL(cg_norm_act_params_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream_, batch);
+  return cg_launch_status();
+}
+
 extern "C" int cg_norm_act_fwd(const CgNormAct* a, void* stream_) { return cg_norm_act_fwd_many(a, 1, stream_); }
 
 extern "C" int cg_norm_act_bwd(const CgNormAct* a, int need_reduce, void* stream_) {

@@ -4,6 +4,7 @@ is produced by a HIP kernel.  Views (permute / reshape / slicing) are metadata o
 take strides, so layout changes of the reference (`CISTGCN.py:582,588,592,595`) cost nothing.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -2144,7 +2145,7 @@ class _TowerMaps(torch.autograd.Function):
         stream = _stream(x)
         # pass 1: channel sums of the gradient in front of the BatchNorm, slope gradients, dgamma / dbeta
         arr = (NormAct * n)()
-        reds, smalls = [], []
+        reds, smalls, have_red = [], [], []
         for i in range(n):
             a, bn = arr[i], cfg["bn"][i]
             M = ws[i].shape[0]
@@ -2157,13 +2158,24 @@ class _TowerMaps(torch.autograd.Function):
             nal = alphas[i].numel() if ctx.has_alpha[i] else 0
             if nal:
                 a.alpha, a.alpha_n = alphas[i].data_ptr(), nal
-            red = _arena(dev).take(2 * M + (_lib.ALPHA_SLOTS if nal <= 1 else nal))
+            given = ctx.deferred[i].get("red") if getattr(ctx, "deferred", None) else None
+            red = given if given is not None else _arena(dev).take(2 * M + (_lib.ALPHA_SLOTS if nal <= 1 else nal))
+            have_red.append(given is not None)
             small = torch.empty(3, M, dtype=f32, device=dev)
             a.red, a.dgamma, a.dbeta = red.data_ptr(), small[0].data_ptr(), small[1].data_ptr()
             if nal:
                 a.dalpha = small[2].data_ptr()
             reds.append(red); smalls.append(small)
-        _lib.call("cg_norm_act_bwd_reduce_many", arr, n, stream)
+        if all(have_red):
+            _lib.call("cg_norm_act_params_many", arr, n, stream)        # the consumers' backward kernels summed already: parameter gradients only
+        else:
+            if any(have_red):                                           # mixed: redo all of them here (fresh words for the ones already summed)
+                for i in range(n):
+                    if have_red[i]:
+                        nal = alphas[i].numel() if ctx.has_alpha[i] else 0
+                        reds[i] = _arena(dev).take(2 * ws[i].shape[0] + (_lib.ALPHA_SLOTS if nal <= 1 else nal))
+                        arr[i].red = reds[i].data_ptr()
+            _lib.call("cg_norm_act_bwd_reduce_many", arr, n, stream)
         # pass 2: dx and dW_i (db_i) with BatchNorm / PReLU undone on load
         t = _PointwiseMaps._block(x, ws, [None] * n)
         dx = torch.empty_like(x)
@@ -2247,6 +2259,13 @@ def split_channels(y, sizes):
 _ROWS_KERNELS = __import__("os").environ.get("CISTGCN_ROWS_KERNELS", "1") != "0"     # 0: the generic contraction (tuning aid)
 
 
+# BatchNorm / PReLU backward sums of a deferred tower map from the collapsing backward kernel (`in_red`) instead of cg_norm_act_bwd_reduce_many.
+# OFF by default: measured at the headline shape the two backward kernels grow from 48 / 55 to 71 / 82 us per call (228 / 286 VGPRs: the raw
+# x of the result positions travels a sample ahead, nine f64 sums per lane), more than the 65 us reduction pass per block they replace.
+# `transform["fold_reduce"] = True` selects it per map (tests/checks.py::check_tower_collapse does for one shape).
+_FOLD_REDUCE = os.environ.get("CISTGCN_FOLD_REDUCE", "0") == "1"
+
+
 def collapse_rows_ok(x, w):
     """True when `collapse_rows` takes the (T,1) convolution `w` (O,C,T) of x (B,C,T,V)."""
     if not _ROWS_KERNELS or x.dim() != 4 or not x.is_contiguous() or w.dim() != 3:
@@ -2301,6 +2320,11 @@ class _CollapseRows(torch.autograd.Function):
         dy = dy if dy.is_contiguous() else _copy(dy)
         B, C, T, V = x.shape
         t = _CollapseRows._block(x, w, ctx.tr)
+        if ctx.tr is not None and ctx.tr.get("fold_reduce", _FOLD_REDUCE):
+            # the reduction pass of the BatchNorm / PReLU backward (sums of g, g * xhat, slope gradient) is done here, where dx' is produced
+            red = _arena(x.device).take(2 * C + _lib.ALPHA_SLOTS)
+            t.in_red = red.data_ptr()
+            ctx.tr["red"] = red
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         zb, _z = _zeros(int(_lib.lib().cg_collapse_rows_ws_floats(C, T, w.shape[0])), x.device)
@@ -2352,6 +2376,11 @@ class _CollapseCols(torch.autograd.Function):
         dy = dy if dy.is_contiguous() else _copy(dy)
         B, C, T, V = x.shape
         t = _CollapseRows._block(x, w, ctx.tr)
+        if ctx.tr is not None and ctx.tr.get("fold_reduce", _FOLD_REDUCE):
+            # the reduction pass of the BatchNorm / PReLU backward (sums of g, g * xhat, slope gradient) is done here, where dx' is produced
+            red = _arena(x.device).take(2 * C + _lib.ALPHA_SLOTS)
+            t.in_red = red.data_ptr()
+            ctx.tr["red"] = red
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
         zb, _z = _zeros(int(_lib.lib().cg_collapse_cols_ws_floats(C, V, w.shape[0])), x.device)

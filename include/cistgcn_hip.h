@@ -126,6 +126,9 @@ int cg_norm_act_bwd_many(const CgNormAct* arr, const int* need_reduce, int n, vo
 /* pass 1 of the backward alone (channel sums, slope gradient) + dgamma / dbeta / dalpha: for a consumer that applies the BatchNorm / PReLU
  * backward itself while loading the gradient (cg_pointwise_maps_bwd with yraw) */
 int cg_norm_act_bwd_reduce_many(const CgNormAct* arr, int n, void* stream);
+/* dgamma / dbeta / dalpha from `red` alone: the reduction was done by the kernel that produced the gradient (cg_collapse_rows_bwd /
+ * cg_collapse_cols_bwd with in_red); reads xv.n[1] (channels), bn_mode, red, alpha / alpha_n, dgamma / dbeta / dalpha of each problem */
+int cg_norm_act_params_many(const CgNormAct* arr, int n, void* stream);
 
 /* per-(b,c) mean (kind 0), max with first arg-max (kind 1) or sum (kind 2) over the positions; adjoints of 0/1.
  * Replaces AdaptiveAvgPool (SE.py:8,27; CISTGCN.py:69,76), .max(-1)[0] chains and .mean((2,3))
@@ -256,6 +259,8 @@ typedef struct CgRowsConv {
   int in_on, in_train;
   CgTailBN in_bn;
   const float* in_alpha;
+  double* in_red;                   /* backward, optional (with in_on): [2 C + CG_ALPHA_SLOTS] f64, zero on entry: sums of g = dx' PReLU'(u) and g * xhat per input
+                                     * channel + the slope-gradient partial sums (the reduction pass of the BatchNorm / PReLU backward, done where dx' is produced) */
 } CgRowsConv;
 int cg_collapse_rows_fwd(const CgRowsConv* t, void* stream);
 int cg_collapse_rows_bwd(const CgRowsConv* t, void* stream);
