@@ -205,16 +205,23 @@ __global__ __launch_bounds__(CG_BIN_THREADS) void cg_bin_bwd_sum_kernel(CgBlockI
   float* __restrict__ gp = t.gsum + base;
   int cur = -1;
   double s1 = 0.0, s2 = 0.0;
+  const float* gsrc[CG_BIN_MAXG];                               // the consumers' gradients at this workgroup's span (null: none), read once
+#pragma unroll
+  for (int i = 0; i < CG_BIN_MAXG; ++i) gsrc[i] = (i < t.ng && t.g[i]) ? t.g[i] + base : nullptr;
   for (int e = tid * VW; e < L; e += CG_BIN_THREADS * VW) {
     float x[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
     cg_bin_ld<VW>(xp + e, x);
+    // every gradient's vector is REQUESTED before the first one is added: with the add right behind its load the kernel made up to eight
+    // memory round trips one after the other per vector (load - wait - add, found in the ISA in round 4)
+    float gv[CG_BIN_MAXG][4];
+#pragma unroll
+    for (int i = 0; i < CG_BIN_MAXG; ++i)
+      if (gsrc[i]) cg_bin_ld<VW>(gsrc[i] + e, gv[i]);
 #pragma unroll
     for (int i = 0; i < CG_BIN_MAXG; ++i) {
-      if (i < t.ng && t.g[i]) {
-        float gv[4];
-        cg_bin_ld<VW>(t.g[i] + base + e, gv);
+      if (gsrc[i]) {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) acc[j] += gv[j];
+        for (int j = 0; j < VW; ++j) acc[j] += gv[i][j];
       }
     }
     const int pl = cg_bin_div(e, g.magicTV);                    // TV % VW == 0: a vector never straddles two planes
