@@ -240,7 +240,7 @@ class CISTGCN(nn.Module):
         self.fused_towers = __import__("os").environ.get("CISTGCN_FUSED_TOWERS", "1") != "0"   # first tower level + BatchNorm + PReLU as one operator (backward without the BatchNorm input gradient)
         self.fused_gates = __import__("os").environ.get("CISTGCN_FUSED_GATES", "1") != "0"    # the gate paths behind their (1,V) convolutions as one launch
         self.fused_res_maps = True   # the residual 1x1 convolutions (with bias) of a width-changing block through the stacked kernel too
-        self.stack_min_elements = 1 << 21      # block inputs smaller than this keep one contraction per first-level map
+        self.stack_min_elements = int(__import__("os").environ.get("CISTGCN_STACK_MIN_ELEMENTS", str(1 << 21)))      # block inputs smaller than this keep one contraction per first-level map
         # The reference edits the config lists in place (CISTGCN.py:514-517,548); copies are used here
         # so that one `opt` can build several models.
         widths = [self.in_ch] + list(p.input_gcn.model_complexity) + [self.in_ch]
