@@ -293,6 +293,52 @@ def test_cpu_tensors_are_refused():
         ops.feature_lift(torch.zeros(2, 10, 22, 3))
 
 
+def test_deferred_tower_level_matches_stored_maps():
+    """The production launch plan - first tower level deferred into the collapsing kernels (BatchNorm + PReLU applied on load, the
+    activated maps never stored; `CISTGCN.fused_defer`) - against the plan the branch-replay tests use (maps stored), at a size where the
+    whole-sample kernels run, train mode with dropout 0.1, the same seed: the same function evaluated twice in fp32.  The oracle tests at
+    full size record PReLU branches and therefore run the stored plan; operator-level parity of the deferred plan against fp64 PyTorch is
+    `checks.check_tower_collapse`.  Criterion between two fp32 runs as in the graph-replay test (kink flips are legitimate, a wrong
+    transform would show as tens of per cent)."""
+    from cistgcn_amd import ops
+    C, T, V, B = 64, 50, 22, 32
+    net, _ = checks.build_pair(C, T, V, "cuda", dropout=0.1)
+    net.train()
+    g = torch.Generator().manual_seed(7)
+    x = (50 + 350 * torch.randn(B, T, V, 3, generator=g)).cuda()
+    tgt = (x[:, -1:].cpu() + 20 * torch.randn(B, 25, V, 3, generator=g)).cuda()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    runs = []
+    for defer in (True, False):
+        net.load_state_dict(sd)
+        net.zero_grad()
+        net.fused_defer = defer
+        ops.manual_seed(4321, torch.device("cuda"))
+        calls = []
+        orig = ops.tower_maps
+        ops.tower_maps = lambda *a, **k: (calls.append(bool(k.get("defer"))), orig(*a, **k))[1]
+        try:
+            pred, = net(x)
+            loss = ops.mpjpe(pred, tgt)
+            loss.backward()
+        finally:
+            ops.tower_maps = orig
+        assert any(calls) == defer, "the deferred plan must (not) be taken: %s" % calls
+        runs.append((loss.item(), pred.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()},
+                     {k: b.clone() for k, b in net.named_buffers()}))
+    (l0, p0, g0, b0), (l1, p1, g1, b1) = runs
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l1))
+    assert float((p0 - p1).abs().max()) <= 1e-4 * max(1.0, float(p1.abs().max()))
+    for k in g1:
+        a, r = g0[k].double().cpu(), g1[k].double().cpu()
+        mx = float(r.abs().max())
+        assert float((a - r).abs().max()) <= 1e-3 * max(1.0, mx), k
+        if mx >= 1e-4 and r.numel() >= 64:
+            assert float((a - r).norm() / r.norm().clamp_min(1e-30)) <= 2e-2, "%s: relative L2 %.3e" % (k, float((a - r).norm() / r.norm()))
+    for k in b1:                                          # running statistics: the collapsing kernels keep the books of the deferred BatchNorms
+        assert torch.allclose(b0[k].float(), b1[k].float(), rtol=1e-5, atol=1e-6), k
+
+
 @pytest.mark.parametrize("branches,cfg", [(False, (8, 10, 22, 4)), (True, (8, 10, 22, 4)), (False, (64, 50, 22, 64)), (True, (64, 50, 22, 64))], ids=str)
 def test_graph_replay_matches_eager(branches, cfg):
     """fwd+loss+bwd captured in a HIP graph replays to the same numbers (bench.py's step); `branches`: the independent branches of a
