@@ -123,7 +123,7 @@ class RowsConv(ctypes.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("T", c_int), ("V", c_int), ("O", c_int), ("pad", c_int),
                 ("x", c_void_p), ("W", c_void_p), ("y", c_void_p), ("stats", c_void_p),
                 ("dy", c_void_p), ("dx", c_void_p), ("dW", c_void_p), ("ws", c_void_p),
-                ("in_on", c_int), ("in_train", c_int), ("in_bn", TailBN), ("in_alpha", c_void_p), ("in_red", c_void_p)]
+                ("in_on", c_int), ("in_train", c_int), ("in_bn", TailBN), ("in_alpha", c_void_p), ("in_tap", c_void_p), ("in_red", c_void_p)]
 
 
 class BlockInput(ctypes.Structure):

@@ -20,6 +20,8 @@ struct CgRowsConv {
   int in_on, in_train;
   CgTailBN in_bn;
   const float* in_alpha;
+  float* in_tap;                    // forward, optional (with in_on): the activated input x' (B,C,T,V), written as it is formed - for the PReLU branch
+                                    // records of the parity tests (production never asks for it: not storing x' is the point)
   double* in_red;                   // backward, optional (with in_on): [2 C + CG_ALPHA_SLOTS] f64, zero on entry: sums of g = dx' PReLU'(u) and g * xhat per
                                     // input channel and the slope-gradient partial sums - what cg_norm_act_bwd_reduce would compute from (dx', x) in a pass of its own
 };

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, slot = lane >> 4;
   const bool tr = t.in_on != 0;
   const float in_alpha = tr ? t.in_alpha[0] : 1.f;
+  float* const tapb = (tr && t.in_tap) ? t.in_tap + (long long)b * K * V : nullptr;
   if (tr) {
     for (int c = tid; c < t.C; c += CG_ROWS_FWD_THREADS) {
       const CgAff af = cg_tail_aff(t.in_bn, c, t.C, (double)t.B * t.T * V, t.in_train, false, blockIdx.x == 0);
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_rows_fwd_kernel(CgRows
         const float4 k4 = *reinterpret_cast<const float4*>(sTab + 4 * c);
         f.x0[s] = cg_prelu((f.x0[s] - k4.x) * k4.y + k4.z, in_alpha);
         f.x1[s] = cg_prelu((f.x1[s] - k4.x) * k4.y + k4.z, in_alpha);
+        if (tapb && f.mask != 0.f) {                        // every element of x[b] is held by exactly one lane (clamped lanes repeat a neighbour's value)
+          tapb[(long long)(f.kc + s) * V + vA] = f.x0[s];
+          tapb[(long long)(f.kc + s) * V + vB] = f.x1[s];
+        }
       }
     }
 #pragma unroll
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRows
   float* sTab = sY + nw * 16 * OT * YS;                           // [C][4] input transform: mean, gamma * rstd, beta, -
   const bool tr = t.in_on != 0;
   const float in_alpha = tr ? t.in_alpha[0] : 1.f;
+  float* const tapb = (tr && t.in_tap) ? t.in_tap + (long long)b * K * T : nullptr;
   if (tr) {
     for (int c = tid; c < t.C; c += CG_ROWS_FWD_THREADS) {
       const CgAff af = cg_tail_aff(t.in_bn, c, t.C, (double)t.B * T * V, t.in_train, false, blockIdx.x == 0);
@@ -404,6 +410,11 @@ __global__ __launch_bounds__(CG_ROWS_FWD_THREADS) void cg_cols_fwd_kernel(CgRows
         const float4 k4 = *reinterpret_cast<const float4*>(sTab + 4 * c);
 #pragma unroll
         for (int j = 0; j < NT; ++j) f.x[j][s] = cg_prelu((f.x[j][s] - k4.x) * k4.y + k4.z, in_alpha);
+        if (tapb && f.mask != 0.f) {
+          const int v = f.kc + s - c * V;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) tapb[c * TV + toff[j] + v] = f.x[j][s];
+        }
       }
     }
 #pragma unroll

@@ -498,7 +498,7 @@ class CISTGCN(nn.Module):
                 # first level of the four towers with its BatchNorm + PReLU as one operator: backward never stores the gradient in front of
                 # the BatchNorm (the pointwise backward undoes BatchNorm and PReLU while loading)
                 # ... and, when every map goes into a whole-sample collapsing kernel, the BatchNorm + PReLU themselves move into that
-                # kernel's load path: the four activated (B, C/2, T, V) maps are never stored (branch records need them: not then)
+                # kernel's load path: the four activated (B, C/2, T, V) maps are never stored (unless branch records are asked for: `in_tap`)
                 def _collapse_ok(k, wmap):
                     a_, tower = maps[k // 2], (maps[k // 2].time_compress if k % 2 == 0 else maps[k // 2].joint_compress)
                     c_ = tower[3]
@@ -507,14 +507,17 @@ class CISTGCN(nn.Module):
                     if c_.bias is not None:
                         return False
                     return ops.collapse_rows_ok(probe, wv) if k % 2 == 0 else (self.fused_cols and ops.collapse_cols_ok(probe, wv))
-                defer = self.fused_defer and self.act_trace is None and big and all(_collapse_ok(k, wmap) for k, wmap in enumerate(tower_w))
+                defer = self.fused_defer and big and all(_collapse_ok(k, wmap) for k, wmap in enumerate(tower_w))
                 if defer:
                     towers_done, tower_tr = ops.tower_maps(x_maps, tower_w, tb, tp, tr, defer=True)
+                    if self.act_trace is not None:                       # branch records: the collapsing kernels write the activated maps out as well
+                        for tr_ in tower_tr:
+                            tr_["want_tap"] = True
                 else:
                     towers_done = ops.tower_maps(x_maps, tower_w, tb, tp, tr)
-                if self.act_trace is not None:
-                    for mod, h in zip(tp, towers_done):
-                        self.act_trace[mod] = (h.detach(), None)
+                    if self.act_trace is not None:
+                        for mod, h in zip(tp, towers_done):
+                            self.act_trace[mod] = (h.detach(), None)
                 o = o[:2] + [None] * 4 + o[2:]
             else:
                 o = o[:2] + ops.pointwise_maps(x_maps, tower_w, tr) + o[2:]
@@ -586,6 +589,10 @@ class CISTGCN(nn.Module):
             else:
                 assert tower_tr is None, "a deferred tower map needs its collapsing kernel"
                 items.append(_cols_item(t1[2 * i + 1], c4, tr))
+        if tower_tr and self.act_trace is not None:
+            tp_ = [b_ for a_ in maps for b_ in (a_.time_compress[2], a_.joint_compress[2])]
+            for mod, tr_ in zip(tp_, tower_tr):
+                self.act_trace[mod] = (tr_["tap"].detach(), None)
         o = _run_items(items)
         if rows3 or cols3:                                               # back into the order gates | (time, joint) per tower
             rest, o = o[2:], o[:2]

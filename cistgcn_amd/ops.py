@@ -2292,6 +2292,9 @@ class _CollapseRows(torch.autograd.Function):
             t.in_bn.num_batches_tracked = bn.num_batches_tracked.data_ptr()
             t.in_bn.momentum, t.in_bn.eps, t.in_bn.save = bn.momentum, bn.eps, tr["save"].data_ptr()
             t.in_alpha = tr["alpha"].data_ptr()
+            if tr.get("want_tap") and "tap" not in tr:           # forward only: the activated input, for branch records (tests)
+                tr["tap"] = torch.empty_like(x)
+                t.in_tap = tr["tap"].data_ptr()
         return t
 
     @staticmethod

@@ -259,6 +259,7 @@ typedef struct CgRowsConv {
   int in_on, in_train;
   CgTailBN in_bn;
   const float* in_alpha;
+  float* in_tap;                    /* forward, optional (with in_on): the activated input x' (B,C,T,V), written as it is formed (branch records of the parity tests) */
   double* in_red;                   /* backward, optional (with in_on): [2 C + CG_ALPHA_SLOTS] f64, zero on entry: sums of g = dx' PReLU'(u) and g * xhat per input
                                      * channel + the slope-gradient partial sums (the reduction pass of the BatchNorm / PReLU backward, done where dx' is produced) */
 } CgRowsConv;
